@@ -1,0 +1,822 @@
+// libgoblin_host.so -- scene front end: Goblin JSON + OBJ -> gbl_scene_desc.
+//
+// Host-side mirror of the reference's ContextLoader for the hot-path subset
+// (/root/reference/src/GoblinContextLoader.cpp:33-504).  Same keys, same
+// defaults, same int-vs-float strictness of ParamSet, same "first definition of
+// a name wins" map semantics (SceneCache::add* use std::map::insert,
+// GoblinScene.cpp:130-158).  Where the reference silently substitutes its
+// magenta/unit-sphere error objects for a missing name (GoblinScene.cpp:170-226)
+// this loader fails with GBL_ERR_INVALID and a message instead -- there is no
+// sphere primitive on the device path to stand in with.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/goblin_hip.h"
+#include "json_lite.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+gbl_status fail(gbl_status code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------
+// ParamSet: a strictly typed bag (GoblinParamSet.cpp:100-161,
+// GoblinContextLoader.cpp:33-65).  An integer literal is only visible to
+// get_int, a float literal only to get_float; 2/3/4-element arrays become
+// vectors with elements narrowed to float; nested objects are ignored.
+// ---------------------------------------------------------------------------
+struct Vec {
+    float v[4] = {0, 0, 0, 0};
+};
+
+struct Params {
+    std::map<std::string, bool> bools;
+    std::map<std::string, int> ints;
+    std::map<std::string, float> floats;
+    std::map<std::string, std::string> strings;
+    std::map<std::string, Vec> vec2s, vec3s, vec4s;
+
+    explicit Params(const gbl_json::Value* obj = nullptr) {
+        if (!obj || obj->kind != gbl_json::Value::Object) return;
+        for (const auto& kv : obj->obj) {
+            const gbl_json::Value& v = kv.second;
+            switch (v.kind) {
+                case gbl_json::Value::Bool: bools.insert({kv.first, v.b}); break;
+                case gbl_json::Value::Int: ints.insert({kv.first, static_cast<int>(v.i)}); break;
+                case gbl_json::Value::Float: floats.insert({kv.first, static_cast<float>(v.d)}); break;
+                case gbl_json::Value::String: strings.insert({kv.first, v.s}); break;
+                case gbl_json::Value::Array: {
+                    size_t n = v.arr.size();
+                    if (n < 2 || n > 4) break;
+                    Vec vec;
+                    bool ok = true;
+                    for (size_t i = 0; i < n; ++i) {
+                        if (!v.arr[i].is_number()) ok = false;
+                        else vec.v[i] = v.arr[i].as_float();
+                    }
+                    if (!ok) break;
+                    (n == 2 ? vec2s : n == 3 ? vec3s : vec4s).insert({kv.first, vec});
+                    break;
+                }
+                default: break;
+            }
+        }
+    }
+    bool has_string(const std::string& k) const { return strings.count(k) != 0; }
+    bool has_vec3(const std::string& k) const { return vec3s.count(k) != 0; }
+    int get_int(const std::string& k, int d = 0) const {
+        auto it = ints.find(k);
+        return it == ints.end() ? d : it->second;
+    }
+    float get_float(const std::string& k, float d = 0.0f) const {
+        auto it = floats.find(k);
+        return it == floats.end() ? d : it->second;
+    }
+    std::string get_string(const std::string& k, const std::string& d = "") const {
+        auto it = strings.find(k);
+        return it == strings.end() ? d : it->second;
+    }
+    Vec get_vec(const std::map<std::string, Vec>& m, const std::string& k, Vec d) const {
+        auto it = m.find(k);
+        return it == m.end() ? d : it->second;
+    }
+};
+
+Vec vec(float a, float b = 0, float c = 0, float d = 0) {
+    Vec r;
+    r.v[0] = a; r.v[1] = b; r.v[2] = c; r.v[3] = d;
+    return r;
+}
+
+const float kPi = 3.14159265358979323f;  // GoblinUtils.h:43
+float radians(float deg) { return kPi * (deg / 180.0f); }  // GoblinUtils.h:132-134
+
+// ---------------------------------------------------------------------------
+// Quaternion helpers needed at load time only: "euler" orientations
+// (GoblinUtils.cpp:78-90, GoblinQuaternion.cpp:8-14,124-149).
+// ---------------------------------------------------------------------------
+struct Quat {
+    float w, x, y, z;
+};
+
+Quat quat_axis_angle(int axis, float angle) {
+    float t = angle * 0.5f;
+    float ax[3] = {0, 0, 0};
+    ax[axis] = 1.0f;
+    // normalize(axis): v / length, i.e. multiply by 1/len
+    float inv = 1.0f / std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    float s = std::sin(t);
+    Quat q;
+    q.w = std::cos(t);
+    q.x = ax[0] * inv * s;
+    q.y = ax[1] * inv * s;
+    q.z = ax[2] * inv * s;
+    return q;
+}
+
+Quat quat_mul(const Quat& a, const Quat& b) {
+    // Quaternion(w*rw - dot(v,rv), w*rv + rw*v + cross(v,rv))   GoblinQuaternion.h:45-48
+    Quat r;
+    r.w = a.w * b.w - (a.x * b.x + a.y * b.y + a.z * b.z);
+    float cx = a.y * b.z - a.z * b.y;
+    float cy = a.z * b.x - a.x * b.z;
+    float cz = a.x * b.y - a.y * b.x;
+    r.x = a.w * b.x + b.w * a.x + cx;
+    r.y = a.w * b.y + b.w * a.y + cy;
+    r.z = a.w * b.z + b.w * a.z + cz;
+    return r;
+}
+
+bool read_orientation(const Params& p, float out[4], std::string* err) {
+    if (p.has_vec3("euler")) {
+        Vec e = p.get_vec(p.vec3s, "euler", vec(0, 0, 0));
+        std::string order = p.get_string("rotation_order", "xyz");
+        Quat qx = quat_axis_angle(0, radians(e.v[0]));
+        Quat qy = quat_axis_angle(1, radians(e.v[1]));
+        Quat qz = quat_axis_angle(2, radians(e.v[2]));
+        Quat r;
+        if (order == "xzy") r = quat_mul(quat_mul(qy, qz), qx);
+        else if (order == "yxz") r = quat_mul(quat_mul(qz, qx), qy);
+        else if (order == "yzx") r = quat_mul(quat_mul(qx, qz), qy);
+        else if (order == "zxy") r = quat_mul(quat_mul(qy, qx), qz);
+        else if (order == "zyx") r = quat_mul(quat_mul(qx, qy), qz);
+        else r = quat_mul(quat_mul(qz, qy), qx);  // "xyz" and the unrecognised fallback
+        out[0] = r.w; out[1] = r.x; out[2] = r.y; out[3] = r.z;
+    } else {
+        Vec q = p.get_vec(p.vec4s, "orientation", vec(1, 0, 0, 0));
+        for (int i = 0; i < 4; ++i) out[i] = q.v[i];
+    }
+    (void)err;
+    return true;
+}
+
+void read_trs(const Params& p, gbl_trs* t) {
+    Vec pos = p.get_vec(p.vec3s, "position", vec(0, 0, 0));
+    Vec scl = p.get_vec(p.vec3s, "scale", vec(1, 1, 1));
+    for (int i = 0; i < 3; ++i) {
+        t->position[i] = pos.v[i];
+        t->scale[i] = scl.v[i];
+    }
+    std::string err;
+    read_orientation(p, t->orientation, &err);
+}
+
+// ---------------------------------------------------------------------------
+// OBJ loader: v / vn / vt / f with triangles and quads, format fixed by the
+// first face, python-style negative indices, (v,vn,vt) de-duplicated in face
+// order (GoblinPolygonMesh.cpp:58-262).
+// ---------------------------------------------------------------------------
+struct MeshData {
+    std::vector<float> pos, nrm, uv;
+    std::vector<uint32_t> idx;
+    bool has_normal = false, has_uv = false;
+};
+
+struct Corner {
+    int v, n, t;
+    bool operator<(const Corner& o) const {
+        if (v != o.v) return v < o.v;
+        if (n != o.n) return n < o.n;
+        return t < o.t;
+    }
+};
+
+bool load_obj(const std::string& path, MeshData* mesh, std::string* err) {
+    std::ifstream file(path.c_str());
+    if (!file.is_open()) {
+        *err = "can't open obj file: " + path;
+        return false;
+    }
+    std::vector<float> vs, ns, ts;
+    std::vector<Corner> corners;  // 3 per face
+    enum { V_ONLY, V_UV, V_N, V_UV_N } format = V_ONLY;
+    bool first_face = true;
+    std::string line;
+    int line_no = 0;
+    while (std::getline(file, line)) {
+        ++line_no;
+        std::istringstream ss(line);
+        std::string tok;
+        ss >> tok;
+        if (tok == "v" || tok == "vn") {
+            float x, y, z;
+            ss >> x >> y >> z;
+            if (ss.fail()) {
+                *err = path + ": syntax error on line " + std::to_string(line_no);
+                return false;
+            }
+            std::vector<float>& dst = tok == "v" ? vs : ns;
+            dst.push_back(x); dst.push_back(y); dst.push_back(z);
+        } else if (tok == "vt") {
+            float u, v;
+            ss >> u >> v;
+            if (ss.fail()) {
+                *err = path + ": uv syntax error on line " + std::to_string(line_no);
+                return false;
+            }
+            ts.push_back(u); ts.push_back(v);
+        } else if (tok == "f") {
+            std::vector<std::string> ft;
+            std::string t;
+            while (ss >> t) ft.push_back(t);
+            if (ft.size() < 3 || ft.size() > 4) {
+                *err = path + ": incorrect face vertices number on line " + std::to_string(line_no);
+                return false;
+            }
+            if (first_face) {
+                first_face = false;
+                const std::string& f0 = ft[0];
+                size_t p1 = f0.find('/');
+                if (f0.find("//") != std::string::npos) {
+                    format = V_N;
+                    mesh->has_normal = true;
+                } else if (p1 == std::string::npos) {
+                    format = V_ONLY;
+                } else if (p1 == f0.rfind('/')) {
+                    format = V_UV;
+                    mesh->has_uv = true;
+                } else {
+                    format = V_UV_N;
+                    mesh->has_normal = true;
+                    mesh->has_uv = true;
+                }
+            }
+            Corner c[4];
+            for (size_t i = 0; i < ft.size(); ++i) {
+                const char* s = ft[i].c_str();
+                c[i].v = atoi(s);
+                c[i].n = 0;
+                c[i].t = 0;
+                if (format == V_UV || format == V_UV_N) {
+                    s += strcspn(s, "/") + 1;
+                    c[i].t = atoi(s);
+                    if (format == V_UV_N) {
+                        s += strcspn(s, "/") + 1;
+                        c[i].n = atoi(s);
+                    }
+                } else if (format == V_N) {
+                    s += strcspn(s, "/") + 2;
+                    c[i].n = atoi(s);
+                }
+            }
+            corners.push_back(c[0]); corners.push_back(c[1]); corners.push_back(c[2]);
+            if (ft.size() == 4) {
+                corners.push_back(c[0]); corners.push_back(c[2]); corners.push_back(c[3]);
+            }
+        }
+    }
+    int nv = static_cast<int>(vs.size() / 3), nn = static_cast<int>(ns.size() / 3),
+        nt = static_cast<int>(ts.size() / 2);
+    for (Corner& c : corners) {
+        if (c.v < 0) c.v += nv + 1;
+        if (c.n < 0) c.n += nn + 1;
+        if (c.t < 0) c.t += nt + 1;
+        --c.v; --c.n; --c.t;
+        if (c.v < 0 || c.v >= nv || c.n < -1 || c.n >= nn || c.t < -1 || c.t >= nt) {
+            *err = path + ": invalid index in face";
+            return false;
+        }
+    }
+    std::map<Corner, uint32_t> seen;
+    for (const Corner& c : corners) {
+        auto ins = seen.insert({c, static_cast<uint32_t>(seen.size())});
+        if (ins.second) {
+            for (int k = 0; k < 3; ++k) mesh->pos.push_back(vs[3 * c.v + k]);
+            for (int k = 0; k < 3; ++k) mesh->nrm.push_back(c.n < 0 ? 0.0f : ns[3 * c.n + k]);
+            for (int k = 0; k < 2; ++k) mesh->uv.push_back(c.t < 0 ? 0.0f : ts[2 * c.t + k]);
+        }
+        mesh->idx.push_back(ins.first->second);
+    }
+    return true;
+}
+
+std::string read_file(const std::string& path, bool* ok) {
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f.is_open()) {
+        *ok = false;
+        return "";
+    }
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    *ok = true;
+    return ss.str();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// The loaded scene: owns the arrays gbl_scene_desc points into.
+// ---------------------------------------------------------------------------
+struct gbl_host_scene {
+    std::vector<float> positions, normals, uvs;
+    std::vector<uint32_t> indices;
+    std::vector<gbl_mesh> meshes;
+    std::vector<gbl_material> materials;
+    std::vector<gbl_instance> instances;
+    std::vector<gbl_light> lights;
+    gbl_scene_desc desc;
+};
+
+namespace {
+
+struct GeometryDecl {
+    std::string type, file;
+    int mesh_id = -1;
+};
+struct TextureDecl {
+    std::string format, type;
+    float color[3] = {0, 0, 0};
+    float value = 0.5f;
+};
+struct ModelDecl {
+    bool is_instance = false;
+    std::string geometry, material, area_light;
+};
+
+class Loader {
+public:
+    Loader(const gbl_json::Value& root, const std::string& dir, gbl_host_scene* out)
+        : root_(root), dir_(dir), s_(out) {}
+
+    gbl_status run() {
+        gbl_status st;
+        if ((st = read_setting()) != GBL_OK) return st;
+        if ((st = read_camera()) != GBL_OK) return st;
+        if (root_.find("volume")) return fail(GBL_ERR_UNSUPPORTED, "participating media (\"volume\") are outside the device path");
+        read_geometries();
+        read_textures();
+        if ((st = read_primitives()) != GBL_OK) return st;
+        if ((st = read_lights()) != GBL_OK) return st;
+        finish();
+        return GBL_OK;
+    }
+
+private:
+    const gbl_json::Value& root_;
+    std::string dir_;
+    gbl_host_scene* s_;
+    std::map<std::string, GeometryDecl> geometries_;
+    std::map<std::string, TextureDecl> textures_;
+    std::map<std::string, int> material_ids_;  // resolved materials by name
+    std::map<std::string, ModelDecl> primitives_;
+    std::map<std::string, int> area_lights_;   // name -> light index
+
+    std::string resolve(const std::string& f) const {
+        if (!f.empty() && (f[0] == '/' || (f.size() > 1 && f[1] == ':'))) return f;
+        return dir_ + "/" + f;
+    }
+
+    const gbl_json::Value* list(const char* key) const {
+        const gbl_json::Value* v = root_.find(key);
+        return (v && v->kind == gbl_json::Value::Array) ? v : nullptr;
+    }
+
+    // createRenderer (GoblinContextLoader.cpp:67-92) + createPathTracer / createAO
+    gbl_status read_setting() {
+        Params p(root_.find("render_setting"));
+        std::string method = p.get_string("render_method", "path_tracing");
+        gbl_render_setting& rs = s_->desc.setting;
+        if (method == "ao") {
+            rs.integrator = GBL_INTEGRATOR_AO;
+        } else if (method == "whitted" || method == "light_tracing" || method == "bdpt" || method == "sppm") {
+            return fail(GBL_ERR_UNSUPPORTED, "render_method \"" + method + "\" is outside the device path (path_tracing and ao only)");
+        } else {
+            rs.integrator = GBL_INTEGRATOR_PATH;  // "path_tracing" and the unknown-string fallback
+        }
+        rs.sample_per_pixel = p.get_int("sample_per_pixel", 1);
+        rs.max_ray_depth = std::max(1, p.get_int("max_ray_depth", 5));
+        rs.bssrdf_sample_num = p.get_int("bssrdf_sample_num", 4);
+        rs.ao_sample_num = p.get_int("ao_sample_num", 25);
+        rs.thread_num = p.get_int("thread_num", 0);
+        return GBL_OK;
+    }
+
+    // createCamera / createFilm / createFilter (GoblinContextLoader.cpp:94-187)
+    gbl_status read_camera() {
+        const gbl_json::Value* cam = root_.find("camera");
+        Params p(cam);
+        std::string type = p.get_string("type");
+        if (type == "orthographic") return fail(GBL_ERR_UNSUPPORTED, "orthographic camera is outside the device path");
+        gbl_camera& c = s_->desc.camera;
+        Vec pos = p.get_vec(p.vec3s, "position", vec(0, 0, 0));
+        for (int i = 0; i < 3; ++i) c.position[i] = pos.v[i];
+        std::string err;
+        read_orientation(p, c.orientation, &err);
+        c.fov_degrees = p.get_float("fov", 60.0f);
+        c.near_plane = p.get_float("near_plane", 0.1f);
+        c.far_plane = p.get_float("far_plane", 1000.0f);
+        c.lens_radius = p.get_float("lens_radius", 0.0f);
+        c.focal_distance = p.get_float("focal_distance", 1.0f);
+        if (c.lens_radius != 0.0f)
+            return fail(GBL_ERR_UNSUPPORTED, "thin-lens camera (lens_radius != 0) adds a Disk primitive to the scene; outside the device path");
+
+        Params fp(cam ? cam->find("film") : nullptr);
+        gbl_film& f = s_->desc.film;
+        Vec res = fp.get_vec(fp.vec2s, "resolution", vec(512, 512));
+        f.xres = static_cast<int>(res.v[0]);
+        f.yres = static_cast<int>(res.v[1]);
+        Vec crop = fp.get_vec(fp.vec4s, "crop", vec(0, 1, 0, 1));
+        for (int i = 0; i < 4; ++i) f.crop[i] = crop.v[i];
+        if (f.xres <= 0 || f.yres <= 0) return fail(GBL_ERR_INVALID, "film resolution must be positive");
+
+        Params flt(cam ? cam->find("filter") : nullptr);
+        std::string ft = flt.get_string("type");
+        Vec w = flt.get_vec(flt.vec2s, "width", vec(1.0f, 1.0f));
+        f.filter_width[0] = w.v[0];
+        f.filter_width[1] = w.v[1];
+        f.gaussian_falloff = flt.get_float("falloff", 2.0f);
+        f.mitchell_b = flt.get_float("b", 2.0f);
+        f.mitchell_c = flt.get_float("c", 2.0f);
+        if (ft == "box") f.filter_type = GBL_FILTER_BOX;
+        else if (ft == "triangle") f.filter_type = GBL_FILTER_TRIANGLE;
+        else if (ft == "mitchell") f.filter_type = GBL_FILTER_MITCHELL;
+        else f.filter_type = GBL_FILTER_GAUSSIAN;
+        return GBL_OK;
+    }
+
+    void read_geometries() {
+        const gbl_json::Value* l = list("geometries");
+        if (!l) return;
+        for (const gbl_json::Value& g : l->arr) {
+            Params p(&g);
+            GeometryDecl d;
+            d.type = p.get_string("type");
+            d.file = p.get_string("file");
+            geometries_.insert({p.get_string("name"), d});
+        }
+    }
+
+    void read_textures() {
+        const gbl_json::Value* l = list("textures");
+        if (!l) return;
+        for (const gbl_json::Value& t : l->arr) {
+            Params p(&t);
+            TextureDecl d;
+            d.type = p.get_string("type");
+            d.format = p.get_string("format", "color");
+            Vec c = p.get_vec(p.vec3s, "color", vec(0, 0, 0));
+            for (int i = 0; i < 3; ++i) d.color[i] = c.v[i];
+            d.value = p.get_float("float", 0.5f);
+            // color and float textures live in separate maps in the reference
+            textures_.insert({d.format + ":" + p.get_string("name"), d});
+        }
+    }
+
+    gbl_status color_texture(const std::string& name, float out[3]) {
+        auto it = textures_.find("color:" + name);
+        if (it == textures_.end()) return fail(GBL_ERR_INVALID, "Texture " + name + " not defined!");
+        const std::string& t = it->second.type;
+        if (t == "checkerboard" || t == "scale" || t == "image")
+            return fail(GBL_ERR_UNSUPPORTED, "texture type \"" + t + "\" is outside the device path (constant only)");
+        for (int i = 0; i < 3; ++i) out[i] = it->second.color[i];
+        return GBL_OK;
+    }
+
+    gbl_status float_texture(const std::string& name, float* out) {
+        auto it = textures_.find("float:" + name);
+        if (it == textures_.end()) return fail(GBL_ERR_INVALID, "Texture " + name + " not defined!");
+        const std::string& t = it->second.type;
+        if (t == "checkerboard" || t == "scale" || t == "image")
+            return fail(GBL_ERR_UNSUPPORTED, "texture type \"" + t + "\" is outside the device path (constant only)");
+        *out = it->second.value;
+        return GBL_OK;
+    }
+
+    // createMaterials (GoblinContextLoader.cpp:309-350) + the create*Material
+    // factories (GoblinMaterial.cpp:825-877), resolved on first use.
+    gbl_status material_id(const std::string& name, int* out) {
+        auto hit = material_ids_.find(name);
+        if (hit != material_ids_.end()) {
+            *out = hit->second;
+            return GBL_OK;
+        }
+        const gbl_json::Value* l = list("materials");
+        const gbl_json::Value* decl = nullptr;
+        if (l) {
+            for (const gbl_json::Value& m : l->arr) {
+                Params p(&m);
+                if (p.get_string("name") == name) {
+                    decl = &m;
+                    break;  // first definition wins
+                }
+            }
+        }
+        if (!decl) return fail(GBL_ERR_INVALID, "Material " + name + " not defined!");
+        Params p(decl);
+        if (p.has_string("bumpmap") || p.has_string("normalmap"))
+            return fail(GBL_ERR_UNSUPPORTED, "bump/normal maps are outside the device path");
+        std::string type = p.get_string("type");
+        gbl_material m;
+        memset(&m, 0, sizeof(m));
+        gbl_status st;
+        if (type == "blinn") {
+            m.type = GBL_MAT_BLINN;
+            if ((st = color_texture(p.get_string("Kg"), m.color)) != GBL_OK) return st;
+            if ((st = float_texture(p.get_string("exponent"), &m.exponent)) != GBL_OK) return st;
+            m.index = p.get_float("index", 1.5f);
+            m.k = p.get_float("k", -1.0f);
+        } else if (type == "transparent") {
+            m.type = GBL_MAT_TRANSPARENT;
+            if ((st = color_texture(p.get_string("Kr"), m.color)) != GBL_OK) return st;
+            if ((st = color_texture(p.get_string("Kt"), m.color2)) != GBL_OK) return st;
+            m.index = p.get_float("index", 1.5f);
+        } else if (type == "mirror") {
+            m.type = GBL_MAT_MIRROR;
+            if ((st = color_texture(p.get_string("Kr"), m.color)) != GBL_OK) return st;
+            m.index = p.get_float("index", 0.8f);
+            m.k = p.get_float("k", 6.0f);
+        } else if (type == "subsurface" || type == "mask") {
+            return fail(GBL_ERR_UNSUPPORTED, "material type \"" + type + "\" is outside the device path");
+        } else {  // "lambert" and the unknown-type fallback
+            m.type = GBL_MAT_LAMBERT;
+            if ((st = color_texture(p.get_string("Kd"), m.color)) != GBL_OK) return st;
+        }
+        *out = static_cast<int>(s_->materials.size());
+        s_->materials.push_back(m);
+        material_ids_[name] = *out;
+        return GBL_OK;
+    }
+
+    gbl_status mesh_id(const std::string& geometry, int* out) {
+        auto it = geometries_.find(geometry);
+        if (it == geometries_.end()) return fail(GBL_ERR_INVALID, "Geometry " + geometry + " not defined!");
+        GeometryDecl& g = it->second;
+        if (g.type != "mesh") return fail(GBL_ERR_UNSUPPORTED, "geometry type \"" + g.type + "\" is outside the device path (mesh only)");
+        if (g.mesh_id < 0) {
+            MeshData md;
+            std::string err;
+            if (!load_obj(resolve(g.file), &md, &err)) return fail(GBL_ERR_IO, err);
+            if (md.idx.empty()) return fail(GBL_ERR_INVALID, "mesh " + g.file + " has no faces");
+            gbl_mesh m;
+            m.vertex_offset = static_cast<uint32_t>(s_->positions.size() / 3);
+            m.vertex_count = static_cast<uint32_t>(md.pos.size() / 3);
+            m.tri_offset = static_cast<uint32_t>(s_->indices.size() / 3);
+            m.tri_count = static_cast<uint32_t>(md.idx.size() / 3);
+            m.has_normal = md.has_normal;
+            m.has_uv = md.has_uv;
+            s_->positions.insert(s_->positions.end(), md.pos.begin(), md.pos.end());
+            s_->normals.insert(s_->normals.end(), md.nrm.begin(), md.nrm.end());
+            s_->uvs.insert(s_->uvs.end(), md.uv.begin(), md.uv.end());
+            s_->indices.insert(s_->indices.end(), md.idx.begin(), md.idx.end());
+            g.mesh_id = static_cast<int>(s_->meshes.size());
+            s_->meshes.push_back(m);
+        }
+        *out = g.mesh_id;
+        return GBL_OK;
+    }
+
+    // createPrimitives (GoblinContextLoader.cpp:352-387): models and instances
+    // share one name map; only instances reach the scene (:381-383, :498).
+    gbl_status read_primitives() {
+        const gbl_json::Value* l = list("primitives");
+        if (!l) return GBL_OK;
+        for (const gbl_json::Value& pv : l->arr) {
+            Params p(&pv);
+            std::string type = p.get_string("type");
+            std::string name = p.get_string("name");
+            if (type == "instance") {
+                gbl_status st = add_instance(p, -1);
+                if (st != GBL_OK) return st;
+                ModelDecl d;
+                d.is_instance = true;
+                primitives_.insert({name, d});
+            } else {  // "model" and the unknown-type fallback
+                ModelDecl d;
+                d.geometry = p.get_string("geometry");
+                d.material = p.get_string("material");
+                d.area_light = p.get_string("area_light");
+                primitives_.insert({name, d});
+            }
+        }
+        return GBL_OK;
+    }
+
+    gbl_status add_instance(const Params& p, int area_light) {
+        std::string model = p.get_string("model");
+        auto it = primitives_.find(model);
+        if (it == primitives_.end()) return fail(GBL_ERR_INVALID, "Primitive " + model + " not defined!");
+        if (it->second.is_instance) return fail(GBL_ERR_UNSUPPORTED, "instance of an instance (\"" + model + "\") is outside the device path");
+        const ModelDecl& m = it->second;
+        // A user model's "area_light" can never resolve in the reference: models
+        // are created before lights (GoblinContextLoader.cpp:494-495), so
+        // SceneCache::getAreaLight falls back to its nullptr entry
+        // (GoblinScene.cpp:219-226).  Mirror that: not emissive.
+        if (!m.area_light.empty() && area_light < 0) {
+            auto al = area_lights_.find(m.area_light);
+            if (al != area_lights_.end()) area_light = al->second;
+        }
+        gbl_instance inst;
+        memset(&inst, 0, sizeof(inst));
+        int mesh, mat;
+        gbl_status st;
+        if ((st = mesh_id(m.geometry, &mesh)) != GBL_OK) return st;
+        if ((st = material_id(m.material, &mat)) != GBL_OK) return st;
+        inst.mesh = mesh;
+        inst.material = mat;
+        inst.area_light = area_light;
+        read_trs(p, &inst.to_world);
+        s_->instances.push_back(inst);
+        return GBL_OK;
+    }
+
+    // createLights (GoblinContextLoader.cpp:389-445) + factories
+    // (GoblinLight.cpp:630-676).
+    gbl_status read_lights() {
+        const gbl_json::Value* l = list("lights");
+        if (!l) return GBL_OK;
+        for (const gbl_json::Value& lv : l->arr) {
+            Params p(&lv);
+            std::string type = p.get_string("type");
+            std::string name = p.get_string("name");
+            gbl_light lt;
+            memset(&lt, 0, sizeof(lt));
+            lt.to_world.orientation[0] = 1.0f;
+            lt.to_world.scale[0] = lt.to_world.scale[1] = lt.to_world.scale[2] = 1.0f;
+            if (type == "directional" || type == "ibl") {
+                return fail(GBL_ERR_UNSUPPORTED, "light type \"" + type + "\" is outside the device path");
+            } else if (type == "spot") {
+                lt.type = GBL_LIGHT_SPOT;
+                Vec I = p.get_vec(p.vec3s, "intensity", vec(0, 0, 0));
+                Vec P = p.get_vec(p.vec3s, "position", vec(0, 0, 0));
+                float dir[3];
+                if (p.has_vec3("target")) {
+                    Vec T = p.get_vec(p.vec3s, "target", vec(0, 0, 0));
+                    float d[3] = {T.v[0] - P.v[0], T.v[1] - P.v[1], T.v[2] - P.v[2]};
+                    float inv = 1.0f / std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    for (int i = 0; i < 3; ++i) dir[i] = d[i] * inv;
+                } else {
+                    Vec D = p.get_vec(p.vec3s, "direction", vec(0, 0, 0));
+                    for (int i = 0; i < 3; ++i) dir[i] = D.v[i];
+                }
+                for (int i = 0; i < 3; ++i) {
+                    lt.color[i] = I.v[i];
+                    lt.position[i] = P.v[i];
+                    lt.direction[i] = dir[i];
+                }
+                lt.cos_theta_max = std::cos(radians(p.get_float("theta_max")));
+                lt.cos_falloff_start = std::cos(radians(p.get_float("falloff_start")));
+            } else if (type == "area") {
+                lt.type = GBL_LIGHT_AREA;
+                Vec R = p.get_vec(p.vec3s, "radiance", vec(0, 0, 0));
+                for (int i = 0; i < 3; ++i) lt.color[i] = R.v[i];
+                int mesh;
+                gbl_status st = mesh_id(p.get_string("geometry"), &mesh);
+                if (st != GBL_OK) return st;
+                lt.mesh = mesh;
+                read_trs(p, &lt.to_world);
+            } else {  // "point" and the unknown-type fallback
+                lt.type = GBL_LIGHT_POINT;
+                Vec I = p.get_vec(p.vec3s, "intensity", vec(0, 0, 0));
+                Vec P = p.get_vec(p.vec3s, "position", vec(0, 0, 0));
+                for (int i = 0; i < 3; ++i) {
+                    lt.color[i] = I.v[i];
+                    lt.position[i] = P.v[i];
+                }
+            }
+            int light_index = static_cast<int>(s_->lights.size());
+            s_->lights.push_back(lt);
+            if (type == "area") {
+                // the loader auto-creates an emissive model (black lambert) and
+                // instances it with the light's own transform (:419-441)
+                area_lights_.insert({name, light_index});
+                gbl_material black;
+                memset(&black, 0, sizeof(black));
+                black.type = GBL_MAT_LAMBERT;
+                gbl_instance inst;
+                memset(&inst, 0, sizeof(inst));
+                inst.mesh = lt.mesh;
+                inst.material = static_cast<uint32_t>(s_->materials.size());
+                s_->materials.push_back(black);
+                inst.area_light = light_index;
+                inst.to_world = lt.to_world;
+                s_->instances.push_back(inst);
+            }
+        }
+        return GBL_OK;
+    }
+
+    void finish() {
+        gbl_scene_desc& d = s_->desc;
+        d.abi_version = GBL_ABI_VERSION;
+        d.num_vertices = static_cast<uint32_t>(s_->positions.size() / 3);
+        d.positions = s_->positions.data();
+        d.normals = s_->normals.data();
+        d.uvs = s_->uvs.data();
+        d.num_triangles = static_cast<uint32_t>(s_->indices.size() / 3);
+        d.indices = s_->indices.data();
+        d.num_meshes = static_cast<uint32_t>(s_->meshes.size());
+        d.meshes = s_->meshes.data();
+        d.num_materials = static_cast<uint32_t>(s_->materials.size());
+        d.materials = s_->materials.data();
+        d.num_instances = static_cast<uint32_t>(s_->instances.size());
+        d.instances = s_->instances.data();
+        d.num_lights = static_cast<uint32_t>(s_->lights.size());
+        d.lights = s_->lights.data();
+    }
+};
+
+int round_to_square(int n) {
+    int s = static_cast<int>(std::ceil(std::sqrt(static_cast<float>(n))));
+    return s * s;
+}
+
+}  // namespace
+
+extern "C" {
+
+gbl_status gbl_host_load_string(const char* json_text, const char* scene_dir, gbl_host_scene** out) {
+    if (!json_text || !out) return fail(GBL_ERR_INVALID, "null argument");
+    *out = nullptr;
+    gbl_json::Value root;
+    std::string err;
+    gbl_json::Parser parser(json_text, strlen(json_text));
+    if (!parser.parse(&root, &err)) return fail(GBL_ERR_IO, "json parse error: " + err);
+    if (root.kind != gbl_json::Value::Object) return fail(GBL_ERR_IO, "scene json must be an object");
+    gbl_host_scene* s = new gbl_host_scene();
+    memset(&s->desc, 0, sizeof(s->desc));
+    Loader loader(root, scene_dir ? scene_dir : ".", s);
+    gbl_status st = loader.run();
+    if (st != GBL_OK) {
+        delete s;
+        return st;
+    }
+    *out = s;
+    return GBL_OK;
+}
+
+gbl_status gbl_host_load_file(const char* json_path, gbl_host_scene** out) {
+    if (!json_path || !out) return fail(GBL_ERR_INVALID, "null argument");
+    *out = nullptr;
+    bool ok;
+    std::string text = read_file(json_path, &ok);
+    if (!ok) return fail(GBL_ERR_IO, std::string("error reading scene file: ") + json_path);
+    std::string path(json_path), dir = ".";
+    size_t cut = path.find_last_of('/');
+    if (cut == std::string::npos) cut = path.find_last_of('\\');
+    if (cut != std::string::npos) dir = path.substr(0, cut);
+    return gbl_host_load_string(text.c_str(), dir.c_str(), out);
+}
+
+const gbl_scene_desc* gbl_host_desc(const gbl_host_scene* scene) { return scene ? &scene->desc : nullptr; }
+
+void gbl_host_free(gbl_host_scene* scene) { delete scene; }
+
+const char* gbl_host_last_error(void) { return g_last_error.c_str(); }
+
+void gbl_host_sample_window(const gbl_film* film, int32_t out[4]) {
+    // Film ctor + Film::getSampleRange (GoblinFilm.cpp:92-112,131-138)
+    int xs = static_cast<int>(std::ceil(film->xres * film->crop[0]));
+    int xc = std::max(1, static_cast<int>(std::ceil(film->xres * film->crop[1])) - xs);
+    int ys = static_cast<int>(std::ceil(film->yres * film->crop[2]));
+    int yc = std::max(1, static_cast<int>(std::ceil(film->yres * film->crop[3])) - ys);
+    out[0] = static_cast<int>(std::floor(xs + 0.5f - film->filter_width[0]));
+    out[1] = static_cast<int>(std::floor(xs + 0.5f + xc + film->filter_width[0]));
+    out[2] = static_cast<int>(std::floor(ys + 0.5f - film->filter_width[1]));
+    out[3] = static_cast<int>(std::floor(ys + 0.5f + yc + film->filter_width[1]));
+}
+
+int32_t gbl_host_round_to_square(int32_t n) { return round_to_square(n); }
+
+int32_t gbl_host_sample_dimension(const gbl_render_setting* rs) {
+    if (rs->integrator == GBL_INTEGRATOR_AO) {
+        // one 2D pattern of roundToSquare(roundToSquare(n)) points (GoblinAO.cpp:39-42)
+        return 4 + 2 * round_to_square(round_to_square(rs->ao_sample_num));
+    }
+    // per bounce: light{1D,2D} + bsdf{1D,2D} + pick{1D} with n=1 -> 7 floats;
+    // then the BSSRDF block: 4 x 1D + 2 x 2D patterns of n' points
+    int depth = std::max(1, rs->max_ray_depth);
+    int n1 = round_to_square(rs->bssrdf_sample_num);
+    int n2 = round_to_square(n1);
+    return 4 + 7 * depth + 4 * n1 + 2 * 2 * n2;
+}
+
+void gbl_host_film_normalize(const float* accum, int32_t xres, int32_t yres, float* rgb_out) {
+    // Color / float multiplies by the reciprocal (GoblinColor.h:76-79)
+    for (int64_t i = 0; i < static_cast<int64_t>(xres) * yres; ++i) {
+        float inv = 1.0f / accum[4 * i + 3];
+        rgb_out[3 * i + 0] = accum[4 * i + 0] * inv;
+        rgb_out[3 * i + 1] = accum[4 * i + 1] * inv;
+        rgb_out[3 * i + 2] = accum[4 * i + 2] * inv;
+    }
+}
+
+gbl_status gbl_host_write_pfm(const char* path, const float* rgb, int32_t xres, int32_t yres) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(GBL_ERR_IO, std::string("can't open ") + path);
+    fprintf(f, "PF\n%d %d\n-1.0\n", xres, yres);
+    for (int y = yres - 1; y >= 0; --y) fwrite(rgb + 3 * static_cast<size_t>(y) * xres, sizeof(float), 3 * static_cast<size_t>(xres), f);
+    fclose(f);
+    return GBL_OK;
+}
+
+}  // extern "C"

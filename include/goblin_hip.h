@@ -1,0 +1,303 @@
+/*
+ * goblin_hip.h -- C ABI of the MI355X-native path-tracing integrator.
+ *
+ * This is the drop-in boundary behind Goblin's Renderer seam.  The reference
+ * has no FFI layer: the seam is the C++ virtual `Renderer::render(ScenePtr)`
+ * (/root/reference/src/GoblinRenderer.h:55-59, GoblinRenderContext.h:19-22)
+ * selected by `createRenderer` (GoblinContextLoader.cpp:67-92).  A GPU renderer
+ * replaces that one call: scene arrays in, Film accumulation buffer out.
+ *
+ * Everything here is plain C: POD structs, pointers + counts, int status
+ * codes, no exceptions, caller-owned output buffers.  INTEGRATION.md shows the
+ * `HipPathTracer : Renderer` stub a Goblin maintainer would add on top.
+ *
+ * Two shared libraries implement it:
+ *   libgoblin_host.so  (g++,   no HIP dependency)  gbl_host_*  scene front end
+ *   libgoblin_hip.so   (hipcc, gfx950)             gbl_*       device integrator
+ */
+#ifndef GOBLIN_HIP_H
+#define GOBLIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBL_ABI_VERSION 1
+
+typedef enum gbl_status {
+    GBL_OK = 0,
+    GBL_ERR_INVALID = 1,     /* bad argument / inconsistent description       */
+    GBL_ERR_UNSUPPORTED = 2, /* scene uses a Goblin feature outside the path  */
+    GBL_ERR_IO = 3,          /* file missing / parse error                    */
+    GBL_ERR_DEVICE = 4,      /* HIP runtime error, no device                  */
+    GBL_ERR_OOM = 5
+} gbl_status;
+
+/* ------------------------------------------------------------------------- */
+/* Scene description (host memory, owned by the caller for the duration of    */
+/* gbl_create).  Mirrors what ContextLoader builds (GoblinContextLoader.cpp   */
+/* :447-504) restricted to the hot path: triangle meshes, instances,          */
+/* constant-texture materials, point/spot/area lights, perspective camera.   */
+/* ------------------------------------------------------------------------- */
+
+/* position / orientation(w,x,y,z) / scale, as parsed by getTransform
+ * (GoblinUtils.cpp:78-100) and composed by Transform::update
+ * (GoblinTransform.cpp:182-193). */
+typedef struct gbl_trs {
+    float position[3];
+    float orientation[4]; /* quaternion w, x, y, z */
+    float scale[3];
+} gbl_trs;
+
+/* One PolygonMesh after OBJ loading and (v,vn,vt) de-duplication
+ * (GoblinPolygonMesh.cpp:58-262).  Vertex attributes live in the shared
+ * arrays of gbl_scene_desc; indices are mesh-local. */
+typedef struct gbl_mesh {
+    uint32_t vertex_offset; /* first vertex in positions/normals/uvs          */
+    uint32_t vertex_count;
+    uint32_t tri_offset;    /* first triangle in indices (3 uint32 each)      */
+    uint32_t tri_count;
+    uint32_t has_normal;    /* PolygonMesh::hasNormal()                       */
+    uint32_t has_uv;        /* PolygonMesh::hasTexCoord()                     */
+} gbl_mesh;
+
+typedef enum gbl_material_type {
+    GBL_MAT_LAMBERT = 0,     /* GoblinMaterial.cpp:437-480 */
+    GBL_MAT_BLINN = 1,       /* GoblinMaterial.cpp:540-644 */
+    GBL_MAT_TRANSPARENT = 2, /* GoblinMaterial.cpp:647-706 */
+    GBL_MAT_MIRROR = 3       /* GoblinMaterial.cpp:709-726 */
+} gbl_material_type;
+
+/* Constant-texture materials only (createColorConstantTexture,
+ * GoblinTexture.cpp:622-625).  Colours are rgb; alpha is 1 as in Color(r,g,b). */
+typedef struct gbl_material {
+    uint32_t type;     /* gbl_material_type                                    */
+    float color[3];    /* Lambert Kd | Blinn Kg | Transparent Kr | Mirror Kr   */
+    float color2[3];   /* Transparent Kt                                       */
+    float index;       /* eta: blinn/transparent default 1.5, mirror 0.8       */
+    float k;           /* absorption: blinn conductor iff > 0; mirror 6.0      */
+    float exponent;    /* blinn exponent (float constant texture)              */
+} gbl_material;
+
+/* InstancedPrimitive over a Model(geometry, material[, areaLight])
+ * (GoblinPrimitive.cpp:99-112, GoblinModel.cpp:10-26). */
+typedef struct gbl_instance {
+    uint32_t mesh;
+    uint32_t material;
+    int32_t area_light; /* index into lights, -1 if not emissive              */
+    gbl_trs to_world;
+} gbl_instance;
+
+/* Values follow Light::Type (GoblinLight.h:62-68). */
+typedef enum gbl_light_type {
+    GBL_LIGHT_POINT = 0, /* GoblinLight.cpp:78-134  */
+    GBL_LIGHT_SPOT = 2,  /* GoblinLight.cpp:212-287 */
+    GBL_LIGHT_AREA = 3   /* GoblinLight.cpp:345-461 */
+} gbl_light_type;
+
+typedef struct gbl_light {
+    uint32_t type;           /* gbl_light_type                                 */
+    float color[3];          /* intensity (point/spot) or radiance Le (area)   */
+    float position[3];       /* point/spot                                     */
+    float direction[3];      /* spot: as given to the SpotLight ctor           */
+    float cos_theta_max;     /* spot: cos(radians(theta_max))                  */
+    float cos_falloff_start; /* spot                                           */
+    uint32_t mesh;           /* area: emitting geometry                        */
+    gbl_trs to_world;        /* area                                           */
+} gbl_light;
+
+/* PerspectiveCamera (GoblinCamera.cpp:83-148, 377-387). lens_radius must be 0
+ * (pinhole); the thin-lens branch is listed under SURVEY 8f. */
+typedef struct gbl_camera {
+    float position[3];
+    float orientation[4]; /* w, x, y, z */
+    float fov_degrees;
+    float near_plane, far_plane;
+    float lens_radius, focal_distance;
+} gbl_camera;
+
+typedef enum gbl_filter_type {
+    GBL_FILTER_BOX = 0,
+    GBL_FILTER_TRIANGLE = 1,
+    GBL_FILTER_GAUSSIAN = 2,
+    GBL_FILTER_MITCHELL = 3
+} gbl_filter_type;
+
+/* Film + reconstruction filter (GoblinFilm.cpp:92-112,202-218,
+ * GoblinFilter.h:85-106). */
+typedef struct gbl_film {
+    int32_t xres, yres;
+    float crop[4]; /* x0 x1 y0 y1 fractions */
+    uint32_t filter_type;
+    float filter_width[2];
+    float gaussian_falloff;
+    float mitchell_b, mitchell_c;
+} gbl_film;
+
+typedef enum gbl_integrator {
+    GBL_INTEGRATOR_PATH = 0, /* PathTracer  (GoblinPathtracer.cpp) */
+    GBL_INTEGRATOR_AO = 1    /* AORenderer  (GoblinAO.cpp)         */
+} gbl_integrator;
+
+/* render_setting block (GoblinPathtracer.cpp:210-217, GoblinAO.cpp:44-49). */
+typedef struct gbl_render_setting {
+    uint32_t integrator;
+    int32_t sample_per_pixel;
+    int32_t max_ray_depth;
+    int32_t bssrdf_sample_num;
+    int32_t ao_sample_num;
+    int32_t thread_num; /* CPU paths only */
+} gbl_render_setting;
+
+typedef struct gbl_scene_desc {
+    uint32_t abi_version; /* GBL_ABI_VERSION */
+
+    uint32_t num_vertices;
+    const float* positions; /* 3 per vertex */
+    const float* normals;   /* 3 per vertex (zeros where the mesh has none)   */
+    const float* uvs;       /* 2 per vertex (zeros where the mesh has none)   */
+    uint32_t num_triangles;
+    const uint32_t* indices; /* 3 per triangle, mesh-local */
+
+    uint32_t num_meshes;
+    const gbl_mesh* meshes;
+    uint32_t num_materials;
+    const gbl_material* materials;
+    uint32_t num_instances;
+    const gbl_instance* instances; /* in SceneCache::getInstances() order */
+    uint32_t num_lights;
+    const gbl_light* lights;       /* in SceneCache::getLights() order    */
+
+    gbl_camera camera;
+    gbl_film film;
+    gbl_render_setting setting;
+} gbl_scene_desc;
+
+/* ------------------------------------------------------------------------- */
+/* libgoblin_host.so : scene front end (JSON + OBJ -> gbl_scene_desc).        */
+/* Replaces ContextLoader::load (GoblinContextLoader.cpp:447-504) for the     */
+/* subset above; same keys, defaults and int-vs-float strictness.             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct gbl_host_scene gbl_host_scene;
+
+/* Load a Goblin scene file.  Relative mesh paths resolve against the file's
+ * directory (SceneCache::resolvePath, GoblinScene.cpp:236-243). */
+gbl_status gbl_host_load_file(const char* json_path, gbl_host_scene** out);
+/* Same, from JSON text; `scene_dir` plays the role of the file's directory. */
+gbl_status gbl_host_load_string(const char* json_text, const char* scene_dir, gbl_host_scene** out);
+/* The flattened description; valid until gbl_host_free. */
+const gbl_scene_desc* gbl_host_desc(const gbl_host_scene* scene);
+void gbl_host_free(gbl_host_scene* scene);
+/* Message for the last failing gbl_host_* call on this thread. */
+const char* gbl_host_last_error(void);
+
+/* Film::getSampleRange (GoblinFilm.cpp:131-138): the film padded by the
+ * filter radius.  out = {x0, x1, y0, y1}, half-open. */
+void gbl_host_sample_window(const gbl_film* film, int32_t out[4]);
+/* roundToSquare (GoblinUtils.h:124-130): the spp the sampler really takes. */
+int32_t gbl_host_round_to_square(int32_t n);
+/* Floats per Sample for an integrator: 4 + quota (GoblinPathtracer.cpp:181-208,
+ * GoblinAO.cpp:39-42, GoblinSampler.h:27-31). */
+int32_t gbl_host_sample_dimension(const gbl_render_setting* setting);
+/* Film::writeImage's normalise step (GoblinFilm.cpp:164-172): rgb/weight.
+ * accum = W*H float4 {sum w*L rgb, sum w}; rgb_out = W*H*3 floats. */
+void gbl_host_film_normalize(const float* accum, int32_t xres, int32_t yres, float* rgb_out);
+/* Portable float map writer (the reference writes HALF EXR through tinyexr,
+ * GoblinImageIO.cpp:84 -- out of scope; parity is checked on the float film). */
+gbl_status gbl_host_write_pfm(const char* path, const float* rgb, int32_t xres, int32_t yres);
+
+/* ------------------------------------------------------------------------- */
+/* libgoblin_hip.so : the device integrator.                                  */
+/* ------------------------------------------------------------------------- */
+
+typedef struct gbl_ctx gbl_ctx;
+
+typedef enum gbl_sample_mode {
+    /* Counter-based device sampler with the reference's stratification law
+     * (jittered strata x per-pixel sub-strata, permuted across the pixel's
+     * samples: GoblinSampler.cpp:108-197), keyed by (seed, pixel, dim, k). */
+    GBL_SAMPLES_NATIVE = 0,
+    /* Caller uploads Sample records (device pointer): per sample
+     * gbl_host_sample_dimension floats laid out {imageX, imageY, lensU1,
+     * lensU2, u1D[0][..], u1D[1][..], ..., u2D[0][..], ...} exactly as
+     * Sampler::requestSamples fills them; pixel-major, S samples per pixel,
+     * pixels in row-major order over the sample window given in params. */
+    GBL_SAMPLES_REPLAY = 1
+} gbl_sample_mode;
+
+typedef struct gbl_render_params {
+    uint32_t integrator;      /* gbl_integrator                               */
+    int32_t sample_per_pixel; /* rounded up to a square like the reference    */
+    int32_t max_ray_depth;    /* PathTracer: loop runs max_ray_depth-1 times  */
+    int32_t ao_sample_num;
+    int32_t bssrdf_sample_num; /* only sizes the replay record (dims)         */
+    /* sub-window of the sample window to render, half-open pixel coords; the
+     * multi-GPU shard unit.  {0,0,0,0} = the whole Film::getSampleRange. */
+    int32_t window[4];        /* x0, x1, y0, y1 */
+    uint32_t sample_mode;     /* gbl_sample_mode                              */
+    uint64_t seed;            /* native mode                                  */
+    const float* replay_samples; /* device pointer, replay mode               */
+    /* optional device pointer: per-sample radiance rgba as Li() returns it,
+     * same order as the samples (replay/native), or NULL. */
+    float* li_out;
+    uint32_t russian_roulette; /* build-side extension; MUST be 0 for parity
+                                  (the reference loop is fixed length,
+                                  GoblinPathtracer.cpp:76)                    */
+    uint32_t collect_stats;    /* fill node/triangle counters (slower)        */
+    void* stream;              /* hipStream_t, NULL = default stream          */
+} gbl_render_params;
+
+typedef struct gbl_stats {
+    uint64_t paths;          /* camera samples = Li evaluations               */
+    uint64_t extension_rays; /* closest-hit scene queries (incl. primary)     */
+    uint64_t shadow_rays;    /* any-hit scene queries                         */
+    uint64_t nodes;          /* child boxes tested (32 B each)                */
+    uint64_t tris;           /* triangles tested (48 B each)                  */
+    uint64_t splats;         /* film pixel updates                            */
+    uint64_t dims;           /* sample dimensions consumed (floats)           */
+    double kernel_ms;        /* HIP-event time of the render kernel(s)        */
+} gbl_stats;
+
+/* Build the two-level BVH on the host, pack and upload the scene once
+ * (replaces Scene/BVH/Model construction: GoblinScene.cpp:11-27,
+ * GoblinBVH.cpp:34-151, GoblinModel.cpp:10-26).  `device` is a HIP ordinal. */
+gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out);
+
+/* Run the integrator over params->window and ACCUMULATE into film_accum, a
+ * device buffer of xres*yres float4 {sum w*L.rgb, sum w} (the per-thread
+ * ImageTile of the reference, GoblinFilm.cpp:61-90).  Replaces
+ * Renderer::render's task loop (GoblinRenderer.cpp:99-126, 29-52).
+ * Asynchronous on params->stream unless stats != NULL (then it synchronises
+ * to read counters and timing). */
+gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* params, float* film_accum, gbl_stats* stats);
+
+/* Sum film_accum across the ranks of an RCCL communicator (ncclComm_t passed
+ * as void*): replaces Film::mergeTile under the TLS mutex
+ * (GoblinFilm.cpp:140-153, GoblinThreadLocalStorage.h:69-75). */
+gbl_status gbl_film_allreduce(gbl_ctx* ctx, void* rccl_comm, float* film_accum, void* stream);
+
+/* Device-side Film::writeImage normalise: rgb_out[W*H*3] = rgb / weight. */
+gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_out, void* stream);
+
+/* Scene facts the caller needs for buffer sizing and reporting. */
+typedef struct gbl_info {
+    int32_t xres, yres;
+    int32_t window[4];      /* full sample window x0,x1,y0,y1 */
+    uint64_t blas_nodes, tlas_nodes, triangles, instances;
+    uint64_t scene_bytes;   /* device bytes held by the scene */
+} gbl_info;
+gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out);
+
+void gbl_destroy(gbl_ctx* ctx);
+/* Message for the last failing call on ctx (or on creation when ctx == NULL). */
+const char* gbl_last_error(const gbl_ctx* ctx);
+int gbl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOBLIN_HIP_H */

@@ -1,0 +1,1955 @@
+// TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+//
+// CPU restatement ("oracle") of the reference's path-tracing hot path, written
+// from the reference's published behaviour in its float operation order.  Only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+// library; nothing under goblin_amd/ links, imports or calls it.
+//
+// Parity pin: PINNED.  The reference has no tests or golden vectors of its own
+// (SURVEY.md 8c), so this file is pinned against the real reference compiled
+// from /root/reference/src by oracle/Makefile (oracle/_ref/ref_harness): the
+// fixtures under tests/golden/ were captured from that build by
+// tests/golden/make_golden.py, and tests/test_oracle_vs_reference.py checks this
+// restatement against them (Film accumulators, per-sample (Sample -> Li) pairs,
+// camera rays, filter table, light power, closest hits).
+//
+// Every function cites the reference file:line it restates
+// (paths relative to /root/reference/src).
+//
+// Build: g++ -std=c++17 -O2 -ffp-contract=off (x86-64 SSE2, no FMA contraction,
+// so add/mul/div/sqrt round exactly as in the reference's own -O2 build).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../include/goblin_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Math kernel set (GoblinVector.h, GoblinColor.h, GoblinUtils.h)
+// ---------------------------------------------------------------------------
+const float PI = 3.14159265358979323f;     // GoblinUtils.h:43
+const float TWO_PI = 6.28318530718f;       // :44
+const float INV_PI = 0.31830988618379067154f;   // :45
+const float INV_TWOPI = 0.15915494309189533577f;  // :46
+const float INF = INFINITY;
+
+struct V3 {
+    float x, y, z;
+    V3() = default;
+    V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    float operator[](int i) const { return (&x)[i]; }
+    float& operator[](int i) { return (&x)[i]; }
+};
+inline V3 operator+(V3 a, V3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return a * s; }   // GoblinVector.h:233-235 (rhs * s)
+// Vector3::operator/ multiplies by the reciprocal (GoblinVector.h:166-169)
+inline V3 operator/(V3 a, float s) {
+    float inv = 1.0f / s;
+    return V3(a.x * inv, a.y * inv, a.z * inv);
+}
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // :209-211
+inline float absdot(V3 a, V3 b) { return std::fabs(dot(a, b)); }
+inline V3 cross(V3 a, V3 b) {   // :217-222
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline float length(V3 a) { return std::sqrt(sqlen(a)); }
+inline V3 normalize(V3 a) { return a / length(a); }   // :229-231
+
+// Color: rgba; binary ops keep the LEFT operand's alpha, += / *= leave alpha
+// alone, == compares alpha too (GoblinColor.h:32-108).
+struct Col {
+    float r, g, b, a;
+    Col() = default;
+    explicit Col(float c) : r(c), g(c), b(c), a(1.0f) {}
+    Col(float r_, float g_, float b_, float a_ = 1.0f) : r(r_), g(g_), b(b_), a(a_) {}
+};
+inline Col operator*(Col c, float s) { return Col(c.r * s, c.g * s, c.b * s, c.a); }
+inline Col operator*(float s, Col c) { return c * s; }
+inline Col operator*(Col a, Col b) { return Col(a.r * b.r, a.g * b.g, a.b * b.b, a.a); }
+inline Col operator/(Col c, float s) {
+    float inv = 1.0f / s;
+    return Col(c.r * inv, c.g * inv, c.b * inv, c.a);
+}
+inline Col& operator+=(Col& a, Col b) {
+    a.r += b.r; a.g += b.g; a.b += b.b;
+    return a;
+}
+inline Col& operator*=(Col& a, Col b) {
+    a.r *= b.r; a.g *= b.g; a.b *= b.b;
+    return a;
+}
+inline bool operator==(Col a, Col b) { return a.r == b.r && a.g == b.g && a.b == b.b && a.a == b.a; }
+inline bool operator!=(Col a, Col b) { return !(a == b); }
+inline float luminance(Col c) { return 0.212671f * c.r + 0.715160f * c.g + 0.072169f * c.b; }
+const Col BLACK(0.0f, 0.0f, 0.0f, 1.0f);
+
+inline float clampf(float f, float lo, float hi) { return f < lo ? lo : (f > hi ? hi : f); }
+inline int ceil_int(float f) { return static_cast<int>(std::ceil(f)); }
+inline int floor_int(float f) { return static_cast<int>(std::floor(f)); }
+inline int round_to_square(int n, int* root = nullptr) {   // GoblinUtils.h:124-130
+    int s = ceil_int(std::sqrt(static_cast<float>(n)));
+    if (root) *root = s;
+    return s * s;
+}
+inline float radians(float deg) { return PI * (deg / 180.0f); }
+
+// ---------------------------------------------------------------------------
+// Matrix4 / Quaternion / Transform (GoblinMatrix.cpp, GoblinQuaternion.cpp,
+// GoblinTransform.cpp)
+// ---------------------------------------------------------------------------
+struct M4 {
+    float m[4][4];
+};
+
+M4 quat_to_matrix(const float q[4]) {   // Quaternion::toMatrix, GoblinQuaternion.cpp:62-81
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float x2 = 2.0f * x, y2 = 2.0f * y, z2 = 2.0f * z;
+    float xx2 = x2 * x, xy2 = x2 * y, xz2 = x2 * z, xw2 = x2 * w;
+    float yy2 = y2 * y, yz2 = y2 * z, yw2 = y2 * w;
+    float zz2 = z2 * z, zw2 = z2 * w;
+    M4 r = {{{1 - yy2 - zz2, xy2 - zw2, xz2 + yw2, 0.0f},
+             {xy2 + zw2, 1 - xx2 - zz2, yz2 - xw2, 0.0f},
+             {xz2 - yw2, yz2 + xw2, 1 - xx2 - yy2, 0.0f},
+             {0.0f, 0.0f, 0.0f, 1.0f}}};
+    return r;
+}
+
+V3 quat_rotate(const float q[4], V3 p) {   // Quaternion::operator*(Vector3), GoblinQuaternion.cpp:86-92
+    V3 v(q[1], q[2], q[3]);
+    V3 uv = cross(v, p);
+    V3 uuv = cross(v, uv);
+    uv = uv * (2.0f * q[0]);
+    uuv = uuv * 2.0f;
+    return p + uv + uuv;
+}
+
+M4 mat_mul(const M4& a, const M4& b) {   // Matrix4::operator*, GoblinMatrix.cpp:305-314
+    M4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j] + a.m[i][3] * b.m[3][j];
+    return r;
+}
+
+// inverse(Matrix4*, const Matrix4&), GoblinMatrix.cpp:419-486: adjugate from
+// 2x2 sub-determinants of row pairs (2,3), (1,3), (1,2); returns false and
+// leaves *inv partially written when |det| < 1e-5.
+bool mat_inverse(M4* out, const M4& in) {
+    const float(*a)[4] = in.m;
+    float(*o)[4] = out->m;
+    // sub[r][k]: 2x2 determinants of rows (r0,r1) over column pairs, in the order 23,13,12,03,02,01
+    auto sub = [&](int r0, int r1, float s[6]) {
+        s[0] = a[r0][2] * a[r1][3] - a[r0][3] * a[r1][2];
+        s[1] = a[r0][1] * a[r1][3] - a[r0][3] * a[r1][1];
+        s[2] = a[r0][1] * a[r1][2] - a[r0][2] * a[r1][1];
+        s[3] = a[r0][0] * a[r1][3] - a[r0][3] * a[r1][0];
+        s[4] = a[r0][0] * a[r1][2] - a[r0][2] * a[r1][0];
+        s[5] = a[r0][0] * a[r1][1] - a[r0][1] * a[r1][0];
+    };
+    // cofactor column from a row `row` against sub-determinants s
+    auto col = [&](int row, const float s[6], float c[4]) {
+        c[0] = a[row][1] * s[0] - a[row][2] * s[1] + a[row][3] * s[2];
+        c[1] = a[row][0] * s[0] - a[row][2] * s[3] + a[row][3] * s[4];
+        c[2] = a[row][0] * s[1] - a[row][1] * s[3] + a[row][3] * s[5];
+        c[3] = a[row][0] * s[2] - a[row][1] * s[4] + a[row][2] * s[5];
+    };
+    float s23[6], s13[6], s12[6], c[4];
+    sub(2, 3, s23);
+    col(1, s23, c);
+    o[0][0] = +c[0]; o[1][0] = -c[1]; o[2][0] = +c[2]; o[3][0] = -c[3];
+    float det = a[0][0] * o[0][0] + a[0][1] * o[1][0] + a[0][2] * o[2][0] + a[0][3] * o[3][0];
+    if (std::fabs(det) < 1e-5f) return false;
+    float inv_det = 1.0f / det;
+    col(0, s23, c);
+    o[0][1] = -c[0]; o[1][1] = +c[1]; o[2][1] = -c[2]; o[3][1] = +c[3];
+    sub(1, 3, s13);
+    col(0, s13, c);
+    o[0][2] = +c[0]; o[1][2] = -c[1]; o[2][2] = +c[2]; o[3][2] = -c[3];
+    sub(1, 2, s12);
+    col(0, s12, c);
+    o[0][3] = -c[0]; o[1][3] = +c[1]; o[2][3] = -c[2]; o[3][3] = +c[3];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) o[i][j] *= inv_det;
+    return true;
+}
+
+struct Xform {
+    M4 M, inv;
+    V3 scale;
+    // Transform::update, GoblinTransform.cpp:182-193: M = R*S, translation
+    // written into column 3, then the general inverse.
+    void set(const float pos[3], const float q[4], const float s[3]) {
+        M4 S = {{{s[0], 0, 0, 0}, {0, s[1], 0, 0}, {0, 0, s[2], 0}, {0, 0, 0, 1}}};
+        M = mat_mul(quat_to_matrix(q), S);
+        M.m[0][3] = pos[0]; M.m[1][3] = pos[1]; M.m[2][3] = pos[2];
+        M4 id = {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}};
+        inv = id;
+        mat_inverse(&inv, M);
+        scale = V3(s[0], s[1], s[2]);
+    }
+    V3 on_point(V3 p) const {   // :97-103
+        return V3(M.m[0][0] * p.x + M.m[0][1] * p.y + M.m[0][2] * p.z + M.m[0][3],
+                  M.m[1][0] * p.x + M.m[1][1] * p.y + M.m[1][2] * p.z + M.m[1][3],
+                  M.m[2][0] * p.x + M.m[2][1] * p.y + M.m[2][2] * p.z + M.m[2][3]);
+    }
+    V3 on_vector(V3 v) const {   // :113-119
+        return V3(M.m[0][0] * v.x + M.m[0][1] * v.y + M.m[0][2] * v.z,
+                  M.m[1][0] * v.x + M.m[1][1] * v.y + M.m[1][2] * v.z,
+                  M.m[2][0] * v.x + M.m[2][1] * v.y + M.m[2][2] * v.z);
+    }
+    V3 on_normal(V3 n) const {   // (M^-1)^T n, :105-111
+        return V3(inv.m[0][0] * n.x + inv.m[1][0] * n.y + inv.m[2][0] * n.z,
+                  inv.m[0][1] * n.x + inv.m[1][1] * n.y + inv.m[2][1] * n.z,
+                  inv.m[0][2] * n.x + inv.m[1][2] * n.y + inv.m[2][2] * n.z);
+    }
+    V3 invert_point(V3 p) const {   // :138-144
+        return V3(inv.m[0][0] * p.x + inv.m[0][1] * p.y + inv.m[0][2] * p.z + inv.m[0][3],
+                  inv.m[1][0] * p.x + inv.m[1][1] * p.y + inv.m[1][2] * p.z + inv.m[1][3],
+                  inv.m[2][0] * p.x + inv.m[2][1] * p.y + inv.m[2][2] * p.z + inv.m[2][3]);
+    }
+    V3 invert_vector(V3 v) const {   // :154-160
+        return V3(inv.m[0][0] * v.x + inv.m[0][1] * v.y + inv.m[0][2] * v.z,
+                  inv.m[1][0] * v.x + inv.m[1][1] * v.y + inv.m[1][2] * v.z,
+                  inv.m[2][0] * v.x + inv.m[2][1] * v.y + inv.m[2][2] * v.z);
+    }
+};
+
+struct Box {
+    V3 lo, hi;
+    Box() : lo(INF, INF, INF), hi(-INF, -INF, -INF) {}   // GoblinBBox.h default
+    void expand(V3 p) {
+        lo = V3(std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z));
+        hi = V3(std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z));
+    }
+    void expand(const Box& b) {
+        lo = V3(std::min(lo.x, b.lo.x), std::min(lo.y, b.lo.y), std::min(lo.z, b.lo.z));
+        hi = V3(std::max(hi.x, b.hi.x), std::max(hi.y, b.hi.y), std::max(hi.z, b.hi.z));
+    }
+    int longest_axis() const {   // GoblinBBox.cpp:78-87
+        V3 d = hi - lo;
+        if (d.x > d.y && d.x > d.z) return 0;
+        if (d.y > d.z) return 1;
+        return 2;
+    }
+};
+
+struct Ray {
+    V3 o, d;
+    float mint, maxt;
+};
+
+// ---------------------------------------------------------------------------
+// BVH exactly as the reference builds it (GoblinBVH.cpp:34-151): DFS-linear
+// nodes, leaf iff one primitive (or coincident centroids), split on the longest
+// centroid axis at the median with std::nth_element ("equal_count" is what every
+// caller passes: GoblinScene.cpp:15, GoblinModel.cpp:24).
+// ---------------------------------------------------------------------------
+struct BvhNode {
+    Box box;
+    uint32_t offset;   // leaf: first primitive; interior: second child
+    uint8_t nprims, axis;
+};
+
+struct BuildItem {   // BVHPrimitiveInfo, GoblinBVH.cpp:8-14
+    Box box;
+    int index;
+    V3 center;
+};
+
+struct Bvh {
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> prims;   // ordered primitive ids
+    Box bounds;
+
+    void build(const std::vector<Box>& boxes) {
+        nodes.clear();
+        prims.clear();
+        bounds = Box();
+        for (const Box& b : boxes) bounds.expand(b);
+        if (boxes.empty()) return;
+        std::vector<BuildItem> items;
+        items.reserve(boxes.size());
+        for (size_t i = 0; i < boxes.size(); ++i) {
+            BuildItem it;
+            it.box = boxes[i];
+            it.index = static_cast<int>(i);
+            it.center = 0.5f * (boxes[i].lo + boxes[i].hi);
+            items.push_back(it);
+        }
+        nodes.reserve(2 * boxes.size());
+        recurse(items, 0, static_cast<uint32_t>(items.size()));
+    }
+
+    uint32_t recurse(std::vector<BuildItem>& it, uint32_t start, uint32_t end) {
+        uint32_t me = static_cast<uint32_t>(nodes.size());
+        nodes.push_back(BvhNode());
+        Box box;
+        for (uint32_t i = start; i < end; ++i) box.expand(it[i].box);
+        uint32_t n = end - start;
+        auto make_leaf = [&]() {
+            uint32_t first = static_cast<uint32_t>(prims.size());
+            for (uint32_t i = start; i < end; ++i) prims.push_back(it[i].index);
+            nodes[me].box = box;
+            nodes[me].offset = first;
+            nodes[me].nprims = static_cast<uint8_t>(n);
+            nodes[me].axis = 0;
+        };
+        if (n == 1) {
+            make_leaf();
+            return me;
+        }
+        Box cb;
+        for (uint32_t i = start; i < end; ++i) cb.expand(it[i].center);
+        int dim = cb.longest_axis();
+        if (cb.lo[dim] == cb.hi[dim]) {
+            make_leaf();
+            return me;
+        }
+        uint32_t mid = (start + end) / 2;
+        std::nth_element(&it[start], &it[mid], &it[end - 1] + 1,
+                         [dim](const BuildItem& a, const BuildItem& b) { return a.center[dim] < b.center[dim]; });
+        recurse(it, start, mid);
+        uint32_t second = recurse(it, mid, end);
+        nodes[me].box = box;
+        nodes[me].offset = second;
+        nodes[me].axis = static_cast<uint8_t>(dim);
+        nodes[me].nprims = 0;
+        return me;
+    }
+};
+
+// static intersect(bbox, ray, invDir, dirIsNeg), GoblinBVH.cpp:156-187
+inline bool slab_test(const Box& b, const Ray& ray, V3 inv, const uint32_t neg[3]) {
+    const V3* bb = &b.lo;   // bb[0]=lo, bb[1]=hi
+    float tmin = (bb[neg[0]].x - ray.o.x) * inv.x;
+    float tmax = (bb[1 - neg[0]].x - ray.o.x) * inv.x;
+    float tymin = (bb[neg[1]].y - ray.o.y) * inv.y;
+    float tymax = (bb[1 - neg[1]].y - ray.o.y) * inv.y;
+    if (tymax < tmin || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (bb[neg[2]].z - ray.o.z) * inv.z;
+    float tzmax = (bb[1 - neg[2]].z - ray.o.z) * inv.z;
+    if (tzmax < tmin || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return (tmin < ray.maxt) && (tmax > ray.mint);
+}
+
+struct Counters {
+    uint64_t closest = 0, anyhit = 0, filtered = 0, nodes = 0, tris = 0;
+    void add(const Counters& o) {
+        closest += o.closest; anyhit += o.anyhit; filtered += o.filtered; nodes += o.nodes; tris += o.tris;
+    }
+};
+
+// Generic stack traversal shared by intersect/occluded (GoblinBVH.cpp:189-280).
+// `leaf(prim)` returns true to stop early (any-hit).
+template <class Leaf>
+inline void traverse(const Bvh& bvh, const Ray& ray, Counters* cnt, Leaf&& leaf) {
+    if (bvh.nodes.empty()) return;
+    V3 inv(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    uint32_t neg[3] = {ray.d.x < 0.0f, ray.d.y < 0.0f, ray.d.z < 0.0f};
+    uint32_t node = 0, sp = 0, todo[64];
+    while (true) {
+        const BvhNode& nd = bvh.nodes[node];
+        ++cnt->nodes;
+        if (slab_test(nd.box, ray, inv, neg)) {
+            if (nd.nprims > 0) {
+                for (uint32_t i = 0; i < nd.nprims; ++i)
+                    if (leaf(bvh.prims[nd.offset + i])) return;
+                if (sp == 0) break;
+                node = todo[--sp];
+            } else if (neg[nd.axis]) {
+                todo[sp++] = node + 1;
+                node = nd.offset;
+            } else {
+                todo[sp++] = nd.offset;
+                node = node + 1;
+            }
+        } else {
+            if (sp == 0) break;
+            node = todo[--sp];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Prepared scene
+// ---------------------------------------------------------------------------
+struct Frag {   // Fragment, GoblinGeometry.h:14-127
+    V3 p, n, dpdu, dpdv;
+    float u, v;
+};
+
+struct Mesh {
+    const float *pos, *nrm, *uv;
+    const uint32_t* idx;
+    uint32_t ntris;
+    bool has_n, has_uv;
+    Bvh bvh;
+    Box bounds;   // PolygonMesh::mBBox over de-duplicated vertices
+    V3 P(uint32_t i) const { return V3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); }
+    V3 N(uint32_t i) const { return V3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]); }
+};
+
+struct Instance {
+    uint32_t mesh, material;
+    int area_light;
+    Xform xf;
+};
+
+struct AreaGeo {   // GeometrySet, GoblinLight.cpp:289-343
+    std::vector<float> area, cdf;
+    float sum_area = 0.0f, integral = 0.0f, dx = 0.0f;
+};
+
+struct Light {
+    uint32_t type;
+    Col color;
+    V3 pos;
+    V3 spot_axis;   // mToWorld.onVector(UnitZ)
+    float cos_max, cos_falloff;
+    uint32_t mesh;
+    Xform xf;
+    AreaGeo geo;
+};
+
+// CDF1D, GoblinSampler.cpp:309-342
+struct Cdf {
+    std::vector<float> f, cdf;
+    float integral = 0.0f, dx = 0.0f;
+    void init(const std::vector<float>& fn) {
+        f = fn;
+        size_t n = f.size();
+        dx = 1.0f / n;
+        cdf.assign(n + 1, 0.0f);
+        for (size_t i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + (f[i - 1] * dx);
+        integral = cdf[n];
+        for (size_t i = 1; i < n + 1; ++i) cdf[i] /= integral;
+    }
+    int sample_discrete(float u, float* pdf) const {
+        auto lb = std::lower_bound(cdf.begin(), cdf.end(), u);
+        int off = std::max(0, static_cast<int>(lb - cdf.begin() - 1));
+        if (pdf) *pdf = (f[off] / integral) * dx;
+        return off;
+    }
+};
+
+}  // namespace
+
+struct orc_scene {
+    gbl_scene_desc desc;
+    std::vector<Mesh> meshes;
+    std::vector<Instance> instances;
+    std::vector<gbl_material> materials;
+    std::vector<Light> lights;
+    std::vector<Cdf> light_geo_cdf;   // per light (area only)
+    Cdf light_power;
+    std::vector<Col> light_power_rgb;
+    Bvh tlas;
+    // camera
+    V3 cam_pos;
+    float cam_q[4];
+    float proj00, proj11;
+    // film
+    int xres, yres, xstart, ystart, xcount, ycount;
+    float inv_xres, inv_yres;
+    float filter_w[2];
+    float filter_table[256];
+    int window[4];
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Reconstruction filters (GoblinFilter.cpp) and FilterTable (GoblinFilm.cpp:10-37)
+// ---------------------------------------------------------------------------
+struct FilterFn {
+    uint32_t type;
+    float wx, wy, alpha, expx, expy, b, c;
+    float gaussian(float v, float base) const { return std::max(0.0f, expf(-alpha * v * v) - base); }
+    float mitchell(float x) const {   // GoblinFilter.cpp:79-91
+        x = std::fabs(2.0f * x);
+        if (x > 1.0f)
+            return ((-b - 6 * c) * x * x * x + (6 * b + 30 * c) * x * x + (-12 * b - 48 * c) * x + (8 * b + 24 * c)) / 6.0f;
+        return ((12 - 9 * b - 6 * c) * x * x * x + (-18 + 12 * b + 6 * c) * x * x + (6 - 2 * b)) / 6.0f;
+    }
+    float eval(float x, float y) const {
+        switch (type) {
+            case GBL_FILTER_BOX: return 1.0f;
+            case GBL_FILTER_TRIANGLE: return std::max(0.0f, wx - fabsf(x)) * std::max(0.0f, wy - fabsf(y));
+            case GBL_FILTER_MITCHELL: return mitchell(x * (1.0f / wx)) * mitchell(y * (1.0f / wy));
+            default: return gaussian(x, expx) * gaussian(y, expy);
+        }
+    }
+    float normalize_term() const {
+        switch (type) {
+            case GBL_FILTER_BOX: return 4.0f * wx * wy;
+            case GBL_FILTER_TRIANGLE: return wx * wx * wy * wy;
+            case GBL_FILTER_MITCHELL:   // GoblinFilter.cpp:72-77
+                return 4.0f * ((12 - 9 * b - 6 * c) / 4 + (-18 + 12 * b + 6 * c) / 3 + (6 - 2 * b) + 15 * (-b - 6 * b) / 4 +
+                               7 * (6 * b + 30 * c) / 3 + 3 * (-12 * b - 48 * c) / 2 + (8 * b + 24 * c)) / 6.0f;
+            default: {   // numeric 20x20 quadrature, GoblinFilter.cpp:48-64
+                size_t step = 20;
+                float dx = wx / static_cast<float>(step), dy = wy / static_cast<float>(step);
+                float result = 0.0f;
+                for (size_t i = 0; i < step; ++i)
+                    for (size_t j = 0; j < step; ++j)
+                        result += 4.0f * dx * dy * gaussian(i * dx, expx) * gaussian(j * dy, expy);
+                return result;
+            }
+        }
+    }
+};
+
+void build_filter_table(orc_scene* s) {
+    const gbl_film& f = s->desc.film;
+    FilterFn fn;
+    fn.type = f.filter_type;
+    fn.wx = f.filter_width[0];
+    fn.wy = f.filter_width[1];
+    fn.alpha = f.gaussian_falloff;
+    fn.expx = expf(-fn.alpha * fn.wx * fn.wx);
+    fn.expy = expf(-fn.alpha * fn.wy * fn.wy);
+    fn.b = f.mitchell_b;
+    fn.c = f.mitchell_c;
+    float dx = fn.wx / 16, dy = fn.wy / 16;
+    float norm = fn.normalize_term();
+    size_t k = 0;
+    for (int y = 0; y < 16; ++y) {
+        float fy = y * dy;
+        for (int x = 0; x < 16; ++x) {
+            float fx = x * dx;
+            s->filter_table[k++] = fn.eval(fx, fy) / norm;
+        }
+    }
+    s->filter_w[0] = fn.wx;
+    s->filter_w[1] = fn.wy;
+}
+
+inline float filter_lookup(const orc_scene* s, float x, float y) {   // FilterTable::evaluate, GoblinFilm.cpp:29-37
+    int iy = std::min(floor_int(std::fabs(16 * y / s->filter_w[1])), 15);
+    int ix = std::min(floor_int(std::fabs(16 * x / s->filter_w[0])), 15);
+    return s->filter_table[iy * 16 + ix];
+}
+
+// ImageTile::addSample over the full-film tile (GoblinFilm.cpp:61-90,
+// GoblinThreadLocalStorage.h:30-35).  film = xres*yres float4.
+inline void add_sample(const orc_scene* s, float* film, float image_x, float image_y, Col L, uint64_t* splats) {
+    if (L.r != L.r || L.g != L.g || L.b != L.b || L.a != L.a) return;
+    float dx = image_x - 0.5f, dy = image_y - 0.5f;
+    int x0 = ceil_int(dx - s->filter_w[0]), x1 = floor_int(dx + s->filter_w[0]);
+    int y0 = ceil_int(dy - s->filter_w[1]), y1 = floor_int(dy + s->filter_w[1]);
+    x0 = std::max(x0, s->xstart);
+    x1 = std::min(x1, s->xstart + s->xcount - 1);
+    y0 = std::max(y0, s->ystart);
+    y1 = std::min(y1, s->ystart + s->ycount - 1);
+    for (int y = y0; y <= y1; ++y) {
+        for (int x = x0; x <= x1; ++x) {
+            float w = filter_lookup(s, x - dx, y - dy);
+            float* px = film + 4 * (static_cast<size_t>(y) * s->xres + x);
+            Col wl = w * L;
+            px[0] += wl.r;
+            px[1] += wl.g;
+            px[2] += wl.b;
+            px[3] += w;
+            if (splats) ++*splats;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scene preparation
+// ---------------------------------------------------------------------------
+void coordinate_axes(V3 a1, V3* a2, V3* a3) {   // coordinateAxises, GoblinUtils.cpp:58-69
+    if (fabsf(a1.x) > fabsf(a1.y)) {
+        float inv = 1.0f / sqrtf(a1.x * a1.x + a1.z * a1.z);
+        *a2 = V3(-a1.z * inv, 0.0f, a1.x * inv);
+    } else {
+        float inv = 1.0f / sqrtf(a1.y * a1.y + a1.z * a1.z);
+        *a2 = V3(0.0f, -a1.z * inv, a1.y * inv);
+    }
+    *a3 = cross(a1, *a2);
+}
+
+void quat_from_matrix3(const float R[3][3], float q_wxyz[4]) {   // Quaternion(Matrix3), GoblinQuaternion.cpp:20-52
+    float q[4];
+    float trace = R[0][0] + R[1][1] + R[2][2];
+    if (trace > 0.0f) {
+        float s = std::sqrt(trace + 1.0f);
+        q[3] = s * 0.5f;
+        float t = 0.5f / s;
+        q[0] = (R[2][1] - R[1][2]) * t;
+        q[1] = (R[0][2] - R[2][0]) * t;
+        q[2] = (R[1][0] - R[0][1]) * t;
+    } else {
+        int i = 0;
+        if (R[1][1] > R[0][0]) i = 1;
+        if (R[2][2] > R[i][i]) i = 2;
+        const int next[3] = {1, 2, 0};
+        int j = next[i], k = next[j];
+        float s = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0f);
+        q[i] = s * 0.5f;
+        float t = s != 0.0f ? 0.5f / s : s;
+        q[3] = (R[k][j] - R[j][k]) * t;
+        q[j] = (R[j][i] + R[i][j]) * t;
+        q[k] = (R[k][i] + R[i][k]) * t;
+    }
+    q_wxyz[0] = q[3]; q_wxyz[1] = q[0]; q_wxyz[2] = q[1]; q_wxyz[3] = q[2];
+}
+
+float tri_area(const Mesh& m, uint32_t t) {   // Triangle::area, GoblinTriangle.cpp:179-189
+    V3 p0 = m.P(m.idx[3 * t]), p1 = m.P(m.idx[3 * t + 1]), p2 = m.P(m.idx[3 * t + 2]);
+    return 0.5f * length(cross(p1 - p0, p2 - p0));
+}
+
+Box transform_box(const Xform& xf, const Box& b) {   // Transform::onBBox, GoblinTransform.cpp:125-136
+    Box r;
+    r.expand(xf.on_point(b.lo));
+    r.expand(xf.on_point(V3(b.hi.x, b.lo.y, b.lo.z)));
+    r.expand(xf.on_point(V3(b.lo.x, b.hi.y, b.lo.z)));
+    r.expand(xf.on_point(V3(b.lo.x, b.lo.y, b.hi.z)));
+    r.expand(xf.on_point(V3(b.hi.x, b.hi.y, b.lo.z)));
+    r.expand(xf.on_point(V3(b.hi.x, b.lo.y, b.hi.z)));
+    r.expand(xf.on_point(V3(b.lo.x, b.hi.y, b.hi.z)));
+    r.expand(xf.on_point(b.hi));
+    return r;
+}
+
+void prepare(orc_scene* s) {
+    const gbl_scene_desc& d = s->desc;
+    // meshes + per-mesh BLAS over per-triangle AABBs (GoblinModel.cpp:10-26)
+    s->meshes.resize(d.num_meshes);
+    for (uint32_t mi = 0; mi < d.num_meshes; ++mi) {
+        const gbl_mesh& gm = d.meshes[mi];
+        Mesh& m = s->meshes[mi];
+        m.pos = d.positions + 3 * static_cast<size_t>(gm.vertex_offset);
+        m.nrm = d.normals + 3 * static_cast<size_t>(gm.vertex_offset);
+        m.uv = d.uvs + 2 * static_cast<size_t>(gm.vertex_offset);
+        m.idx = d.indices + 3 * static_cast<size_t>(gm.tri_offset);
+        m.ntris = gm.tri_count;
+        m.has_n = gm.has_normal != 0;
+        m.has_uv = gm.has_uv != 0;
+        m.bounds = Box();
+        for (uint32_t v = 0; v < gm.vertex_count; ++v) m.bounds.expand(m.P(v));
+        std::vector<Box> boxes(m.ntris);
+        for (uint32_t t = 0; t < m.ntris; ++t) {   // Triangle::getObjectBound, GoblinTriangle.cpp:191-205
+            boxes[t].expand(m.P(m.idx[3 * t]));
+            boxes[t].expand(m.P(m.idx[3 * t + 1]));
+            boxes[t].expand(m.P(m.idx[3 * t + 2]));
+        }
+        m.bvh.build(boxes);
+    }
+    s->materials.assign(d.materials, d.materials + d.num_materials);
+    // instances + TLAS over instances only (GoblinScene.cpp:15, GoblinPrimitive.cpp:119-121)
+    s->instances.resize(d.num_instances);
+    std::vector<Box> iboxes(d.num_instances);
+    for (uint32_t i = 0; i < d.num_instances; ++i) {
+        const gbl_instance& gi = d.instances[i];
+        Instance& in = s->instances[i];
+        in.mesh = gi.mesh;
+        in.material = gi.material;
+        in.area_light = gi.area_light;
+        in.xf.set(gi.to_world.position, gi.to_world.orientation, gi.to_world.scale);
+        iboxes[i] = transform_box(in.xf, s->meshes[in.mesh].bounds);   // Model::getAABB = mesh bound
+    }
+    s->tlas.build(iboxes);
+    // lights
+    s->lights.resize(d.num_lights);
+    std::vector<float> powers;
+    s->light_power_rgb.clear();
+    for (uint32_t i = 0; i < d.num_lights; ++i) {
+        const gbl_light& gl = d.lights[i];
+        Light& l = s->lights[i];
+        l.type = gl.type;
+        l.color = Col(gl.color[0], gl.color[1], gl.color[2]);
+        l.pos = V3(gl.position[0], gl.position[1], gl.position[2]);
+        l.cos_max = gl.cos_theta_max;
+        l.cos_falloff = gl.cos_falloff_start;
+        l.mesh = gl.mesh;
+        Col power(0.0f);
+        if (gl.type == GBL_LIGHT_SPOT) {
+            // SpotLight ctor + Light::setOrientation (GoblinLight.cpp:212-223,66-76):
+            // direction -> basis -> Matrix3 -> Quaternion -> Transform -> column z
+            V3 dir = normalize(V3(gl.direction[0], gl.direction[1], gl.direction[2]));
+            V3 xa, ya;
+            coordinate_axes(dir, &xa, &ya);
+            float R[3][3] = {{xa.x, ya.x, dir.x}, {xa.y, ya.y, dir.y}, {xa.z, ya.z, dir.z}};
+            float q[4];
+            quat_from_matrix3(R, q);
+            float one[3] = {1.0f, 1.0f, 1.0f};
+            l.xf.set(gl.position, q, one);
+            l.spot_axis = l.xf.on_vector(V3(0.0f, 0.0f, 1.0f));
+            // SpotLight::power, GoblinLight.cpp:269-275
+            power = l.color * TWO_PI * (1.0f - 0.5f * (l.cos_max + l.cos_falloff));
+        } else if (gl.type == GBL_LIGHT_AREA) {
+            l.xf.set(gl.to_world.position, gl.to_world.orientation, gl.to_world.scale);
+            const Mesh& m = s->meshes[gl.mesh];
+            l.geo.area.resize(m.ntris);
+            l.geo.sum_area = 0.0f;
+            for (uint32_t t = 0; t < m.ntris; ++t) {
+                float a = tri_area(m, t);
+                l.geo.area[t] = a;
+                l.geo.sum_area += a;
+            }
+            // AreaLight::power, GoblinLight.cpp:446-455
+            float world_area = l.geo.sum_area * (l.xf.scale.x * l.xf.scale.y);
+            power = l.color * PI * world_area;
+        } else {
+            power = 4.0f * PI * l.color;   // PointLight::power, GoblinLight.cpp:132-134
+        }
+        s->light_power_rgb.push_back(power);
+        powers.push_back(luminance(power));
+    }
+    s->light_geo_cdf.resize(d.num_lights);
+    for (uint32_t i = 0; i < d.num_lights; ++i)
+        if (s->lights[i].type == GBL_LIGHT_AREA) s->light_geo_cdf[i].init(s->lights[i].geo.area);
+    if (!powers.empty()) s->light_power.init(powers);
+    // camera (GoblinCamera.cpp:11-19,83-95; matrixPerspectiveLHD3D GoblinMatrix.cpp:631-642)
+    const gbl_camera& c = d.camera;
+    s->cam_pos = V3(c.position[0], c.position[1], c.position[2]);
+    memcpy(s->cam_q, c.orientation, sizeof(s->cam_q));
+    float aspect = static_cast<float>(d.film.xres) / static_cast<float>(d.film.yres);
+    float fov = radians(c.fov_degrees);
+    float yscale = 1.0f / std::tan(fov / 2.0f);
+    s->proj11 = yscale;
+    s->proj00 = yscale / aspect;
+    // film (GoblinFilm.cpp:92-112,131-138)
+    const gbl_film& f = d.film;
+    s->xres = f.xres;
+    s->yres = f.yres;
+    s->xstart = ceil_int(f.xres * f.crop[0]);
+    s->xcount = std::max(1, ceil_int(f.xres * f.crop[1]) - s->xstart);
+    s->ystart = ceil_int(f.yres * f.crop[2]);
+    s->ycount = std::max(1, ceil_int(f.yres * f.crop[3]) - s->ystart);
+    s->inv_xres = 1.0f / static_cast<float>(f.xres);
+    s->inv_yres = 1.0f / static_cast<float>(f.yres);
+    build_filter_table(s);
+    s->window[0] = floor_int(s->xstart + 0.5f - s->filter_w[0]);
+    s->window[1] = floor_int(s->xstart + 0.5f + s->xcount + s->filter_w[0]);
+    s->window[2] = floor_int(s->ystart + 0.5f - s->filter_w[1]);
+    s->window[3] = floor_int(s->ystart + 0.5f + s->ycount + s->filter_w[1]);
+}
+
+// ---------------------------------------------------------------------------
+// Camera (PerspectiveCamera::generateRay pinhole branch, GoblinCamera.cpp:97-148)
+// ---------------------------------------------------------------------------
+inline Ray camera_ray(const orc_scene* s, float image_x, float image_y) {
+    float xndc = +2.0f * image_x * s->inv_xres - 1.0f;
+    float yndc = -2.0f * image_y * s->inv_yres + 1.0f;
+    float xv = xndc / s->proj00;
+    float yv = yndc / s->proj11;
+    V3 view(xv, yv, 1.0f);
+    Ray r;
+    r.o = s->cam_pos;
+    r.d = quat_rotate(s->cam_q, normalize(view));
+    r.mint = 1e-3f;
+    r.maxt = INF;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Triangle (GoblinTriangle.cpp:38-163)
+// ---------------------------------------------------------------------------
+inline bool tri_test(const Mesh& m, uint32_t t, const Ray& ray, float* t_out, float* b1_out, float* b2_out) {
+    V3 p0 = m.P(m.idx[3 * t]), p1 = m.P(m.idx[3 * t + 1]), p2 = m.P(m.idx[3 * t + 2]);
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    V3 s1 = cross(ray.d, e2);
+    float divisor = dot(s1, e1);
+    if (divisor == 0.0f) return false;
+    float inv = 1.0f / divisor;
+    const float eps = 1e-7f;
+    V3 sv = ray.o - p0;
+    float b1 = dot(sv, s1) * inv;
+    if (b1 + eps < 0.0f || b1 - eps > 1.0f) return false;
+    V3 s2 = cross(sv, e1);
+    float b2 = dot(ray.d, s2) * inv;
+    if (b2 + eps < 0.0f || b1 + b2 - eps > 1.0f) return false;
+    float tt = dot(e2, s2) * inv;
+    if (tt < ray.mint || tt > ray.maxt) return false;
+    *t_out = tt;
+    *b1_out = b1;
+    *b2_out = b2;
+    return true;
+}
+
+// Fragment outputs of Triangle::intersect (:77-123).  `prev` is the fragment
+// the caller passed in: the degenerate-uv branch reads it before overwriting
+// (:113-117).
+inline void tri_fragment(const Mesh& m, uint32_t t, const Ray& ray, float tt, float b1, float b2, Frag* f) {
+    uint32_t i0 = m.idx[3 * t], i1 = m.idx[3 * t + 1], i2 = m.idx[3 * t + 2];
+    V3 p0 = m.P(i0), p1 = m.P(i1), p2 = m.P(i2);
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    float b0 = 1.0f - b1 - b2;
+    V3 position = ray.o + tt * ray.d;
+    V3 normal;
+    if (m.has_n) normal = normalize(b0 * m.N(i0) + b1 * m.N(i1) + b2 * m.N(i2));
+    else normal = normalize(cross(e1, e2));
+    float u0, v0, u1, v1, u2, v2;
+    if (m.has_uv) {
+        u0 = m.uv[2 * i0]; v0 = m.uv[2 * i0 + 1];
+        u1 = m.uv[2 * i1]; v1 = m.uv[2 * i1 + 1];
+        u2 = m.uv[2 * i2]; v2 = m.uv[2 * i2 + 1];
+    } else {
+        u0 = 0.0f; v0 = 0.0f; u1 = 1.0f; v1 = 0.0f; u2 = 0.0f; v2 = 1.0f;
+    }
+    // Vector2: b0*uv0 + b1*uv1 + b2*uv2
+    float u = b0 * u0 + b1 * u1 + b2 * u2;
+    float v = b0 * v0 + b1 * v1 + b2 * v2;
+    float du1 = u1 - u0, dv1 = v1 - v0, du2 = u2 - u0, dv2 = v2 - v0;
+    float det = du1 * dv2 - dv1 * du2;
+    V3 dpdu, dpdv;
+    if (det == 0.0f) {
+        dpdu = normalize(e1 - dot(f->n, e1) * f->n);
+        dpdv = cross(f->n, f->dpdv);
+    } else {
+        float inv_det = 1.0f / det;
+        dpdu = inv_det * (dv2 * e1 - dv1 * e2);
+        dpdv = inv_det * (-du2 * e1 + du1 * e2);
+    }
+    f->p = position;
+    f->n = normal;
+    f->u = u;
+    f->v = v;
+    f->dpdu = dpdu;
+    f->dpdv = dpdv;
+}
+
+struct Hit {
+    Frag frag;
+    int instance = -1;
+    float epsilon = 0.0f;
+};
+
+// Scene::intersect -> TLAS -> InstancedPrimitive::intersect -> Model BLAS ->
+// Triangle::intersect (GoblinScene.cpp:75-83, GoblinPrimitive.cpp:103-112,
+// GoblinModel.cpp:39-55).  ray.maxt shrinks in place.  Frag state persists
+// across candidate hits exactly as the reference's single Intersection does.
+bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt) {
+    ++cnt->closest;
+    bool any = false;
+    traverse(s->tlas, ray, cnt, [&](uint32_t inst_id) {
+        const Instance& in = s->instances[inst_id];
+        const Mesh& m = s->meshes[in.mesh];
+        Ray r;   // Transform::invertRay: d is NOT renormalised, so t is shared
+        r.o = in.xf.invert_point(ray.o);
+        r.d = in.xf.invert_vector(ray.d);
+        r.mint = ray.mint;
+        r.maxt = ray.maxt;
+        bool h = false;
+        traverse(m.bvh, r, cnt, [&](uint32_t tri) {
+            ++cnt->tris;
+            float tt, b1, b2;
+            if (tri_test(m, tri, r, &tt, &b1, &b2)) {
+                r.maxt = tt;
+                hit->epsilon = 1e-3f * tt;
+                tri_fragment(m, tri, r, tt, b1, b2, &hit->frag);
+                hit->instance = static_cast<int>(inst_id);
+                h = true;
+            }
+            return false;
+        });
+        if (h) {
+            // Fragment::transform, GoblinGeometry.cpp:31-37
+            Frag& f = hit->frag;
+            f.p = in.xf.on_point(f.p);
+            f.n = normalize(in.xf.on_normal(f.n));
+            f.dpdu = in.xf.on_vector(f.dpdu);
+            f.dpdv = in.xf.on_vector(f.dpdv);
+            ray.maxt = r.maxt;
+            any = true;
+        }
+        return false;
+    });
+    return any;
+}
+
+bool scene_occluded(const orc_scene* s, const Ray& ray, Counters* cnt) {   // GoblinScene.cpp:85-87, GoblinBVH.cpp:189-232
+    ++cnt->anyhit;
+    bool occ = false;
+    traverse(s->tlas, ray, cnt, [&](uint32_t inst_id) {
+        const Instance& in = s->instances[inst_id];
+        const Mesh& m = s->meshes[in.mesh];
+        Ray r;
+        r.o = in.xf.invert_point(ray.o);
+        r.d = in.xf.invert_vector(ray.d);
+        r.mint = ray.mint;
+        r.maxt = ray.maxt;
+        traverse(m.bvh, r, cnt, [&](uint32_t tri) {
+            ++cnt->tris;
+            float tt, b1, b2;
+            if (tri_test(m, tri, r, &tt, &b1, &b2)) {
+                occ = true;
+                return true;
+            }
+            return false;
+        });
+        return occ;
+    });
+    return occ;
+}
+
+// A full traversal whose every leaf is rejected by the intersect filter before
+// the geometry test (Model::intersect with notOpaque in a mask-free scene,
+// GoblinModel.cpp:44-46): what evalAttenuation costs the reference
+// (GoblinPathtracer.cpp:21-48).  Only run when ref_faithful != 0.
+void scene_filtered_traversal(const orc_scene* s, const Ray& ray, Counters* cnt) {
+    ++cnt->filtered;
+    traverse(s->tlas, ray, cnt, [&](uint32_t inst_id) {
+        const Instance& in = s->instances[inst_id];
+        const Mesh& m = s->meshes[in.mesh];
+        Ray r;
+        r.o = in.xf.invert_point(ray.o);
+        r.d = in.xf.invert_vector(ray.d);
+        r.mint = ray.mint;
+        r.maxt = ray.maxt;
+        traverse(m.bvh, r, cnt, [&](uint32_t) { return false; });
+        return false;
+    });
+}
+
+// Fragment::getWorldToShade rows t, b, n (GoblinGeometry.cpp:17-29)
+struct Frame {
+    V3 t, b, n;
+};
+inline Frame shade_frame(const Frag& f) {
+    Frame fr;
+    fr.n = f.n;
+    fr.t = normalize(f.dpdu - fr.n * dot(f.dpdu, fr.n));
+    fr.b = cross(fr.n, fr.t);
+    return fr;
+}
+// shadeToWorld * v with shadeToWorld = worldToShade^T (Matrix3 * Vector3 row dot products)
+inline V3 shade_to_world(const Frame& fr, V3 v) {
+    return V3(fr.t.x * v.x + fr.b.x * v.y + fr.n.x * v.z, fr.t.y * v.x + fr.b.y * v.y + fr.n.y * v.z,
+              fr.t.z * v.x + fr.b.z * v.y + fr.n.z * v.z);
+}
+
+// ---------------------------------------------------------------------------
+// Sampling warps (GoblinSampler.cpp:420-575)
+// ---------------------------------------------------------------------------
+inline V3 cosine_sample_hemisphere(float u1, float u2) {   // :549-557
+    float sin_t = sqrtf(u1);
+    float cos_t = sqrtf(std::max(0.0f, 1.0f - u1));
+    float phi = TWO_PI * u2;
+    float z = cos_t;
+    float x = sin_t * std::cos(phi);
+    float y = sin_t * std::sin(phi);
+    return V3(x, y, z);
+}
+inline V3 uniform_sample_hemisphere(float u1, float u2) {   // :517-524
+    float z = u1;
+    float sin_t = sqrtf(std::max(0.0f, 1.0f - u1 * u1));
+    float phi = TWO_PI * u2;
+    float x = sin_t * std::cos(phi);
+    float y = sin_t * std::sin(phi);
+    return V3(x, y, z);
+}
+inline float power_heuristic(float na, float pa, float nb, float pb) {   // GoblinSampler.h:286-290
+    float A = na * pa, B = nb * pb;
+    return A * A / (A * A + B * B);
+}
+
+// ---------------------------------------------------------------------------
+// Materials (GoblinMaterial.cpp)
+// ---------------------------------------------------------------------------
+enum { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_NULL = 32, BSDF_ALL = 63 };
+
+inline int material_type_bits(const gbl_material& m) {
+    switch (m.type) {
+        case GBL_MAT_BLINN: return BSDF_GLOSSY | BSDF_REFLECTION;
+        case GBL_MAT_TRANSPARENT: return BSDF_SPECULAR | BSDF_REFLECTION | BSDF_TRANSMISSION;
+        case GBL_MAT_MIRROR: return BSDF_SPECULAR | BSDF_REFLECTION;
+        default: return BSDF_DIFFUSE | BSDF_REFLECTION;
+    }
+}
+inline bool match_type(int type, int to_match) { return (type & to_match) == to_match; }
+inline int sample_type(V3 wo, V3 wi, V3 n, int type) {   // Material::getSampleType, :285-294
+    if (dot(n, wo) * dot(n, wi) > 0.0f) return type & ~BSDF_TRANSMISSION;
+    return type & ~BSDF_REFLECTION;
+}
+inline bool same_hemisphere(V3 n, V3 wo, V3 wi) { return dot(wo, n) * dot(wi, n) > 0.0f; }
+
+float fresnel_dielectric(float cosi, float etai, float etat) {   // :390-406
+    cosi = clampf(cosi, -1.0f, 1.0f);
+    float sint = (etai / etat) * std::sqrt(std::max(0.0f, 1.0f - cosi * cosi));
+    if (sint >= 1.0f) return 1.0f;
+    float cost = std::sqrt(std::max(0.0f, 1 - sint * sint));
+    cosi = std::fabs(cosi);
+    float r_parl = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    float r_perp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
+}
+float fresnel_conductor(float cosi, float eta, float k) {   // :408-416
+    float tmp = (eta * eta + k * k);
+    float cosi2 = cosi * cosi;
+    float r_parl2 = (tmp * cosi2 - 2.0f * eta * cosi + 1.0f) / (tmp * cosi2 + 2.0f * eta * cosi + 1.0f);
+    float r_perp2 = (tmp - 2.0f * eta * cosi + cosi2) / (tmp + 2.0f * eta * cosi + cosi2);
+    return (r_parl2 + r_perp2) * 0.5f;
+}
+float specular_reflect_dielectric(V3 n, V3 wo, V3* wi, float etai, float etat) {   // :306-327
+    float cosi = dot(n, wo);
+    float ei = etai, et = etat;
+    if (!(cosi > 0.0f)) {
+        std::swap(ei, et);
+        n = -n;
+        cosi = -cosi;
+    }
+    float f = fresnel_dielectric(cosi, ei, et);
+    *wi = 2 * cosi * n - wo;
+    float cosr = cosi;
+    return f / cosr;
+}
+float specular_reflect_conductor(V3 n, V3 wo, V3* wi, float eta, float k) {   // :329-341
+    float cosi = dot(n, wo);
+    if (cosi <= 0.0f) return 0.0f;
+    float f = fresnel_conductor(cosi, eta, k);
+    *wi = 2 * cosi * n - wo;
+    float cosr = cosi;
+    return f / cosr;
+}
+float specular_refract(V3 n, V3 wo, V3* wi, float etao, float etai) {   // :343-387, radiance mode
+    float coso = dot(n, wo);
+    float et = etao, ei = etai;
+    if (!(coso > 0.0f)) {
+        std::swap(ei, et);
+        n = -n;
+        coso = -coso;
+    }
+    float f = fresnel_dielectric(coso, et, ei);
+    if (f == 1.0f) return 0.0f;
+    float eta = et / ei;
+    *wi = normalize(n * (eta * coso - std::sqrt(std::max(0.0f, 1.0f - eta * eta * (1.0f - coso * coso)))) - eta * wo);
+    return eta * eta * (1.0f - f) / absdot(*wi, n);
+}
+
+inline Col mat_color(const gbl_material& m) { return Col(m.color[0], m.color[1], m.color[2]); }
+inline Col mat_color2(const gbl_material& m) { return Col(m.color2[0], m.color2[1], m.color2[2]); }
+
+Col blinn_bsdf(const gbl_material& m, V3 n, V3 wo, V3 wi, int type) {   // :540-570
+    type = sample_type(wo, wi, n, type);
+    if (!match_type(type, BSDF_GLOSSY | BSDF_REFLECTION)) return BLACK;
+    float cosi = absdot(n, wi), coso = absdot(n, wo);
+    if (cosi == 0.0f || coso == 0.0f) return BLACK;
+    V3 wh = normalize(wo + wi);
+    float cosh = absdot(n, wh);
+    float e = m.exponent;
+    float D = (e + 2.0f) * INV_TWOPI * std::pow(cosh, e);
+    float wo_wh = absdot(wo, wh);
+    float G = std::min(1.0f, std::min(2.0f * cosh * coso / wo_wh, 2.0f * cosh * cosi / wo_wh));
+    float F = m.k > 0.0f ? fresnel_conductor(wo_wh, m.index, m.k) : fresnel_dielectric(wo_wh, 1.0f, m.index);
+    return mat_color(m) * D * G * F / (4.0f * cosi * coso);
+}
+float blinn_pdf(const gbl_material& m, V3 n, V3 wo, V3 wi) {   // :629-644
+    if (!same_hemisphere(n, wo, wi)) return 0.0f;
+    V3 wh = normalize(wo + wi);
+    float cos_h = absdot(wh, n);
+    float e = m.exponent;
+    return (e + 1.0f) * std::pow(cos_h, e) / (TWO_PI * 4.0f * dot(wo, wh));
+}
+
+// material->bsdf(fragment, wo, wi) with the defaults BSDFAll / BSDFRadiance
+Col mat_bsdf(const gbl_material& m, V3 n, V3 wo, V3 wi) {
+    switch (m.type) {
+        case GBL_MAT_LAMBERT: {   // :437-446
+            Col f(BLACK);
+            int type = sample_type(wo, wi, n, BSDF_ALL);
+            if (match_type(type, BSDF_DIFFUSE | BSDF_REFLECTION)) f += mat_color(m) * INV_PI;
+            return f;
+        }
+        case GBL_MAT_BLINN: return blinn_bsdf(m, n, wo, wi, BSDF_ALL);
+        default: return BLACK;   // transparent / mirror: GoblinMaterial.h:306-309,346-350
+    }
+}
+float mat_pdf(const gbl_material& m, V3 n, V3 wo, V3 wi) {
+    switch (m.type) {
+        case GBL_MAT_LAMBERT: return same_hemisphere(n, wo, wi) ? absdot(n, wi) * INV_PI : 0.0f;   // :472-480
+        case GBL_MAT_BLINN: return blinn_pdf(m, n, wo, wi);
+        default: return 0.0f;
+    }
+}
+
+// material->sampleBSDF(fragment, wo, bs, &wi, &pdf, BSDFAll, &sampledType)
+Col mat_sample(const gbl_material& m, const Frag& frag, V3 wo, float u_comp, float u1, float u2, V3* wi, float* pdf, int* sampled) {
+    V3 n = frag.n;
+    switch (m.type) {
+        case GBL_MAT_LAMBERT: {   // :448-470
+            V3 local = cosine_sample_hemisphere(u1, u2);
+            if (dot(wo, n) < 0.0f) local = local * -1.0f;
+            *wi = shade_to_world(shade_frame(frag), local);
+            *pdf = mat_pdf(m, n, wo, *wi);
+            *sampled = BSDF_DIFFUSE | BSDF_REFLECTION;
+            return mat_color(m) * INV_PI;
+        }
+        case GBL_MAT_BLINN: {   // :594-623
+            float e = m.exponent;
+            float cos_t = std::pow(u1, 1.0f / (e + 1.0f));
+            float sin_t = sqrtf(std::max(0.0f, 1.0f - cos_t * cos_t));
+            float phi = u2 * TWO_PI;
+            V3 wh_local(sin_t * std::cos(phi), sin_t * std::sin(phi), cos_t);
+            if (dot(wo, n) < 0.0f) wh_local = wh_local * -1.0f;
+            V3 wh = shade_to_world(shade_frame(frag), wh_local);
+            *wi = -wo + 2.0f * dot(wo, wh) * wh;
+            *pdf = blinn_pdf(m, n, wo, *wi);
+            *sampled = BSDF_GLOSSY | BSDF_REFLECTION;
+            return blinn_bsdf(m, n, wo, *wi, BSDF_GLOSSY | BSDF_REFLECTION);
+        }
+        case GBL_MAT_TRANSPARENT: {   // :647-706 with type == BSDFAll -> nMatch == 2
+            V3 w_refl(0, 0, 0), w_refr(0, 0, 0);
+            float reflect = specular_reflect_dielectric(n, wo, &w_refl, 1.0f, m.index);
+            float refract = specular_refract(n, wo, &w_refr, 1.0f, m.index);
+            float fresnel = reflect * absdot(w_refl, n);
+            float chance = fresnel;
+            if (u_comp < chance) {
+                *wi = w_refl;
+                *sampled = BSDF_SPECULAR | BSDF_REFLECTION;
+                *pdf = chance;
+                return mat_color(m) * reflect;
+            }
+            *wi = w_refr;
+            *sampled = BSDF_SPECULAR | BSDF_TRANSMISSION;
+            *pdf = 1.0f - chance;
+            return mat_color2(m) * refract;
+        }
+        default: {   // mirror, :709-726
+            *wi = V3(0, 0, 0);
+            Col f = mat_color(m) * specular_reflect_conductor(n, wo, wi, m.index, m.k);
+            *pdf = 1.0f;
+            *sampled = BSDF_SPECULAR | BSDF_REFLECTION;
+            return f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Lights (GoblinLight.cpp)
+// ---------------------------------------------------------------------------
+float spot_falloff(const Light& l, V3 w) {   // :277-287
+    float cos_t = dot(w, l.spot_axis);
+    if (cos_t < l.cos_max) return 0.0f;
+    if (cos_t > l.cos_falloff) return 1.0f;
+    float d = (cos_t - l.cos_max) / (l.cos_falloff - l.cos_max);
+    return d * d * d * d;
+}
+
+// Geometry::pdf for one light triangle in light-local space (GoblinGeometry.cpp:44-62)
+float tri_pdf(const Mesh& m, uint32_t t, float area, V3 p, V3 wi) {
+    Ray ray;
+    ray.o = p;
+    ray.d = wi;
+    ray.mint = 1e-3f;
+    ray.maxt = INF;
+    float tt, b1, b2;
+    if (!tri_test(m, t, ray, &tt, &b1, &b2)) return 0.0f;
+    Frag f;
+    f.n = V3(0, 0, 0);
+    f.dpdv = V3(0, 0, 0);
+    tri_fragment(m, t, ray, tt, b1, b2, &f);
+    float pdf = sqlen(p - f.p) / (area * absdot(-wi, f.n));
+    if (std::isinf(pdf)) pdf = 0.0f;
+    return pdf;
+}
+float geoset_pdf(const orc_scene* s, const Light& l, V3 p, V3 wi) {   // GeometrySet::pdf, :336-343
+    const Mesh& m = s->meshes[l.mesh];
+    float pdf = 0.0f;
+    for (uint32_t t = 0; t < m.ntris; ++t) pdf += l.geo.area[t] * tri_pdf(m, t, l.geo.area[t], p, wi);
+    pdf /= l.geo.sum_area;
+    return pdf;
+}
+
+// light->sampleL(p, epsilon, ls, &wi, &pdf, &shadowRay)
+Col light_sample(const orc_scene* s, int li, V3 p, float epsilon, float u_comp, float u1, float u2, V3* wi, float* pdf, Ray* shadow) {
+    const Light& l = s->lights[li];
+    if (l.type == GBL_LIGHT_AREA) {   // AreaLight::sampleL, :373-394
+        const Mesh& m = s->meshes[l.mesh];
+        V3 p_local = l.xf.invert_point(p);
+        int tri = s->light_geo_cdf[li].sample_discrete(u_comp, nullptr);   // GeometrySet::sample, :313-323
+        // Triangle::sample, GoblinTriangle.cpp:165-177 ; uniformSampleTriangle GoblinSampler.cpp:420-424
+        float root = sqrtf(u1);
+        float b0 = 1.0f - root, b1 = root * u2;
+        V3 p0 = m.P(m.idx[3 * tri]), p1 = m.P(m.idx[3 * tri + 1]), p2 = m.P(m.idx[3 * tri + 2]);
+        V3 ns_local = normalize(cross(p1 - p0, p2 - p0));
+        V3 ps_local = b0 * p0 + b1 * p1 + (1.0f - b0 - b1) * p2;
+        V3 wi_local = normalize(ps_local - p_local);
+        *pdf = geoset_pdf(s, l, p_local, wi_local);
+        V3 ps = l.xf.on_point(ps_local);
+        V3 ns = normalize(l.xf.on_normal(ns_local));
+        *wi = normalize(ps - p);
+        shadow->o = p;
+        shadow->d = *wi;
+        shadow->mint = epsilon;
+        shadow->maxt = length(ps - p) - epsilon;
+        return dot(ns, -*wi) > 0.0f ? l.color : BLACK;   // AreaLight::L, :368-371
+    }
+    // PointLight / SpotLight::sampleL, :87-99 / :225-237
+    V3 dir = l.pos - p;
+    *wi = normalize(dir);
+    *pdf = 1.0f;
+    shadow->o = p;
+    shadow->d = *wi;
+    shadow->mint = epsilon;
+    float d2 = sqlen(dir);
+    shadow->maxt = std::sqrt(d2) - epsilon;
+    if (l.type == GBL_LIGHT_SPOT) return spot_falloff(l, -(*wi)) * l.color / d2;
+    return l.color / d2;
+}
+float light_pdf(const orc_scene* s, int li, V3 p, V3 wi) {   // Light::pdf default 0 ; AreaLight::pdf :457-461
+    const Light& l = s->lights[li];
+    if (l.type != GBL_LIGHT_AREA) return 0.0f;
+    return geoset_pdf(s, l, l.xf.invert_point(p), l.xf.invert_vector(wi));
+}
+inline bool light_is_delta(const Light& l) { return l.type != GBL_LIGHT_AREA; }
+
+// Intersection::Le, GoblinPrimitive.cpp:8-14
+Col hit_Le(const orc_scene* s, const Hit& h, V3 out_dir) {
+    int al = s->instances[h.instance].area_light;
+    if (al < 0) return BLACK;
+    return dot(h.frag.n, out_dir) > 0.0f ? s->lights[al].color : BLACK;
+}
+
+// ---------------------------------------------------------------------------
+// Sample record layout: {imageX, imageY, lensU1, lensU2, u1D[0].., u2D[0]..}
+// (Sample::allocateQuota, GoblinSampler.cpp:35-58).
+// ---------------------------------------------------------------------------
+struct Quota {
+    std::vector<uint32_t> n1, n2;
+    std::vector<uint32_t> off1, off2;   // float offsets into the record (after the 4 header floats)
+    uint32_t size = 0;
+    uint32_t one_d(uint32_t n) {   // SampleQuota::requestOneDQuota, :23-27
+        n1.push_back(round_to_square(n));
+        return static_cast<uint32_t>(n1.size() - 1);
+    }
+    uint32_t two_d(uint32_t n) {   // requestTwoDQuota, :29-33
+        n2.push_back(round_to_square(round_to_square(n)));
+        return static_cast<uint32_t>(n2.size() - 1);
+    }
+    void finish() {
+        uint32_t o = 4;
+        off1.clear();
+        off2.clear();
+        for (uint32_t n : n1) {
+            off1.push_back(o);
+            o += n;
+        }
+        for (uint32_t n : n2) {
+            off2.push_back(o);
+            o += 2 * n;
+        }
+        size = o - 4;
+    }
+    uint32_t dims() const { return size + 4; }
+};
+
+struct PtIndices {   // PathTracer::querySampleQuota, GoblinPathtracer.cpp:181-208
+    std::vector<uint32_t> light1, light2, bsdf1, bsdf2, pick;
+};
+
+Quota pt_quota(const gbl_render_setting& rs, PtIndices* ix) {
+    Quota q;
+    int bounces = std::max(1, rs.max_ray_depth);
+    for (int i = 0; i < bounces; ++i) {
+        uint32_t l1 = q.one_d(1), l2 = q.two_d(1);   // LightSampleIndex, GoblinLight.cpp:11-20
+        uint32_t b1 = q.one_d(1), b2 = q.two_d(1);   // BSDFSampleIndex, GoblinMaterial.cpp:15-24
+        uint32_t pk = q.one_d(1);
+        if (ix) {
+            ix->light1.push_back(l1); ix->light2.push_back(l2);
+            ix->bsdf1.push_back(b1); ix->bsdf2.push_back(b2);
+            ix->pick.push_back(pk);
+        }
+    }
+    // BSSRDFSampleIndex, GoblinLight.cpp:35-43
+    int n = rs.bssrdf_sample_num;
+    q.one_d(n); q.two_d(n);   // lsIndex
+    q.one_d(n);               // pickLight
+    q.one_d(n);               // pickAxis
+    q.two_d(n);               // disc
+    q.one_d(n);               // singleScatter
+    q.finish();
+    return q;
+}
+
+Quota ao_quota(const gbl_render_setting& rs) {   // AORenderer::querySampleQuota, GoblinAO.cpp:39-42
+    Quota q;
+    q.two_d(rs.ao_sample_num);
+    q.finish();
+    return q;
+}
+
+// ---------------------------------------------------------------------------
+// RNG (GoblinUtils.cpp:13-56): mt19937 seeded with the next value of the
+// process-global, never-seeded libc rand(); floats via
+// uniform_real_distribution<float>(0,1), uints via uniform_int_distribution.
+// glibc's rand() is the TYPE_3 additive-feedback generator r[i] = r[i-3] +
+// r[i-31] seeded with 1; restated here so the oracle does not depend on (or
+// disturb) the process-global state.  tests/ check it against libc itself.
+// ---------------------------------------------------------------------------
+struct GlibcRand {
+    int32_t r[34];
+    std::vector<uint32_t> st;
+    size_t k;
+    explicit GlibcRand(uint32_t seed = 1) {
+        r[0] = static_cast<int32_t>(seed);
+        for (int i = 1; i < 31; ++i) {
+            int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+            int64_t w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            r[i] = static_cast<int32_t>(w);
+        }
+        st.resize(344);
+        for (int i = 0; i < 31; ++i) st[i] = static_cast<uint32_t>(r[i]);
+        for (int i = 31; i < 34; ++i) st[i] = st[i - 31];
+        for (int i = 34; i < 344; ++i) st[i] = st[i - 31] + st[i - 3];
+        k = 344;
+    }
+    int next() {
+        uint32_t v = st[k - 31] + st[k - 3];
+        st.push_back(v);
+        ++k;
+        return static_cast<int>(v >> 1);
+    }
+};
+
+struct Rng {
+    std::mt19937 engine;
+    std::uniform_real_distribution<float> real{0.0f, 1.0f};
+    std::uniform_int_distribution<uint32_t> uint{0, std::numeric_limits<uint32_t>::max()};
+    explicit Rng(uint32_t seed) : engine(seed) {}
+    float f() { return real(engine); }
+    uint32_t u() { return uint(engine); }
+};
+
+template <class T>
+void shuffle(T* buf, uint32_t num, uint32_t dim, Rng* rng) {   // GoblinSampler.h:149-157
+    for (uint32_t n = 0; n < num; ++n) {
+        size_t other = rng->u() % num;
+        for (uint32_t d = 0; d < dim; ++d) std::swap(buf[n * dim + d], buf[other * dim + d]);
+    }
+}
+
+// Sampler (GoblinSampler.cpp:60-307) over one SampleRange, emitting flattened records.
+struct Sampler {
+    int x0, x1, y0, y1, cx, cy, spp, root;
+    const Quota& q;
+    Rng* rng;
+    std::vector<float> buf;
+    Sampler(int xs, int xe, int ys, int ye, int sample_per_pixel, const Quota& quota, Rng* r)
+        : x0(xs), x1(xe), y0(ys), y1(ye), cx(xs), cy(ys), q(quota), rng(r) {
+        spp = round_to_square(sample_per_pixel, &root);
+    }
+    void strat1(float* b, uint32_t n) {   // stratifiedUniform1D, :276-286
+        float strata = 1.0f / static_cast<float>(n);
+        float sub = strata / spp;
+        for (uint32_t i = 0; i < n; ++i)
+            for (int j = 0; j < spp; ++j) {
+                float off = j + rng->f();
+                b[i * spp + j] = i * strata + off * sub;
+            }
+    }
+    void strat2(float* b, uint32_t n) {   // stratifiedUniform2D, :288-307
+        int r = static_cast<int>(sqrtf(static_cast<float>(n)));
+        float strata = 1.0f / r;
+        float sub = strata / root;
+        for (uint32_t k = 0; k < n; ++k) {
+            int ux = k % r, uy = k / r;
+            for (int p = 0; p < spp; ++p) {
+                int px = p % root, py = p / root;
+                float xo = px + rng->f();
+                float yo = py + rng->f();
+                int index = 2 * (k * spp + py * root + px);
+                b[index] = ux * strata + xo * sub;
+                b[index + 1] = uy * strata + yo * sub;
+            }
+        }
+    }
+    // requestSamples, :108-197.  out: spp records of q.dims() floats.
+    int request(float* out) {
+        if (cy == y1) return 0;
+        if (buf.empty()) buf.resize(static_cast<size_t>(spp) * (4 + q.size));
+        uint32_t dims = q.dims();
+        float* image = buf.data();
+        float* lens = image + 2 * spp;
+        float* quota = image + 4 * spp;
+        strat2(image, 1);
+        strat2(lens, 1);
+        float* cur = quota;
+        for (uint32_t n : q.n1) {
+            strat1(cur, n);
+            cur += n * spp;
+        }
+        for (uint32_t n : q.n2) {
+            strat2(cur, n);
+            cur += 2 * n * spp;
+        }
+        shuffle(lens, spp, 2, rng);
+        float* sh = quota;
+        for (uint32_t n : q.n1)
+            for (uint32_t j = 0; j < n; ++j) {
+                shuffle(sh, spp, 1, rng);
+                sh += spp;
+            }
+        for (uint32_t n : q.n2)
+            for (uint32_t j = 0; j < n; ++j) {
+                shuffle(sh, spp, 2, rng);
+                sh += 2 * spp;
+            }
+        for (int i = 0; i < spp; ++i) {
+            float* rec = out + static_cast<size_t>(i) * dims;
+            rec[0] = cx + image[2 * i];
+            rec[1] = cy + image[2 * i + 1];
+            rec[2] = lens[2 * i];
+            rec[3] = lens[2 * i + 1];
+        }
+        float* fill = quota;
+        for (size_t i = 0; i < q.n1.size(); ++i)
+            for (uint32_t j = 0; j < q.n1[i]; ++j) {
+                for (int k = 0; k < spp; ++k) out[static_cast<size_t>(k) * dims + q.off1[i] + j] = fill[k];
+                fill += spp;
+            }
+        for (size_t i = 0; i < q.n2.size(); ++i)
+            for (uint32_t j = 0; j < q.n2[i]; ++j) {
+                for (int k = 0; k < spp; ++k) {
+                    float* rec = out + static_cast<size_t>(k) * dims + q.off2[i];
+                    rec[2 * j] = fill[2 * k];
+                    rec[2 * j + 1] = fill[2 * k + 1];
+                }
+                fill += 2 * spp;
+            }
+        for (int i = 0; i < spp; ++i) {
+            float* rec = out + static_cast<size_t>(i) * dims;
+            for (size_t j = 0; j < q.n1.size(); ++j) shuffle(rec + q.off1[j], q.n1[j], 1, rng);
+            for (size_t j = 0; j < q.n2.size(); ++j) shuffle(rec + q.off2[j], q.n2[j], 2, rng);
+        }
+        if (++cx == x1) {
+            cx = x0;
+            cy++;
+        }
+        return spp;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Integrators
+// ---------------------------------------------------------------------------
+struct LiCtx {
+    const orc_scene* s;
+    const gbl_render_setting* rs;
+    const Quota* q;
+    const PtIndices* ix;
+    Rng* rng;          // null in replay: the three discarded draws are skipped
+    int ref_faithful;  // also run the reference's redundant traversals
+    Counters cnt;
+    uint64_t dims_used = 0;
+};
+
+// BSDFSample(rng), GoblinMaterial.cpp:26-30 -- three draws whose values never
+// matter in a mask-free scene but which advance the tile's stream.
+inline void draw_bsdf_sample(LiCtx* c) {
+    if (c->rng) {
+        c->rng->f();
+        c->rng->f();
+        c->rng->f();
+    }
+}
+
+// PathTracer::evalAttenuation, GoblinPathtracer.cpp:21-48: identity without BSDFnullptr materials.
+inline Col eval_attenuation(LiCtx* c, const Ray& ray) {
+    if (c->ref_faithful) scene_filtered_traversal(c->s, ray, &c->cnt);
+    return Col(1.0f);
+}
+
+// PathTracer::Li, GoblinPathtracer.cpp:50-179
+Col path_li(LiCtx* c, const Ray& primary, const float* rec) {
+    const orc_scene* s = c->s;
+    if (s->lights.empty()) return Col(0.0f);
+    Col Li(0.0f);
+    Ray ray = primary;
+    Hit hit;
+    hit.frag.n = V3(0, 0, 0);
+    hit.frag.dpdv = V3(0, 0, 0);
+    if (!scene_intersect(s, ray, &hit, &c->cnt)) return Li;   // no IBL lights on this path: evalEnvironmentLight = 0
+    Li += hit_Le(s, hit, -ray.d);
+    // Lsubsurface: 0 without a BSSRDF (GoblinRenderer.cpp:282-286)
+    Ray cur = ray;
+    Col throughput(1.0f);
+    float epsilon = hit.epsilon;
+    for (int bounce = 0; bounce < c->rs->max_ray_depth - 1; ++bounce) {
+        float ls_comp = rec[c->q->off1[c->ix->light1[bounce]]];
+        const float* ls_geo = rec + c->q->off2[c->ix->light2[bounce]];
+        float bs_comp = rec[c->q->off1[c->ix->bsdf1[bounce]]];
+        const float* bs_dir = rec + c->q->off2[c->ix->bsdf2[bounce]];
+        float pick = rec[c->q->off1[c->ix->pick[bounce]]];
+        c->dims_used += 7;
+        float pick_pdf;
+        int light = s->light_power.sample_discrete(pick, &pick_pdf);   // Scene::sampleLight, GoblinScene.cpp:97-104
+        Col Ld(0.0f);
+        const gbl_material& mat = s->materials[s->instances[hit.instance].material];
+        const Frag& frag = hit.frag;
+        V3 wo = -cur.d;
+        V3 wi;
+        V3 p = frag.p, n = frag.n;
+        float light_pdf_v, bsdf_pdf;
+        Ray shadow;
+        Col L = light_sample(s, light, p, epsilon, ls_comp, ls_geo[0], ls_geo[1], &wi, &light_pdf_v, &shadow);
+        if (L != BLACK && light_pdf_v > 0.0f) {
+            Col f = mat_bsdf(mat, n, wo, wi);
+            if (f != BLACK && !scene_occluded(s, shadow, &c->cnt)) {
+                draw_bsdf_sample(c);
+                Col tr = eval_attenuation(c, shadow);
+                if (light_is_delta(s->lights[light])) {
+                    Ld += f * tr * L * absdot(n, wi) / light_pdf_v;
+                } else {
+                    bsdf_pdf = mat_pdf(mat, n, wo, wi);
+                    float lw = power_heuristic(1, light_pdf_v, 1, bsdf_pdf);
+                    Ld += f * tr * L * absdot(n, wi) * lw / light_pdf_v;
+                }
+            }
+        }
+        int sampled = 0;
+        Col f = mat_sample(mat, frag, wo, bs_comp, bs_dir[0], bs_dir[1], &wi, &bsdf_pdf, &sampled);
+        if (f != BLACK && bsdf_pdf > 0.0f) {
+            // (sampledType == BSDFnullptr cannot happen without mask materials)
+            float fw = 1.0f;
+            if (!(sampled & BSDF_SPECULAR)) {
+                light_pdf_v = light_pdf(s, light, p, wi);
+                fw = power_heuristic(1, bsdf_pdf, 1, light_pdf_v);
+            }
+            Ray r;
+            r.o = p; r.d = wi; r.mint = epsilon; r.maxt = INF;
+            // The reference traces this "MIS ray" and then the identical
+            // extension ray below.  Unless asked to be faithful to that cost we
+            // trace it once and reuse the hit.
+            Hit lh;
+            lh.frag = hit.frag;
+            Ray rr = r;
+            bool lhit = scene_intersect(s, rr, &lh, &c->cnt);
+            if (lhit) {
+                draw_bsdf_sample(c);
+                Col tr = eval_attenuation(c, r);
+                if (s->instances[lh.instance].area_light == light) {
+                    Col Le = hit_Le(s, lh, -wi);
+                    if (Le != BLACK) Ld += f * tr * Le * absdot(wi, n) * fw / bsdf_pdf;
+                }
+            } else {
+                draw_bsdf_sample(c);
+                Col tr = eval_attenuation(c, r);
+                (void)tr;   // light->Le(r) is Black for every light on this path (IBL only)
+            }
+            Li += throughput * Ld / pick_pdf;
+            throughput *= f * absdot(wi, n) / bsdf_pdf;
+            if (c->ref_faithful) {   // the second, identical closest-hit query (GoblinPathtracer.cpp:170)
+                Hit again;
+                again.frag = hit.frag;
+                Ray r2 = r;
+                scene_intersect(s, r2, &again, &c->cnt);
+            }
+            if (!lhit) break;
+            cur = r;
+            cur.maxt = rr.maxt;
+            // The reference's second query starts from the previous bounce's
+            // Intersection; only the degenerate-uv branch could tell the
+            // difference, and it reads fields both queries overwrite alike.
+            hit = lh;
+            epsilon = lh.epsilon;
+        } else {
+            Li += throughput * Ld / pick_pdf;
+            break;
+        }
+    }
+    return Li;
+}
+
+// AORenderer::Li, GoblinAO.cpp:12-37
+Col ao_li(LiCtx* c, const Ray& primary, const float* rec) {
+    const orc_scene* s = c->s;
+    Col Li = BLACK;
+    Ray ray = primary;
+    Hit hit;
+    hit.frag.n = V3(0, 0, 0);
+    hit.frag.dpdv = V3(0, 0, 0);
+    if (scene_intersect(s, ray, &hit, &c->cnt)) {
+        uint32_t n = static_cast<uint32_t>(round_to_square(c->rs->ao_sample_num));   // SampleIndex.sampleNum
+        uint32_t occluded = 0;
+        const float* u = rec + c->q->off2[0];
+        Frame fr = shade_frame(hit.frag);
+        for (uint32_t i = 0; i < n; ++i) {
+            V3 dir = uniform_sample_hemisphere(u[2 * i], u[2 * i + 1]);
+            V3 wdir = shade_to_world(fr, dir);
+            Ray occ;
+            occ.o = hit.frag.p; occ.d = wdir; occ.mint = hit.epsilon; occ.maxt = INF;
+            if (scene_occluded(s, occ, &c->cnt)) ++occluded;
+        }
+        c->dims_used += 2 * n;
+        Li = Col(static_cast<float>(n - occluded) / static_cast<float>(n));
+    }
+    return Li;
+}
+
+inline Col eval_li(LiCtx* c, const float* rec) {
+    Ray ray = camera_ray(c->s, rec[0], rec[1]);
+    c->dims_used += 2;
+    return c->rs->integrator == GBL_INTEGRATOR_AO ? ao_li(c, ray, rec) : path_li(c, ray, rec);
+}
+
+// ---------------------------------------------------------------------------
+// "Native" sampler: the counter-based law the device path uses, restated here
+// bit-for-bit (integer hashing only) so GPU-native renders can be checked
+// sample by sample.  Same stratification as Sampler::requestSamples: every
+// pattern is jittered over (strata x per-pixel sub-strata) and the sub-stratum
+// a camera sample receives is a per-(pixel, pattern, stratum) permutation of
+// the sample index; image samples are not permuted (GoblinSampler.cpp:130-131).
+// Definition shared with goblin_amd/csrc/kernels/sampler.hip.h (restated there,
+// not included from here).
+// ---------------------------------------------------------------------------
+inline uint32_t nat_mix(uint32_t a, uint32_t b) {
+    uint32_t h = (a ^ 0x9E3779B9u) * 0x85EBCA6Bu;
+    h ^= b + 0x7F4A7C15u + (h << 6) + (h >> 2);
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+inline float nat_u01(uint32_t h) { return static_cast<float>(h >> 8) * (1.0f / 16777216.0f); }
+// keyed bijection on [0, n): cycle-walked 3-round xor/multiply/xorshift network on the next power of two
+inline uint32_t nat_permute(uint32_t i, uint32_t n, uint32_t key) {
+    if (n <= 1) return 0;
+    uint32_t w = n - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    uint32_t k1 = nat_mix(key, 0x3C6EF372u) | 1u, k2 = nat_mix(key, 0xDAA66D2Bu) | 1u;
+    do {
+        i ^= key & w;
+        i = (i * k1) & w;
+        i ^= i >> 3;
+        i ^= (key >> 11) & w;
+        i = (i * k2) & w;
+        i ^= i >> 5;
+        i = (i * 0x2C1B3C6Du) & w;
+        i ^= i >> 2;
+    } while (i >= n);
+    return i;
+}
+
+struct NativeSampler {
+    uint32_t seed_key;
+    int spp, root;
+    NativeSampler(uint64_t seed, int sample_per_pixel) {
+        spp = round_to_square(sample_per_pixel, &root);
+        seed_key = nat_mix(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+    }
+    // pattern ids: 0 image, 1 lens, 2+i one-D pattern i, 0x10000+i two-D pattern i
+    uint32_t key(uint32_t pixel, uint32_t pattern, uint32_t stratum) const {
+        return nat_mix(nat_mix(nat_mix(seed_key, pixel), pattern), stratum);
+    }
+    float one_d(uint32_t pixel, uint32_t pattern, uint32_t n, uint32_t i, uint32_t k) const {
+        uint32_t ky = key(pixel, 2 + pattern, i);
+        uint32_t j = nat_permute(k, spp, ky);
+        float strata = 1.0f / static_cast<float>(n);
+        float sub = strata / spp;
+        float off = j + nat_u01(nat_mix(ky, k));
+        return i * strata + off * sub;
+    }
+    void two_d(uint32_t pixel, uint32_t pattern_id, uint32_t n, uint32_t i, uint32_t k, bool permute, float out[2]) const {
+        uint32_t ky = key(pixel, pattern_id, i);
+        uint32_t p = permute ? nat_permute(k, spp, ky) : k;
+        int r = static_cast<int>(sqrtf(static_cast<float>(n)));
+        float strata = 1.0f / r;
+        float sub = strata / root;
+        int ux = i % r, uy = i / r;
+        int px = p % root, py = p / root;
+        float xo = px + nat_u01(nat_mix(ky, 2 * k));
+        float yo = py + nat_u01(nat_mix(ky, 2 * k + 1));
+        out[0] = ux * strata + xo * sub;
+        out[1] = uy * strata + yo * sub;
+    }
+    // Fill one record.  `pixel` = linear index in the FULL sample window, so a
+    // sharded render draws the same numbers as a whole one.
+    void fill(const Quota& q, uint32_t pixel, int px, int py, uint32_t k, float* rec) const {
+        float im[2], ln[2];
+        two_d(pixel, 0, 1, 0, k, false, im);
+        two_d(pixel, 1, 1, 0, k, true, ln);
+        rec[0] = px + im[0];
+        rec[1] = py + im[1];
+        rec[2] = ln[0];
+        rec[3] = ln[1];
+        for (size_t i = 0; i < q.n1.size(); ++i)
+            for (uint32_t j = 0; j < q.n1[i]; ++j) rec[q.off1[i] + j] = one_d(pixel, static_cast<uint32_t>(i), q.n1[i], j, k);
+        for (size_t i = 0; i < q.n2.size(); ++i)
+            for (uint32_t j = 0; j < q.n2[i]; ++j) two_d(pixel, 0x10000u + static_cast<uint32_t>(i), q.n2[i], j, k, true, rec + q.off2[i] + 2 * j);
+    }
+};
+
+Quota make_quota(const gbl_render_setting& rs, PtIndices* ix) {
+    return rs.integrator == GBL_INTEGRATOR_AO ? ao_quota(rs) : pt_quota(rs, ix);
+}
+
+}  // namespace
+
+// ===========================================================================
+// C interface (used by tests/, smoke() and bench.py's cpu_baseline only)
+// ===========================================================================
+extern "C" {
+
+typedef struct orc_counters {
+    uint64_t paths, closest_queries, anyhit_queries, filtered_queries, nodes, tris, splats, dims;
+} orc_counters;
+
+orc_scene* orc_create(const gbl_scene_desc* desc) {
+    if (!desc || desc->abi_version != GBL_ABI_VERSION) return nullptr;
+    orc_scene* s = new orc_scene();
+    s->desc = *desc;   // arrays stay owned by the caller and must outlive the scene
+    prepare(s);
+    return s;
+}
+
+void orc_destroy(orc_scene* s) { delete s; }
+
+void orc_sample_window(const orc_scene* s, int32_t out[4]) { memcpy(out, s->window, sizeof(s->window)); }
+
+int32_t orc_sample_dimension(const gbl_render_setting* rs) { return static_cast<int32_t>(make_quota(*rs, nullptr).dims()); }
+
+// Float offsets of the path tracer's per-bounce sample slots inside a record:
+// out[5*b + {0..4}] = {light component, light geometry(2), bsdf component, bsdf direction(2), pick light}
+void orc_pt_offsets(const gbl_render_setting* rs, int32_t* out) {
+    PtIndices ix;
+    Quota q = pt_quota(*rs, &ix);
+    for (size_t b = 0; b < ix.pick.size(); ++b) {
+        out[5 * b + 0] = q.off1[ix.light1[b]];
+        out[5 * b + 1] = q.off2[ix.light2[b]];
+        out[5 * b + 2] = q.off1[ix.bsdf1[b]];
+        out[5 * b + 3] = q.off2[ix.bsdf2[b]];
+        out[5 * b + 4] = q.off1[ix.pick[b]];
+    }
+}
+
+// First `n` values of glibc rand() after srand(1)
+void orc_glibc_rand(int32_t* out, int32_t n) {
+    GlibcRand g(1);
+    for (int i = 0; i < n; ++i) out[i] = g.next();
+}
+
+// --- known-answer probes ---------------------------------------------------
+void orc_filter_table(const orc_scene* s, float out[256]) { memcpy(out, s->filter_table, sizeof(s->filter_table)); }
+void orc_camera_ray(const orc_scene* s, float image_x, float image_y, float out[8]) {
+    Ray r = camera_ray(s, image_x, image_y);
+    out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z;
+    out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+    out[6] = r.mint; out[7] = r.maxt;
+}
+int32_t orc_light_power(const orc_scene* s, float* out4_per_light) {
+    for (size_t i = 0; i < s->lights.size(); ++i) {
+        Col p = s->light_power_rgb[i];
+        out4_per_light[4 * i] = p.r; out4_per_light[4 * i + 1] = p.g; out4_per_light[4 * i + 2] = p.b;
+        out4_per_light[4 * i + 3] = luminance(p);
+    }
+    return static_cast<int32_t>(s->lights.size());
+}
+// closest hit along a ray: out = {t, eps, p(3), n(3), tangent(3), instance}
+int32_t orc_intersect(const orc_scene* s, const float o[3], const float d[3], float mint, float maxt, float out[12]) {
+    Ray r;
+    r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]); r.mint = mint; r.maxt = maxt < 0 ? INF : maxt;
+    Hit h;
+    h.frag.n = V3(0, 0, 0); h.frag.dpdv = V3(0, 0, 0);
+    Counters c;
+    if (!scene_intersect(s, r, &h, &c)) return 0;
+    Frame fr = shade_frame(h.frag);
+    out[0] = r.maxt; out[1] = h.epsilon;
+    out[2] = h.frag.p.x; out[3] = h.frag.p.y; out[4] = h.frag.p.z;
+    out[5] = h.frag.n.x; out[6] = h.frag.n.y; out[7] = h.frag.n.z;
+    out[8] = fr.t.x; out[9] = fr.t.y; out[10] = fr.t.z;
+    out[11] = static_cast<float>(h.instance);
+    return 1;
+}
+int32_t orc_occluded(const orc_scene* s, const float o[3], const float d[3], float mint, float maxt) {
+    Ray r;
+    r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]); r.mint = mint; r.maxt = maxt < 0 ? INF : maxt;
+    Counters c;
+    return scene_occluded(s, r, &c) ? 1 : 0;
+}
+
+// --- replay: Li for caller-supplied Sample records -------------------------
+// samples: n records of orc_sample_dimension floats; li_out: n rgba.
+int32_t orc_li_replay(const orc_scene* s, const gbl_render_setting* rs, const float* samples, int64_t n, float* li_out,
+                      int32_t threads, orc_counters* counters) {
+    PtIndices ix;
+    Quota q = make_quota(*rs, &ix);
+    uint32_t dims = q.dims();
+    int nt = std::max(1, threads);
+    std::vector<Counters> cnts(nt);
+    std::vector<uint64_t> dims_used(nt, 0);
+    std::vector<std::thread> pool;
+    auto work = [&](int tid) {
+        LiCtx c;
+        c.s = s; c.rs = rs; c.q = &q; c.ix = &ix; c.rng = nullptr; c.ref_faithful = 0;
+        for (int64_t i = tid; i < n; i += nt) {
+            Col L = eval_li(&c, samples + i * dims);
+            li_out[4 * i] = L.r; li_out[4 * i + 1] = L.g; li_out[4 * i + 2] = L.b; li_out[4 * i + 3] = L.a;
+        }
+        cnts[tid] = c.cnt;
+        dims_used[tid] = c.dims_used;
+    };
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
+    if (counters) {
+        memset(counters, 0, sizeof(*counters));
+        counters->paths = static_cast<uint64_t>(n);
+        for (int t = 0; t < nt; ++t) {
+            counters->closest_queries += cnts[t].closest; counters->anyhit_queries += cnts[t].anyhit;
+            counters->filtered_queries += cnts[t].filtered; counters->nodes += cnts[t].nodes; counters->tris += cnts[t].tris;
+            counters->dims += dims_used[t];
+        }
+    }
+    return 0;
+}
+
+// Splat (sample, Li) pairs into a film in order: ImageTile::addSample.
+int32_t orc_splat(const orc_scene* s, const float* samples, int32_t dims, const float* li, int64_t n, float* film_accum) {
+    uint64_t splats = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* rec = samples + i * dims;
+        add_sample(s, film_accum, rec[0], rec[1], Col(li[4 * i], li[4 * i + 1], li[4 * i + 2], li[4 * i + 3]), &splats);
+    }
+    return static_cast<int32_t>(splats > 0x7fffffff ? 0x7fffffff : splats);
+}
+
+// Native (counter-based) sample records for a sub-window, pixel-major.
+int32_t orc_native_samples(const orc_scene* s, const gbl_render_setting* rs, uint64_t seed, const int32_t window[4], float* out) {
+    Quota q = make_quota(*rs, nullptr);
+    NativeSampler ns(seed, rs->sample_per_pixel);
+    int fw = s->window[1] - s->window[0];
+    uint32_t dims = q.dims();
+    size_t rec = 0;
+    for (int y = window[2]; y < window[3]; ++y)
+        for (int x = window[0]; x < window[1]; ++x) {
+            uint32_t pixel = static_cast<uint32_t>((y - s->window[2]) * fw + (x - s->window[0]));
+            for (int k = 0; k < ns.spp; ++k) ns.fill(q, pixel, x, y, k, out + (rec++) * dims);
+        }
+    return 0;
+}
+
+// --- the whole render loop as the reference runs it ------------------------
+// Renderer::render + RenderTask::run (GoblinRenderer.cpp:99-126,29-52): 8x8
+// tiles in row-major order, one mt19937 per tile seeded from consecutive
+// rand() values, stratified sampler, Li, film splat.  threads == 1 reproduces
+// the reference's thread_num=1 accumulation order exactly; threads > 1 gives
+// every worker its own full film and sums them at the end (the reference's
+// per-thread ImageTile + mergeTile).
+//   samples_out / li_out: optional, all records in tile-then-pixel order.
+//   sampler: 0 = reference stream (mt19937), 1 = native counter-based law.
+int32_t orc_render(const orc_scene* s, const gbl_render_setting* rs, int32_t threads, int32_t ref_faithful, int32_t sampler,
+                   uint64_t seed, float* film_accum, float* samples_out, float* li_out, double* seconds,
+                   orc_counters* counters) {
+    PtIndices ix;
+    Quota q = make_quota(*rs, &ix);
+    uint32_t dims = q.dims();
+    int root;
+    int spp = round_to_square(rs->sample_per_pixel, &root);
+    struct Tile {
+        int x0, x1, y0, y1;
+        uint32_t seed;
+        size_t first_record;
+    };
+    std::vector<Tile> tiles;
+    GlibcRand libc(1);
+    size_t nrec = 0;
+    for (int y = s->window[2]; y < s->window[3]; y += 8)       // Renderer::getSampleRanges, :650-665
+        for (int x = s->window[0]; x < s->window[1]; x += 8) {
+            Tile t;
+            t.x0 = x; t.x1 = std::min(x + 8, s->window[1]);
+            t.y0 = y; t.y1 = std::min(y + 8, s->window[3]);
+            t.seed = static_cast<uint32_t>(libc.next());        // RNGImp ctor, GoblinUtils.cpp:19-20
+            t.first_record = nrec;
+            nrec += static_cast<size_t>(t.x1 - t.x0) * (t.y1 - t.y0) * spp;
+            tiles.push_back(t);
+        }
+    size_t film_floats = static_cast<size_t>(s->xres) * s->yres * 4;
+    int nt = std::max(1, threads);
+    std::vector<std::vector<float>> films(nt > 1 ? nt : 0);
+    for (auto& f : films) f.assign(film_floats, 0.0f);
+    std::vector<Counters> cnts(nt);
+    std::vector<uint64_t> splats(nt, 0), dims_used(nt, 0);
+    std::atomic<size_t> next_tile{0};
+    NativeSampler native(seed, rs->sample_per_pixel);
+    int fw = s->window[1] - s->window[0];
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int tid) {
+        float* film = nt > 1 ? films[tid].data() : film_accum;
+        std::vector<float> recs(static_cast<size_t>(spp) * dims);
+        LiCtx c;
+        c.s = s; c.rs = rs; c.q = &q; c.ix = &ix; c.ref_faithful = ref_faithful;
+        while (true) {
+            size_t ti = nt > 1 ? next_tile.fetch_add(1) : next_tile++;
+            if (ti >= tiles.size()) break;
+            const Tile& t = tiles[ti];
+            Rng rng(t.seed);
+            c.rng = sampler == 0 ? &rng : nullptr;
+            Sampler smp(t.x0, t.x1, t.y0, t.y1, rs->sample_per_pixel, q, &rng);
+            size_t rec_index = t.first_record;
+            for (int py = t.y0; py < t.y1; ++py)
+                for (int px = t.x0; px < t.x1; ++px) {
+                    if (sampler == 0) {
+                        smp.request(recs.data());
+                    } else {
+                        uint32_t pixel = static_cast<uint32_t>((py - s->window[2]) * fw + (px - s->window[0]));
+                        for (int k = 0; k < spp; ++k) native.fill(q, pixel, px, py, k, recs.data() + static_cast<size_t>(k) * dims);
+                    }
+                    for (int k = 0; k < spp; ++k) {
+                        const float* rec = recs.data() + static_cast<size_t>(k) * dims;
+                        Col L = eval_li(&c, rec);
+                        // RenderTask::run: w * (tr * L + Lv) with w = 1, tr = Color(1), Lv = Black
+                        Col tr(1.0f);
+                        Col TL = tr * L;
+                        Col out(TL.r + 0.0f, TL.g + 0.0f, TL.b + 0.0f, TL.a);
+                        out = 1.0f * out;
+                        add_sample(s, film, rec[0], rec[1], out, &splats[tid]);
+                        if (samples_out) memcpy(samples_out + rec_index * dims, rec, dims * sizeof(float));
+                        if (li_out) {
+                            li_out[4 * rec_index] = L.r; li_out[4 * rec_index + 1] = L.g;
+                            li_out[4 * rec_index + 2] = L.b; li_out[4 * rec_index + 3] = L.a;
+                        }
+                        ++rec_index;
+                    }
+                }
+        }
+        cnts[tid] = c.cnt;
+        dims_used[tid] = c.dims_used;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
+    if (nt > 1)   // Film::mergeTile, GoblinFilm.cpp:140-153
+        for (int t = 0; t < nt; ++t)
+            for (size_t i = 0; i < film_floats; ++i) film_accum[i] += films[t][i];
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (counters) {
+        memset(counters, 0, sizeof(*counters));
+        counters->paths = nrec;
+        for (int t = 0; t < nt; ++t) {
+            counters->closest_queries += cnts[t].closest; counters->anyhit_queries += cnts[t].anyhit;
+            counters->filtered_queries += cnts[t].filtered; counters->nodes += cnts[t].nodes; counters->tris += cnts[t].tris;
+            counters->splats += splats[t]; counters->dims += dims_used[t];
+        }
+    }
+    return 0;
+}
+
+int32_t orc_hardware_threads(void) { return static_cast<int32_t>(std::thread::hardware_concurrency()); }
+
+}  // extern "C"

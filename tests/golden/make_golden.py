@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs only in the authoring container: it needs oracle/_ref/ref_harness, i.e. the
+reference compiled from /root/reference/src by oracle/Makefile (`make -C oracle
+ref`).  The fixtures are data only -- inputs (scene name + overrides, Sample
+records) and the reference's outputs (Film accumulators, per-sample Li, known
+answer tables).  No reference source is stored.
+
+    python tests/golden/make_golden.py
+
+Each case is rendered with thread_num = 1 so the Film accumulation order is the
+deterministic one (GoblinThreadPool.cpp:63-71).
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from goblin_amd import scene as gs  # noqa: E402
+
+HARNESS = os.path.join(REPO, "oracle", "_ref", "ref_harness")
+
+
+def ov(resolution, spp, depth=None, method=None, ao=None, filt=None, crop=None, geometries=None):
+    o = gs.config_overrides(resolution=resolution, spp=spp, depth=depth, method=method, ao_samples=ao, filter=filt)
+    if crop:
+        o["camera"]["film"]["crop"] = crop
+    if geometries:
+        o["geometries"] = geometries
+    return o
+
+
+VN_GEOMS = [{"name": "bunny", "type": "mesh", "file": "models/bunny_vn.obj"},
+            {"name": "plane", "type": "mesh", "file": "models/plane.obj"}]
+
+# name -> (scene, overrides, number of (Sample -> Li) records to keep, with_kat)
+CASES = {
+    "bunny_pt": ("bunny", ov((64, 64), 16, 4), 2048, True),
+    "bunny_pt_d8": ("bunny", ov((32, 32), 4, 8), 1024, False),
+    "cornell_pt": ("cornell", ov((48, 48), 16, 6), 2048, True),
+    "grid_pt": ("grid", ov((48, 48), 4, 5), 1024, True),
+    "bunny_ao": ("bunny", ov((48, 48), 4, method="ao", ao=9), 1024, False),
+    "bunny_vn_box": ("bunny", ov((48, 48), 9, 5, filt={"type": "box", "width": [0.5, 0.5]}, geometries=VN_GEOMS), 512, False),
+    "cornell_mitchell": ("cornell", ov((40, 30), 5, 3, filt={"type": "mitchell", "width": [2.0, 2.0], "b": 0.33, "c": 0.33}), 0, False),
+    "cornell_triangle_crop": ("cornell", ov((40, 30), 4, 3, filt={"type": "triangle", "width": [1.5, 1.5]},
+                                            crop=[0.25, 0.75, 0.1, 0.9]), 0, False),
+}
+
+
+def absolute_scene(scene, overrides, path):
+    src = gs.scene_path(scene)
+    with open(src) as f:
+        doc = json.load(f)
+    gs._merge(doc, overrides)
+    doc.setdefault("render_setting", {})["thread_num"] = 1
+    for g in doc.get("geometries", []):
+        if "file" in g:
+            g["file"] = os.path.join(os.path.dirname(src), g["file"])
+    with open(path, "w") as f:
+        json.dump(doc, f)
+
+
+def parse_kat(path):
+    out = {}
+    with open(path) as f:
+        lines = f.read().split("\n")
+    i = 0
+    while i < len(lines):
+        parts = lines[i].split()
+        i += 1
+        if not parts:
+            continue
+        key = parts[0]
+        if key == "sample_range":
+            out[key] = np.array([int(x) for x in parts[1:]], np.int32)
+            continue
+        n = int(parts[1])
+        rows = [[float(x) for x in lines[i + k].split()] for k in range(n)]
+        i += n
+        out[key] = np.array(rows, np.float32)
+    return out
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("oracle/_ref/ref_harness is missing: run `make -C oracle ref` (needs /root/reference)")
+    manifest = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (scene, overrides, nrec, with_kat) in CASES.items():
+            jp = os.path.join(tmp, name + ".json")
+            absolute_scene(scene, overrides, jp)
+            prefix = os.path.join(tmp, name)
+            # count the Li calls first so the kept records are spread over the whole image
+            meta = json.loads(subprocess.check_output([HARNESS, "li", jp, prefix, "1", "0"]).decode())
+            calls = meta["li_calls"]
+            stride = max(1, calls // nrec) if nrec else 1
+            meta = json.loads(subprocess.check_output([HARNESS, "li", jp, prefix, str(stride), str(nrec)]).decode())
+            film = np.fromfile(prefix + ".film.f32", np.float32).reshape(meta["yres"], meta["xres"], 4)
+            arrays = {"film": film}
+            if nrec:
+                dims = meta["dims"]
+                arrays["samples"] = np.fromfile(prefix + ".samples.f32", np.float32).reshape(-1, dims)
+                arrays["li"] = np.fromfile(prefix + ".li.f32", np.float32).reshape(-1, 4)
+                assert arrays["samples"].shape[0] == arrays["li"].shape[0] == meta["records"]
+            if with_kat:
+                subprocess.check_output([HARNESS, "kat", jp, prefix])
+                for k, v in parse_kat(prefix + ".kat.txt").items():
+                    arrays["kat_" + k] = v
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+            manifest[name] = {"scene": scene, "overrides": overrides, "window": meta["window"], "spp": meta["spp"],
+                              "paths": meta["paths"], "records": meta["records"], "record_stride": stride,
+                              "dims": meta["dims"]}
+            print(name, meta["paths"], "paths,", meta["records"], "records, film", film.shape)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
