@@ -1,0 +1,141 @@
+// Device-resident scene layout (HBM) shared by the host packer (scene_prep.cpp)
+// and the kernels.  Everything is POD and sized/aligned for 16-byte vector loads.
+//
+//   nodes[]      64 B  BVH2 node holding BOTH children's boxes (one fetch = two
+//                      32-byte box tests).  BLAS nodes of every mesh first, then
+//                      the TLAS nodes; all child references are absolute.
+//   tris[]       48 B  p0, e1, e2 in object space, in BLAS leaf order; e1/e2 are
+//                      the same float32 differences the reference forms per test
+//                      (GoblinTriangle.cpp:52-53) so Moller-Trumbore is bit-equal.
+//   tri_shade[]  16 B  vertex ids for normal/uv interpolation at the final hit.
+//   instances[] 128 B  3x4 toWorld, 3x4 inverse (Transform::update order), ids.
+#pragma once
+#include <stdint.h>
+
+#define GBL_TILE 8              // sample tiles are 8x8 pixels, as Renderer::getSampleRanges (GoblinRenderer.cpp:654)
+#define GBL_BLOCK 256           // threads per workgroup (4 waves of 64)
+#define GBL_MAX_LEAF_TRIS 4
+#define GBL_STACK_SENTINEL 0x7fffffff
+#define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
+
+// child reference: >= 0 interior node index; < 0 leaf: ~ref = (first << 2) | (count - 1)
+// (TLAS leaves: first = instance id, count = 1)
+struct DevNode {
+    float c0x[2], c0y[2];   // child 0: lo.x hi.x lo.y hi.y
+    float c1x[2], c1y[2];   // child 1
+    float c0z[2], c1z[2];   // lo.z hi.z of child 0, child 1
+    int32_t child[2];
+    int32_t pad[2];
+};
+
+struct DevTri {
+    float p0[3];
+    uint32_t shade;   // index into tri_shade / original triangle id within the scene
+    float e1[3];
+    float pad0;
+    float e2[3];
+    float pad1;
+};
+
+struct DevTriShade {
+    uint32_t v[3];    // absolute vertex ids into normals / uvs
+    uint32_t flags;   // bit0 has_normal, bit1 has_uv
+};
+
+struct DevInstance {
+    float m[12];      // toWorld rows 0..2 (3x4)
+    float inv[12];    // inverse rows 0..2 (3x4)
+    int32_t root;     // BLAS root child reference
+    int32_t material;
+    int32_t area_light;
+    int32_t mesh;
+    int32_t pad[4];
+};
+
+struct DevMaterial {
+    uint32_t type;
+    float color[3];
+    float color2[3];
+    float index, k, exponent;
+    float pad[2];
+};
+
+// one emitting triangle of an area light, light-local space (GeometrySet, GoblinLight.cpp:289-343)
+struct DevLightTri {
+    float p0[3], area;
+    float p1[3], cdf_lo;   // normalised area CDF value at this triangle's start (CDF1D::mCDF[i])
+    float p2[3], cdf_hi;
+    float n0[3], has_normal;
+    float n1[3], pad0;
+    float n2[3], pad1;
+};
+
+struct DevLight {
+    uint32_t type;
+    float color[3];
+    float pos[3];
+    float cos_max;
+    float axis[3];          // spot: toWorld.onVector(UnitZ)
+    float cos_falloff;
+    float m[12], inv[12];   // area: light toWorld / inverse
+    uint32_t tri_first, tri_count;   // into light_tris
+    float sum_area;
+    float pad;
+};
+
+struct DevCamera {
+    float pos[3];
+    float proj00;
+    float q[4];       // w x y z
+    float proj11, inv_xres, inv_yres, pad;
+};
+
+struct DevFilm {
+    int32_t xres, yres;
+    int32_t xstart, ystart, xcount, ycount;   // crop rect (Film ctor, GoblinFilm.cpp:101-104)
+    float wx, wy;                              // filter half widths
+    int32_t window[4];                         // full sample window x0 x1 y0 y1
+    int32_t halo;                              // LDS tile halo in pixels
+    int32_t pad[3];
+};
+
+struct DevScene {
+    const DevNode* nodes;
+    const DevTri* tris;
+    const DevTriShade* tri_shade;
+    const float* normals;    // 3 per vertex
+    const float* uvs;        // 2 per vertex
+    const DevInstance* instances;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    const DevLightTri* light_tris;
+    const float* light_cdf;       // num_lights + 1, normalised (CDF1D::mCDF)
+    const float* light_pick_pdf;  // per light: (f[i] / integral) * dx
+    const float* filter_table;    // 256 floats
+    int32_t tlas_root;            // child reference of the TLAS root
+    int32_t num_instances;
+    int32_t num_lights;
+    int32_t stack_entries;        // traversal stack depth this scene needs
+    DevCamera camera;
+    DevFilm film;
+};
+
+struct RenderArgs {
+    int32_t integrator;
+    int32_t spp, root;          // roundToSquare(sample_per_pixel) and its root
+    int32_t max_depth;
+    int32_t ao_n;               // AO directions per camera sample
+    int32_t dims;               // floats per Sample record
+    int32_t off2_base;          // float offset of the first 2D pattern in a record
+    int32_t window[4];          // sub-window being rendered x0 x1 y0 y1
+    int32_t tiles_x, tiles_y;
+    int32_t chunks;             // each tile's spp split in `chunks` work items
+    int32_t chunk_spp;
+    uint32_t seed_key;
+    uint32_t russian_roulette;
+    const float* replay;        // Sample records for the sub-window, pixel-major
+    float* li_out;
+    float* film;                // xres*yres float4 accumulators
+    uint32_t* work_counter;     // zeroed before each launch
+    unsigned long long* stats;  // 8 counters
+};

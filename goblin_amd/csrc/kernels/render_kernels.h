@@ -1,0 +1,489 @@
+// The render kernels: persistent workgroups pull (tile, sample-chunk) work items
+// from a global counter; inside an item the lanes of a wave keep themselves busy
+// by regenerating camera paths from an LDS counter as soon as their previous
+// path ends (wave ballot + prefix popcount).  Radiance is splatted through the
+// reconstruction filter into an LDS film tile (8x8 pixels + halo) with LDS float
+// atomics and flushed to the HBM film once per item.
+//
+// Replaces RenderTask::run + PathTracer::Li / AORenderer::Li + ImageTile::addSample
+// (GoblinRenderer.cpp:29-52, GoblinPathtracer.cpp:50-179, GoblinAO.cpp:12-37,
+// GoblinFilm.cpp:61-90) and PerspectiveCamera::generateRay (GoblinCamera.cpp:97-148).
+//
+// Per bounce the reference issues up to five BVH traversals (shadow, two
+// notOpaque attenuation walks that cannot hit anything in a mask-free scene, the
+// MIS ray and the identical extension ray).  Here a bounce is exactly one
+// any-hit query and one closest-hit query: the MIS lookup and the path
+// extension are the same ray, so its hit is used for both.
+#pragma once
+#include "../device_scene.h"
+#include "sampler.h"
+#include "shade.h"
+#include "trace.h"
+#include "vecmath.h"
+
+struct ItemInfo {
+    int px0, py0, tw, th;   // tile origin and clipped size in pixels
+    int k0;                 // first sample index of this chunk
+    int paths;              // tw * th * chunk_spp
+};
+
+__device__ __forceinline__ ItemInfo decode_item(const RenderArgs& ra, uint32_t item) {
+    ItemInfo it;
+    uint32_t tile = item / ra.chunks, chunk = item % ra.chunks;
+    int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
+    it.px0 = ra.window[0] + GBL_TILE * tx;
+    it.py0 = ra.window[2] + GBL_TILE * ty;
+    it.tw = min(GBL_TILE, ra.window[1] - it.px0);
+    it.th = min(GBL_TILE, ra.window[3] - it.py0);
+    it.k0 = chunk * ra.chunk_spp;
+    it.paths = it.tw * it.th * ra.chunk_spp;
+    return it;
+}
+
+// PerspectiveCamera::generateRay, pinhole branch
+__device__ __forceinline__ void camera_ray(const DevCamera& c, float image_x, float image_y, F3* o, F3* d) {
+    float xndc = +2.0f * image_x * c.inv_xres - 1.0f;
+    float yndc = -2.0f * image_y * c.inv_yres + 1.0f;
+    float xv = xndc / c.proj00;
+    float yv = yndc / c.proj11;
+    F3 v = normalize(f3(xv, yv, 1.0f));
+    // Quaternion * Vector3 (GoblinQuaternion.cpp:86-92)
+    F3 qv = f3(c.q[1], c.q[2], c.q[3]);
+    F3 uv = cross(qv, v);
+    F3 uuv = cross(qv, uv);
+    uv = uv * (2.0f * c.q[0]);
+    uuv = uuv * 2.0f;
+    *o = f3(c.pos[0], c.pos[1], c.pos[2]);
+    *d = v + uv + uuv;
+}
+
+// ImageTile::addSample into the LDS tile.  tile origin (tx0, ty0), row pitch tp pixels.
+template <bool STATS>
+__device__ __forceinline__ void splat(const DevFilm& film, const float* ftab, float* tile, int tx0, int ty0, int tp, float image_x,
+                                      float image_y, F3 L, LaneCounters& cnt) {
+    if (L.x != L.x || L.y != L.y || L.z != L.z) return;   // NaN sample: dropped (GoblinFilm.cpp:62-66)
+    float dx = image_x - 0.5f, dy = image_y - 0.5f;
+    int x0 = static_cast<int>(ceilf(dx - film.wx)), x1 = static_cast<int>(floorf(dx + film.wx));
+    int y0 = static_cast<int>(ceilf(dy - film.wy)), y1 = static_cast<int>(floorf(dy + film.wy));
+    x0 = max(x0, film.xstart);
+    x1 = min(x1, film.xstart + film.xcount - 1);
+    y0 = max(y0, film.ystart);
+    y1 = min(y1, film.ystart + film.ycount - 1);
+    // The footprint of a sample generated inside this tile always lies inside the
+    // LDS tile (halo = ceil(w + 0.5)).  A replayed record may carry any image
+    // position: clip so a foreign record can never write outside the tile.
+    x0 = max(x0, tx0);
+    x1 = min(x1, tx0 + tp - 1);
+    y0 = max(y0, ty0);
+    y1 = min(y1, ty0 + tp - 1);
+    for (int y = y0; y <= y1; ++y) {
+        int iy = min(static_cast<int>(floorf(fabsf(16 * (y - dy) / film.wy))), 15);
+        for (int x = x0; x <= x1; ++x) {
+            int ix = min(static_cast<int>(floorf(fabsf(16 * (x - dx) / film.wx))), 15);
+            float w = ftab[iy * 16 + ix];
+            float* px = tile + 4 * ((y - ty0) * tp + (x - tx0));
+            atomicAdd(px + 0, w * L.x);
+            atomicAdd(px + 1, w * L.y);
+            atomicAdd(px + 2, w * L.z);
+            atomicAdd(px + 3, w);
+            if (STATS) cnt.splats += 1;
+        }
+    }
+}
+
+__device__ __forceinline__ void flush_tile(const DevFilm& film, float* tile, int tx0, int ty0, int tp, float* out) {
+    for (int i = threadIdx.x; i < tp * tp; i += GBL_BLOCK) {
+        int x = tx0 + i % tp, y = ty0 + i / tp;
+        float4 v = reinterpret_cast<float4*>(tile)[i];
+        if (x >= 0 && y >= 0 && x < film.xres && y < film.yres && (v.w != 0.0f || v.x != 0.0f || v.y != 0.0f || v.z != 0.0f)) {
+            float* px = out + 4 * (static_cast<size_t>(y) * film.xres + x);
+            atomicAdd(px + 0, v.x);
+            atomicAdd(px + 1, v.y);
+            atomicAdd(px + 2, v.z);
+            atomicAdd(px + 3, v.w);
+        }
+    }
+}
+
+// Grab the next path index of this work item for every idle lane of the wave:
+// one LDS atomic per wave, prefix popcount for the lane's offset.
+__device__ __forceinline__ int wave_fetch(bool want, uint32_t* next_path) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return -1;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(next_path, static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, leader);
+    uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    return want ? static_cast<int>(base + rank) : -1;
+}
+
+__device__ __forceinline__ void accumulate_stats(const RenderArgs& ra, const LaneCounters& c, uint32_t paths) {
+    unsigned long long v[7] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims};
+    for (int i = 0; i < 7; ++i) {
+        unsigned long long x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(ra.stats + i, x);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Path state carried by a lane between iterations of the persistent loop.
+// ---------------------------------------------------------------------------
+struct PathState {
+    F3 o, d;            // ray to trace next (primary or extension)
+    float mint;
+    F3 throughput, Li;
+    // deferred terms of the bounce whose extension ray is in flight
+    F3 Ld, f;           // direct light gathered so far; bsdf value of the sampled direction
+    float cosw, fw, bsdf_pdf, pick_pdf;   // |wi.n|, MIS weight, pdfs
+    int light;          // light picked at the previous vertex
+    int bounce;         // -1: the ray in flight is the camera ray
+    uint32_t path;      // index of this path inside the work item
+};
+
+template <bool REPLAY, bool STATS>
+__global__ __launch_bounds__(GBL_BLOCK) void path_trace_kernel(DevScene sc, RenderArgs ra) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tp = GBL_TILE + 2 * sc.film.halo;
+    float* tile = reinterpret_cast<float*>(smem);
+    float* ftab = tile + 4 * tp * tp;
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
+    uint32_t* stack = ctrl + 4;
+    uint32_t* stk = stack + threadIdx.x;
+    for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    uint32_t paths_done = 0;
+    const uint32_t n_items = static_cast<uint32_t>(ra.tiles_x) * ra.tiles_y * ra.chunks;
+    const int sub_w = ra.window[1] - ra.window[0];
+    const int full_w = sc.film.window[1] - sc.film.window[0];
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ctrl[0] = atomicAdd(ra.work_counter, 1u);
+            ctrl[1] = 0u;
+        }
+        for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
+        __syncthreads();
+        const uint32_t item = ctrl[0];
+        if (item >= n_items) break;
+        const ItemInfo it = decode_item(ra, item);
+        const int tx0 = it.px0 - sc.film.halo, ty0 = it.py0 - sc.film.halo;
+
+        PathState ps;
+        bool active = false;
+        bool exhausted = false;
+        SampleSource src;
+        src.spp = ra.spp;
+        src.root = ra.root;
+        src.rec = nullptr;
+        src.pixel_key = 0;
+        src.k = 0;
+        float image_x = 0.0f, image_y = 0.0f;
+        uint32_t out_index = 0;
+
+        for (;;) {
+            // ---- regeneration: idle lanes start a new camera path
+            int fetched = wave_fetch(!active && !exhausted, ctrl + 1);
+            if (!active && !exhausted) {
+                if (fetched >= 0 && fetched < it.paths) {
+                    int pix = fetched / ra.chunk_spp;
+                    src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);
+                    int px = it.px0 + pix % it.tw, py = it.py0 + pix / it.tw;
+                    out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
+                    if (REPLAY) {
+                        src.rec = ra.replay + static_cast<size_t>(out_index) * ra.dims;
+                        image_x = src.rec[0];
+                        image_y = src.rec[1];
+                    } else {
+                        uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
+                        src.pixel_key = nat_mix(ra.seed_key, pixel);
+                        float u, v;
+                        src.native_2d(0u, 1u, 0u, false, &u, &v);
+                        image_x = px + u;
+                        image_y = py + v;
+                    }
+                    camera_ray(sc.camera, image_x, image_y, &ps.o, &ps.d);
+                    ps.mint = 1e-3f;
+                    ps.throughput = f3(1.0f, 1.0f, 1.0f);
+                    ps.Li = f3(0.0f, 0.0f, 0.0f);
+                    ps.bounce = -1;
+                    ps.path = fetched;
+                    active = true;
+                    if (STATS) cnt.dims += 2;
+                } else {
+                    exhausted = true;
+                }
+            }
+            if (__ballot(active) == 0ull) break;
+
+            bool finished = false;
+            Hit hit;
+            bool got = false;
+            if (active) {
+                if (sc.num_lights == 0) {
+                    finished = true;   // PathTracer::Li returns Black without lights (:53-56)
+                } else {
+                    got = trace<false, STATS>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
+                    if (STATS) cnt.ext += 1;
+                }
+            }
+            Frag fr;
+            if (active && !finished) {
+                if (got) make_fragment(sc, hit, ps.o, ps.d, fr);
+                if (ps.bounce < 0) {
+                    if (!got) {
+                        finished = true;   // no image based light on this path: evalEnvironmentLight == 0
+                    } else {
+                        F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                        ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                        ps.bounce = 0;
+                    }
+                } else {
+                    // close the previous bounce: MIS term for the sampled direction, then Li and throughput
+                    if (got && sc.instances[hit.inst].area_light == ps.light) {
+                        F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                        if (!is_black(le)) {
+                            // Ld += f * tr * Li * absdot(wi, n) * fWeight / bsdfPdf   (tr == 1)
+                            F3 term = div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
+                            ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
+                        }
+                    }
+                    F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
+                    ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
+                    F3 scale = div(ps.f * ps.cosw, ps.bsdf_pdf);
+                    ps.throughput = ps.throughput * scale;
+                    ps.bounce += 1;
+                    if (!got) finished = true;
+                }
+                if (!finished && ps.bounce >= ra.max_depth - 1) finished = true;
+            }
+
+            // ---- shade the vertex: light sample (shadow ray below) and BSDF sample
+            bool need_shadow = false;
+            F3 shadow_d = f3(0, 0, 1), contrib = f3(0, 0, 0);
+            float shadow_maxt = 0.0f;
+            F3 wo = -ps.d;
+            const DevMaterial* mat = nullptr;
+            float u_bsdf_c = 0.0f, u_bsdf_1 = 0.0f, u_bsdf_2 = 0.0f;
+            if (active && !finished) {
+                const int b = ps.bounce;
+                float u_light_c, u_light_1, u_light_2, u_pick;
+                if (REPLAY) {
+                    const float* r1 = src.rec + 4 + 3 * b;
+                    const float* r2 = src.rec + ra.off2_base + 4 * b;
+                    u_light_c = r1[0]; u_bsdf_c = r1[1]; u_pick = r1[2];
+                    u_light_1 = r2[0]; u_light_2 = r2[1]; u_bsdf_1 = r2[2]; u_bsdf_2 = r2[3];
+                } else {
+                    u_light_c = src.native_1d(3u * b + 0u);
+                    u_bsdf_c = src.native_1d(3u * b + 1u);
+                    u_pick = src.native_1d(3u * b + 2u);
+                    src.native_2d(0x10000u + 2u * b, 1u, 0u, true, &u_light_1, &u_light_2);
+                    src.native_2d(0x10000u + 2u * b + 1u, 1u, 0u, true, &u_bsdf_1, &u_bsdf_2);
+                }
+                if (STATS) cnt.dims += 7;
+                // Scene::sampleLight: CDF1D::sampleDiscrete over the power distribution
+                int li = 0;
+                for (int i = 1; i <= sc.num_lights; ++i)
+                    if (sc.light_cdf[i] < u_pick) li = i;
+                if (li >= sc.num_lights) li = sc.num_lights - 1;
+                ps.light = li;
+                ps.pick_pdf = sc.light_pick_pdf[li];
+                ps.Ld = f3(0, 0, 0);
+                mat = sc.materials + sc.instances[hit.inst].material;
+                const DevLight& light = sc.lights[li];
+                LightSampleOut ls;
+                light_sample(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
+                if (!is_black(ls.L) && ls.pdf > 0.0f) {
+                    F3 f = mat_bsdf(*mat, fr.n, wo, ls.wi);
+                    if (!is_black(f)) {
+                        need_shadow = true;
+                        shadow_d = ls.wi;
+                        shadow_maxt = ls.maxt;
+                        if (light.type != GBL_LIGHT_AREA) {
+                            contrib = div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);
+                        } else {
+                            float bp = mat_pdf(*mat, fr.n, wo, ls.wi);
+                            float lw = power_heuristic(ls.pdf, bp);
+                            contrib = div(f * ls.L * absdot(fr.n, ls.wi) * lw, ls.pdf);
+                        }
+                    }
+                }
+            }
+            // ---- shadow query (any-hit)
+            if (need_shadow) {
+                Hit dummy;
+                bool occluded = trace<true, STATS>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt);
+                if (STATS) cnt.shadow += 1;
+                if (!occluded) ps.Ld = f3(ps.Ld.x + contrib.x, ps.Ld.y + contrib.y, ps.Ld.z + contrib.z);
+            }
+            // ---- BSDF sample: the next ray
+            if (active && !finished) {
+                F3 wi;
+                float pdf;
+                bool specular;
+                F3 f = mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
+                if (!is_black(f) && pdf > 0.0f) {
+                    float fw = 1.0f;
+                    if (!specular) fw = power_heuristic(pdf, light_pdf(sc, sc.lights[ps.light], fr.p, wi));
+                    ps.f = f;
+                    ps.fw = fw;
+                    ps.bsdf_pdf = pdf;
+                    ps.cosw = absdot(wi, fr.n);
+                    ps.o = fr.p;
+                    ps.d = wi;
+                    ps.mint = fr.eps;
+                    if (ra.russian_roulette && !REPLAY && ps.bounce >= 2) {
+                        // build-side extension, off in every parity mode
+                        F3 tn = ps.throughput * div(ps.f * ps.cosw, ps.bsdf_pdf);
+                        float q = fminf(0.95f, fmaxf(tn.x, fmaxf(tn.y, tn.z)));
+                        float u = nat_u01(nat_mix(nat_mix(src.pixel_key, 0xBADC0DEu + ps.bounce), src.k));
+                        if (!(u < q)) {
+                            // terminate after accounting this vertex's direct light
+                            F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
+                            ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
+                            finished = true;
+                        } else {
+                            ps.throughput = div(ps.throughput, q);
+                        }
+                    }
+                } else {
+                    // Li += throughput * Ld / pickLightPdf; break   (:163-167)
+                    F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
+                    ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
+                    finished = true;
+                }
+            }
+            // ---- path end: splat and free the lane
+            if (active && finished) {
+                // RenderTask::run: w * (tr * L + Lv), w = 1, tr = 1, Lv = 0
+                splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, ps.Li, cnt);
+                if (ra.li_out) {
+                    float4 v = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
+                    reinterpret_cast<float4*>(ra.li_out)[out_index] = v;
+                }
+                active = false;
+                paths_done += 1;
+            }
+        }
+        __syncthreads();
+        flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
+    }
+    if (STATS) accumulate_stats(ra, cnt, paths_done);
+}
+
+// ---------------------------------------------------------------------------
+// Ambient occlusion (AORenderer::Li): one closest hit, N uniform-hemisphere
+// any-hit rays, unoccluded fraction as grey radiance.
+// ---------------------------------------------------------------------------
+template <bool REPLAY, bool STATS>
+__global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs ra) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tp = GBL_TILE + 2 * sc.film.halo;
+    float* tile = reinterpret_cast<float*>(smem);
+    float* ftab = tile + 4 * tp * tp;
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
+    uint32_t* stack = ctrl + 4;
+    uint32_t* stk = stack + threadIdx.x;
+    for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    uint32_t paths_done = 0;
+    const uint32_t n_items = static_cast<uint32_t>(ra.tiles_x) * ra.tiles_y * ra.chunks;
+    const int sub_w = ra.window[1] - ra.window[0];
+    const int full_w = sc.film.window[1] - sc.film.window[0];
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ctrl[0] = atomicAdd(ra.work_counter, 1u);
+            ctrl[1] = 0u;
+        }
+        for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
+        __syncthreads();
+        const uint32_t item = ctrl[0];
+        if (item >= n_items) break;
+        const ItemInfo it = decode_item(ra, item);
+        const int tx0 = it.px0 - sc.film.halo, ty0 = it.py0 - sc.film.halo;
+
+        for (;;) {
+            int fetched = wave_fetch(true, ctrl + 1);
+            bool valid = fetched >= 0 && fetched < it.paths;
+            if (__ballot(valid) == 0ull) break;
+            if (valid) {
+            int pix = fetched / ra.chunk_spp;
+            SampleSource src;
+            src.spp = ra.spp;
+            src.root = ra.root;
+            src.rec = nullptr;
+            src.pixel_key = 0;
+            src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);
+            int px = it.px0 + pix % it.tw, py = it.py0 + pix / it.tw;
+            uint32_t out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
+            float image_x, image_y;
+            if (REPLAY) {
+                src.rec = ra.replay + static_cast<size_t>(out_index) * ra.dims;
+                image_x = src.rec[0];
+                image_y = src.rec[1];
+            } else {
+                uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
+                src.pixel_key = nat_mix(ra.seed_key, pixel);
+                float u, v;
+                src.native_2d(0u, 1u, 0u, false, &u, &v);
+                image_x = px + u;
+                image_y = py + v;
+            }
+            F3 o, d;
+            camera_ray(sc.camera, image_x, image_y, &o, &d);
+            Hit hit;
+            F3 L = f3(0, 0, 0);
+            bool got = trace<false, STATS>(sc, o, d, 1e-3f, INFINITY, stk, hit, cnt);
+            if (STATS) {
+                cnt.ext += 1;
+                cnt.dims += 2;
+            }
+            if (got) {
+                Frag fr;
+                make_fragment(sc, hit, o, d, fr);
+                uint32_t occluded = 0;
+                for (int i = 0; i < ra.ao_n; ++i) {
+                    float u1, u2;
+                    if (REPLAY) {
+                        u1 = src.rec[4 + 2 * i];
+                        u2 = src.rec[4 + 2 * i + 1];
+                    } else {
+                        src.native_2d(0x10000u, static_cast<uint32_t>(ra.ao_n), static_cast<uint32_t>(i), true, &u1, &u2);
+                    }
+                    F3 dir = shade_to_world(fr, uniform_sample_hemisphere(u1, u2));
+                    Hit dummy;
+                    if (trace<true, STATS>(sc, fr.p, dir, fr.eps, INFINITY, stk, dummy, cnt)) occluded += 1;
+                    if (STATS) cnt.shadow += 1;
+                }
+                if (STATS) cnt.dims += 2 * ra.ao_n;
+                float g = static_cast<float>(static_cast<uint32_t>(ra.ao_n) - occluded) / static_cast<float>(static_cast<uint32_t>(ra.ao_n));
+                L = f3(g, g, g);
+            }
+            splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, L, cnt);
+            if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+            paths_done += 1;
+            }   // valid
+        }
+        __syncthreads();
+        flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
+    }
+    if (STATS) accumulate_stats(ra, cnt, paths_done);
+}
+
+// Film::writeImage's normalise step on the device: rgb = color / weight
+__global__ void film_resolve_kernel(const float* accum, float* rgb, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = reinterpret_cast<const float4*>(accum)[i];
+    float inv = 1.0f / a.w;
+    rgb[3 * i + 0] = a.x * inv;
+    rgb[3 * i + 1] = a.y * inv;
+    rgb[3 * i + 2] = a.z * inv;
+}

@@ -1,0 +1,335 @@
+// Surface interaction at a hit: fragment reconstruction, BSDFs, lights.
+//
+// Restates, in the reference's float operation order:
+//   Triangle::intersect outputs      GoblinTriangle.cpp:79-123
+//   Fragment::transform / frame      GoblinGeometry.cpp:17-37
+//   Lambert / Blinn / Transparent / Mirror   GoblinMaterial.cpp:285-726
+//   Point / Spot / Area lights       GoblinLight.cpp:87-99, 225-237, 277-287, 313-343, 368-394, 457-461
+//   Geometry::pdf                    GoblinGeometry.cpp:44-62
+//   warps, power heuristic           GoblinSampler.cpp:420-424, 517-557; GoblinSampler.h:286-290
+#pragma once
+#include "../device_scene.h"
+#include "trace.h"
+#include "vecmath.h"
+
+#define GBL_MAT_LAMBERT 0u
+#define GBL_MAT_BLINN 1u
+#define GBL_MAT_TRANSPARENT 2u
+#define GBL_MAT_MIRROR 3u
+#define GBL_LIGHT_POINT 0u
+#define GBL_LIGHT_SPOT 2u
+#define GBL_LIGHT_AREA 3u
+
+struct Frag {
+    F3 p, n;      // world position / shading normal
+    F3 t, b;      // tangent frame rows (Fragment::getWorldToShade)
+    float eps;    // 1e-3 * t
+};
+
+// Rebuild the reference's Fragment for the closest hit and move it to world space.
+__device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, F3 wo_origin, F3 w_dir, Frag& fr) {
+    const DevInstance* ip = sc.instances + h.inst;
+    // the object-space ray the triangle test saw (Transform::invertRay)
+    F3 ro = xf_point(ip->inv, wo_origin), rd = xf_vector(ip->inv, w_dir);
+    const DevTri* tp = sc.tris + h.tri;
+    const float4 q0 = reinterpret_cast<const float4*>(tp)[0];
+    const float4 q1 = reinterpret_cast<const float4*>(tp)[1];
+    const float4 q2 = reinterpret_cast<const float4*>(tp)[2];
+    F3 e1 = f3(q1.x, q1.y, q1.z), e2 = f3(q2.x, q2.y, q2.z);
+    const DevTriShade sh = sc.tri_shade[__float_as_uint(q0.w)];
+    float b1 = h.b1, b2 = h.b2;
+    float b0 = 1.0f - b1 - b2;
+    F3 pos = ro + h.t * rd;
+    F3 nrm;
+    if (sh.flags & 1u) {
+        F3 n0 = load3(sc.normals + 3 * sh.v[0]), n1 = load3(sc.normals + 3 * sh.v[1]), n2 = load3(sc.normals + 3 * sh.v[2]);
+        nrm = normalize(b0 * n0 + b1 * n1 + b2 * n2);
+    } else {
+        nrm = normalize(cross(e1, e2));
+    }
+    F3 dpdu;
+    if (sh.flags & 2u) {
+        const float* uv = sc.uvs;
+        float u0 = uv[2 * sh.v[0]], v0 = uv[2 * sh.v[0] + 1];
+        float u1 = uv[2 * sh.v[1]], v1 = uv[2 * sh.v[1] + 1];
+        float u2 = uv[2 * sh.v[2]], v2 = uv[2 * sh.v[2] + 1];
+        float du1 = u1 - u0, dv1 = v1 - v0, du2 = u2 - u0, dv2 = v2 - v0;
+        float det = du1 * dv2 - dv1 * du2;   // never 0: the packer rejects degenerate-uv meshes
+        float inv_det = 1.0f / det;
+        dpdu = inv_det * (dv2 * e1 - dv1 * e2);
+    } else {
+        dpdu = e1;   // default uvs (0,0),(1,0),(0,1): invDet * (1*e1 - 0*e2)
+    }
+    // Fragment::transform
+    fr.p = xf_point(ip->m, pos);
+    fr.n = normalize(xf_normal(ip->inv, nrm));
+    F3 dpdu_w = xf_vector(ip->m, dpdu);
+    // Fragment::getWorldToShade
+    fr.t = normalize(dpdu_w - fr.n * dot(dpdu_w, fr.n));
+    fr.b = cross(fr.n, fr.t);
+    fr.eps = 1e-3f * h.t;
+}
+
+// shadeToWorld * v, shadeToWorld = transpose(rows t, b, n)
+__device__ __forceinline__ F3 shade_to_world(const Frag& fr, F3 v) {
+    return f3(fr.t.x * v.x + fr.b.x * v.y + fr.n.x * v.z, fr.t.y * v.x + fr.b.y * v.y + fr.n.y * v.z,
+              fr.t.z * v.x + fr.b.z * v.y + fr.n.z * v.z);
+}
+
+__device__ __forceinline__ F3 cosine_sample_hemisphere(float u1, float u2) {
+    float sin_t = sqrtf(u1);
+    float cos_t = sqrtf(fmaxf(0.0f, 1.0f - u1));
+    float phi = GBL_TWO_PI * u2;
+    return f3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+}
+__device__ __forceinline__ F3 uniform_sample_hemisphere(float u1, float u2) {
+    float sin_t = sqrtf(fmaxf(0.0f, 1.0f - u1 * u1));
+    float phi = GBL_TWO_PI * u2;
+    return f3(sin_t * cosf(phi), sin_t * sinf(phi), u1);
+}
+__device__ __forceinline__ float power_heuristic(float pa, float pb) {
+    float A = 1.0f * pa, B = 1.0f * pb;
+    return A * A / (A * A + B * B);
+}
+
+// ------------------------------------------------------------------ materials
+__device__ __forceinline__ float clamp_pm1(float f) { return f < -1.0f ? -1.0f : (f > 1.0f ? 1.0f : f); }
+
+__device__ __forceinline__ float fresnel_dielectric(float cosi, float etai, float etat) {
+    cosi = clamp_pm1(cosi);
+    float sint = (etai / etat) * sqrtf(fmaxf(0.0f, 1.0f - cosi * cosi));
+    if (sint >= 1.0f) return 1.0f;
+    float cost = sqrtf(fmaxf(0.0f, 1 - sint * sint));
+    cosi = fabsf(cosi);
+    float r_parl = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    float r_perp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
+}
+__device__ __forceinline__ float fresnel_conductor(float cosi, float eta, float k) {
+    float tmp = (eta * eta + k * k);
+    float cosi2 = cosi * cosi;
+    float r_parl2 = (tmp * cosi2 - 2.0f * eta * cosi + 1.0f) / (tmp * cosi2 + 2.0f * eta * cosi + 1.0f);
+    float r_perp2 = (tmp - 2.0f * eta * cosi + cosi2) / (tmp + 2.0f * eta * cosi + cosi2);
+    return (r_parl2 + r_perp2) * 0.5f;
+}
+
+__device__ __forceinline__ bool same_hemisphere(F3 n, F3 wo, F3 wi) { return dot(wo, n) * dot(wi, n) > 0.0f; }
+
+__device__ __forceinline__ F3 blinn_bsdf(const DevMaterial& m, F3 n, F3 wo, F3 wi) {
+    // getSampleType strips Reflection when wo, wi are on opposite sides -> no match
+    if (!(dot(n, wo) * dot(n, wi) > 0.0f)) return f3(0, 0, 0);
+    float cosi = absdot(n, wi), coso = absdot(n, wo);
+    if (cosi == 0.0f || coso == 0.0f) return f3(0, 0, 0);
+    F3 wh = normalize(wo + wi);
+    float cosh = absdot(n, wh);
+    float e = m.exponent;
+    float D = (e + 2.0f) * GBL_INV_TWOPI * powf(cosh, e);
+    float wo_wh = absdot(wo, wh);
+    float G = fminf(1.0f, fminf(2.0f * cosh * coso / wo_wh, 2.0f * cosh * cosi / wo_wh));
+    float F = m.k > 0.0f ? fresnel_conductor(wo_wh, m.index, m.k) : fresnel_dielectric(wo_wh, 1.0f, m.index);
+    F3 kg = f3(m.color[0], m.color[1], m.color[2]);
+    return div(kg * D * G * F, 4.0f * cosi * coso);
+}
+__device__ __forceinline__ float blinn_pdf(const DevMaterial& m, F3 n, F3 wo, F3 wi) {
+    if (!same_hemisphere(n, wo, wi)) return 0.0f;
+    F3 wh = normalize(wo + wi);
+    float cos_h = absdot(wh, n);
+    float e = m.exponent;
+    return (e + 1.0f) * powf(cos_h, e) / (GBL_TWO_PI * 4.0f * dot(wo, wh));
+}
+
+// material->bsdf(fragment, wo, wi)
+__device__ __forceinline__ F3 mat_bsdf(const DevMaterial& m, F3 n, F3 wo, F3 wi) {
+    if (m.type == GBL_MAT_LAMBERT) {
+        if (dot(n, wo) * dot(n, wi) > 0.0f) {
+            F3 kd = f3(m.color[0], m.color[1], m.color[2]);
+            F3 v = kd * GBL_INV_PI;
+            return f3(0.0f + v.x, 0.0f + v.y, 0.0f + v.z);   // f(Black) += Kd * INV_PI
+        }
+        return f3(0, 0, 0);
+    }
+    if (m.type == GBL_MAT_BLINN) return blinn_bsdf(m, n, wo, wi);
+    return f3(0, 0, 0);
+}
+__device__ __forceinline__ float mat_pdf(const DevMaterial& m, F3 n, F3 wo, F3 wi) {
+    if (m.type == GBL_MAT_LAMBERT) return same_hemisphere(n, wo, wi) ? absdot(n, wi) * GBL_INV_PI : 0.0f;
+    if (m.type == GBL_MAT_BLINN) return blinn_pdf(m, n, wo, wi);
+    return 0.0f;
+}
+
+// material->sampleBSDF(fragment, wo, bs, &wi, &pdf, BSDFAll, &sampledType); *specular = sampledType & BSDFSpecular
+__device__ __forceinline__ F3 mat_sample(const DevMaterial& m, const Frag& fr, F3 wo, float u_comp, float u1, float u2, F3* wi,
+                                         float* pdf, bool* specular) {
+    F3 n = fr.n;
+    if (m.type == GBL_MAT_LAMBERT) {
+        F3 local = cosine_sample_hemisphere(u1, u2);
+        if (dot(wo, n) < 0.0f) local = local * -1.0f;
+        *wi = shade_to_world(fr, local);
+        *pdf = mat_pdf(m, n, wo, *wi);
+        *specular = false;
+        return f3(m.color[0], m.color[1], m.color[2]) * GBL_INV_PI;
+    }
+    if (m.type == GBL_MAT_BLINN) {
+        float e = m.exponent;
+        float cos_t = powf(u1, 1.0f / (e + 1.0f));
+        float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+        float phi = u2 * GBL_TWO_PI;
+        F3 wh_local = f3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+        if (dot(wo, n) < 0.0f) wh_local = wh_local * -1.0f;
+        F3 wh = shade_to_world(fr, wh_local);
+        *wi = -wo + 2.0f * dot(wo, wh) * wh;
+        *pdf = blinn_pdf(m, n, wo, *wi);
+        *specular = false;
+        return blinn_bsdf(m, n, wo, *wi);
+    }
+    *specular = true;
+    if (m.type == GBL_MAT_TRANSPARENT) {
+        // specularReflectDieletric / specularRefract with etai = 1, etat = index
+        float cosi = dot(n, wo);
+        bool entering = cosi > 0.0f;
+        F3 nn = entering ? n : -n;
+        float ci = entering ? cosi : -cosi;
+        float ei = entering ? 1.0f : m.index, et = entering ? m.index : 1.0f;
+        float fr_refl = fresnel_dielectric(ci, ei, et);
+        F3 w_refl = 2 * ci * nn - wo;
+        float reflect = fr_refl / ci;
+        // refraction: (et, ei) roles as in specularRefract (etao = 1, etai = index)
+        float ro_et = entering ? 1.0f : m.index, ro_ei = entering ? m.index : 1.0f;
+        float f2 = fresnel_dielectric(ci, ro_et, ro_ei);
+        float refract = 0.0f;
+        F3 w_refr = f3(0, 0, 0);
+        if (f2 != 1.0f) {
+            float eta = ro_et / ro_ei;
+            w_refr = normalize(nn * (eta * ci - sqrtf(fmaxf(0.0f, 1.0f - eta * eta * (1.0f - ci * ci)))) - eta * wo);
+            refract = eta * eta * (1.0f - f2) / absdot(w_refr, nn);
+        }
+        float chance = reflect * absdot(w_refl, n);
+        if (u_comp < chance) {
+            *wi = w_refl;
+            *pdf = chance;
+            return f3(m.color[0], m.color[1], m.color[2]) * reflect;
+        }
+        *wi = w_refr;
+        *pdf = 1.0f - chance;
+        return f3(m.color2[0], m.color2[1], m.color2[2]) * refract;
+    }
+    // mirror
+    float cosi = dot(n, wo);
+    *pdf = 1.0f;
+    if (cosi <= 0.0f) {
+        *wi = f3(0, 0, 0);
+        return f3(m.color[0], m.color[1], m.color[2]) * 0.0f;
+    }
+    float f = fresnel_conductor(cosi, m.index, m.k);
+    *wi = 2 * cosi * n - wo;
+    return f3(m.color[0], m.color[1], m.color[2]) * (f / cosi);
+}
+
+// --------------------------------------------------------------------- lights
+// Geometry::pdf for one emitting triangle, light-local space
+__device__ __forceinline__ float light_tri_pdf(const DevLightTri& lt, F3 p, F3 wi) {
+    F3 p0 = f3(lt.p0[0], lt.p0[1], lt.p0[2]), p1 = f3(lt.p1[0], lt.p1[1], lt.p1[2]), p2 = f3(lt.p2[0], lt.p2[1], lt.p2[2]);
+    F3 e1 = p1 - p0, e2 = p2 - p0;
+    F3 s1 = cross(wi, e2);
+    float divisor = dot(s1, e1);
+    if (divisor == 0.0f) return 0.0f;
+    float inv = 1.0f / divisor;
+    const float eps = 1e-7f;
+    F3 s = p - p0;
+    float b1 = dot(s, s1) * inv;
+    if (b1 + eps < 0.0f || b1 - eps > 1.0f) return 0.0f;
+    F3 s2 = cross(s, e1);
+    float b2 = dot(wi, s2) * inv;
+    if (b2 + eps < 0.0f || b1 + b2 - eps > 1.0f) return 0.0f;
+    float t = dot(e2, s2) * inv;
+    if (t < 1e-3f || t > INFINITY) return 0.0f;
+    float b0 = 1.0f - b1 - b2;
+    F3 pos = p + t * wi;
+    F3 nrm;
+    if (lt.has_normal != 0.0f) {
+        F3 n0 = f3(lt.n0[0], lt.n0[1], lt.n0[2]), n1 = f3(lt.n1[0], lt.n1[1], lt.n1[2]), n2 = f3(lt.n2[0], lt.n2[1], lt.n2[2]);
+        nrm = normalize(b0 * n0 + b1 * n1 + b2 * n2);
+    } else {
+        nrm = normalize(cross(e1, e2));
+    }
+    float pdf = sqlen(p - pos) / (lt.area * absdot(-wi, nrm));
+    if (isinf(pdf)) pdf = 0.0f;
+    return pdf;
+}
+// GeometrySet::pdf
+__device__ __forceinline__ float light_geoset_pdf(const DevScene& sc, const DevLight& l, F3 p, F3 wi) {
+    float pdf = 0.0f;
+    for (uint32_t k = 0; k < l.tri_count; ++k) {
+        const DevLightTri& lt = sc.light_tris[l.tri_first + k];
+        pdf += lt.area * light_tri_pdf(lt, p, wi);
+    }
+    pdf /= l.sum_area;
+    return pdf;
+}
+
+struct LightSampleOut {
+    F3 L, wi;
+    float pdf, maxt;
+};
+
+// light->sampleL(p, epsilon, ls, ...)
+__device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight& l, F3 p, float epsilon, float u_comp, float u1,
+                                             float u2, LightSampleOut& o) {
+    F3 color = f3(l.color[0], l.color[1], l.color[2]);
+    if (l.type == GBL_LIGHT_AREA) {
+        F3 p_local = xf_point(l.inv, p);
+        // CDF1D::sampleDiscrete: lower_bound(cdf, u) - 1, clamped at 0
+        uint32_t tri = 0;
+        for (uint32_t k = 0; k < l.tri_count; ++k)
+            if (sc.light_tris[l.tri_first + k].cdf_hi < u_comp) tri = k + 1;
+        if (tri >= l.tri_count) tri = l.tri_count - 1;
+        const DevLightTri& lt = sc.light_tris[l.tri_first + tri];
+        float root = sqrtf(u1);
+        float b0 = 1.0f - root, b1 = root * u2;
+        F3 p0 = f3(lt.p0[0], lt.p0[1], lt.p0[2]), p1 = f3(lt.p1[0], lt.p1[1], lt.p1[2]), p2 = f3(lt.p2[0], lt.p2[1], lt.p2[2]);
+        F3 ns_local = normalize(cross(p1 - p0, p2 - p0));
+        F3 ps_local = b0 * p0 + b1 * p1 + (1.0f - b0 - b1) * p2;
+        F3 wi_local = normalize(ps_local - p_local);
+        o.pdf = light_geoset_pdf(sc, l, p_local, wi_local);
+        F3 ps = xf_point(l.m, ps_local);
+        F3 ns = normalize(xf_normal(l.inv, ns_local));
+        o.wi = normalize(ps - p);
+        o.maxt = length(ps - p) - epsilon;
+        o.L = dot(ns, -o.wi) > 0.0f ? color : f3(0, 0, 0);
+        return;
+    }
+    F3 dir = f3(l.pos[0], l.pos[1], l.pos[2]) - p;
+    o.wi = normalize(dir);
+    o.pdf = 1.0f;
+    float d2 = sqlen(dir);
+    o.maxt = sqrtf(d2) - epsilon;
+    if (l.type == GBL_LIGHT_SPOT) {
+        float cos_t = dot(-o.wi, f3(l.axis[0], l.axis[1], l.axis[2]));
+        float fall;
+        if (cos_t < l.cos_max) {
+            fall = 0.0f;
+        } else if (cos_t > l.cos_falloff) {
+            fall = 1.0f;
+        } else {
+            float dl = (cos_t - l.cos_max) / (l.cos_falloff - l.cos_max);
+            fall = dl * dl * dl * dl;
+        }
+        o.L = div(fall * color, d2);
+    } else {
+        o.L = div(color, d2);
+    }
+}
+
+// light->pdf(p, wi): 0 for delta lights, AreaLight::pdf otherwise (wi is NOT renormalised in light space)
+__device__ __forceinline__ float light_pdf(const DevScene& sc, const DevLight& l, F3 p, F3 wi) {
+    if (l.type != GBL_LIGHT_AREA) return 0.0f;
+    return light_geoset_pdf(sc, l, xf_point(l.inv, p), xf_vector(l.inv, wi));
+}
+
+// Intersection::Le(out): the hit instance's area light, one-sided
+__device__ __forceinline__ F3 hit_Le(const DevScene& sc, int inst, F3 n, F3 out_dir) {
+    int al = sc.instances[inst].area_light;
+    if (al < 0) return f3(0, 0, 0);
+    const DevLight& l = sc.lights[al];
+    return dot(n, out_dir) > 0.0f ? f3(l.color[0], l.color[1], l.color[2]) : f3(0, 0, 0);
+}

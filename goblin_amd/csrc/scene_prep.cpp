@@ -1,0 +1,664 @@
+// Host-side scene packing for the device integrator: transforms, the two-level
+// BVH (our own binned-SAH builder, NOT the reference's median-split tree), the
+// packed triangle / instance / material / light tables, camera and film
+// constants.  Replaces the constructors the reference runs at load time:
+//   Transform::update            GoblinTransform.cpp:182-193
+//   Model / Scene BVH build      GoblinModel.cpp:10-26, GoblinScene.cpp:11-27, GoblinBVH.cpp:34-151
+//   SpotLight / AreaLight ctors  GoblinLight.cpp:212-223, 345-361
+//   PerspectiveCamera ctor       GoblinCamera.cpp:83-95
+//   FilterTable ctor             GoblinFilm.cpp:10-27
+// Radiance is BVH-independent except for exact t ties, so the tree is built for
+// the GPU: both child boxes in the parent (64 B nodes), <= 4 triangles per leaf,
+// SAH splits, depth-capped so the LDS traversal stack has a hard bound.
+#include "scene_prep.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+const float kPi = 3.14159265358979323f;
+const float kTwoPi = 6.28318530718f;
+
+// ---------------------------------------------------------------- transforms
+struct Mat4 {
+    float v[4][4];
+};
+
+Mat4 identity() {
+    Mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) r.v[i][j] = i == j ? 1.0f : 0.0f;
+    return r;
+}
+
+Mat4 multiply(const Mat4& a, const Mat4& b) {
+    Mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = a.v[i][0] * b.v[0][j];
+            acc = acc + a.v[i][1] * b.v[1][j];
+            acc = acc + a.v[i][2] * b.v[2][j];
+            acc = acc + a.v[i][3] * b.v[3][j];
+            r.v[i][j] = acc;
+        }
+    return r;
+}
+
+Mat4 rotation_of(const float q[4]) {   // q = w x y z
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float xx = tx * x, xy = tx * y, xz = tx * z, xw = tx * w;
+    const float yy = ty * y, yz = ty * z, yw = ty * w;
+    const float zz = tz * z, zw = tz * w;
+    Mat4 r = identity();
+    r.v[0][0] = 1 - yy - zz; r.v[0][1] = xy - zw;     r.v[0][2] = xz + yw;
+    r.v[1][0] = xy + zw;     r.v[1][1] = 1 - xx - zz; r.v[1][2] = yz - xw;
+    r.v[2][0] = xz - yw;     r.v[2][1] = yz + xw;     r.v[2][2] = 1 - xx - yy;
+    return r;
+}
+
+// 2x2 minor of rows (r0, r1), columns (c0, c1)
+inline float minor2(const Mat4& m, int r0, int r1, int c0, int c1) { return m.v[r0][c0] * m.v[r1][c1] - m.v[r0][c1] * m.v[r1][c0]; }
+
+// General 4x4 inverse by cofactors, expanding each cofactor along the row that
+// is NOT in the minor's row pair, in the same association as the reference so
+// the float32 result is the same; fails (returns false) when |det| < 1e-5.
+bool invert(const Mat4& m, Mat4* out) {
+    const int cols[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+    float a[6], b[6], c[6];   // minors of row pairs (2,3), (1,3), (1,2)
+    for (int k = 0; k < 6; ++k) {
+        a[k] = minor2(m, 2, 3, cols[k][0], cols[k][1]);
+        b[k] = minor2(m, 1, 3, cols[k][0], cols[k][1]);
+        c[k] = minor2(m, 1, 2, cols[k][0], cols[k][1]);
+    }
+    auto cof = [&](int row, const float s[6], float r[4]) {
+        r[0] = m.v[row][1] * s[0] - m.v[row][2] * s[1] + m.v[row][3] * s[2];
+        r[1] = m.v[row][0] * s[0] - m.v[row][2] * s[3] + m.v[row][3] * s[4];
+        r[2] = m.v[row][0] * s[1] - m.v[row][1] * s[3] + m.v[row][3] * s[5];
+        r[3] = m.v[row][0] * s[2] - m.v[row][1] * s[4] + m.v[row][2] * s[5];
+    };
+    float k0[4], k1[4], k2[4], k3[4];
+    cof(1, a, k0);
+    cof(0, a, k1);
+    cof(0, b, k2);
+    cof(0, c, k3);
+    const float sgn[4] = {1.0f, -1.0f, 1.0f, -1.0f};
+    Mat4& o = *out;
+    for (int i = 0; i < 4; ++i) o.v[i][0] = sgn[i] > 0 ? k0[i] : -k0[i];
+    float det = m.v[0][0] * o.v[0][0] + m.v[0][1] * o.v[1][0] + m.v[0][2] * o.v[2][0] + m.v[0][3] * o.v[3][0];
+    if (std::fabs(det) < 1e-5f) return false;
+    float inv_det = 1.0f / det;
+    for (int i = 0; i < 4; ++i) {
+        o.v[i][1] = sgn[i] > 0 ? -k1[i] : k1[i];
+        o.v[i][2] = sgn[i] > 0 ? k2[i] : -k2[i];
+        o.v[i][3] = sgn[i] > 0 ? -k3[i] : k3[i];
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) o.v[i][j] *= inv_det;
+    return true;
+}
+
+struct Trs {
+    Mat4 m, inv;
+    bool invertible;
+};
+
+Trs compose(const float pos[3], const float q[4], const float scale[3]) {
+    Mat4 S = identity();
+    S.v[0][0] = scale[0]; S.v[1][1] = scale[1]; S.v[2][2] = scale[2];
+    Trs t;
+    t.m = multiply(rotation_of(q), S);
+    t.m.v[0][3] = pos[0]; t.m.v[1][3] = pos[1]; t.m.v[2][3] = pos[2];
+    t.inv = identity();
+    t.invertible = invert(t.m, &t.inv);
+    return t;
+}
+
+void store3x4(const Mat4& m, float out[12]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = m.v[i][j];
+}
+
+void point_by(const Mat4& m, const float p[3], float out[3]) {
+    for (int i = 0; i < 3; ++i) out[i] = m.v[i][0] * p[0] + m.v[i][1] * p[1] + m.v[i][2] * p[2] + m.v[i][3];
+}
+
+// ---------------------------------------------------------------------- BVH
+struct Aabb {
+    float lo[3], hi[3];
+    Aabb() {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = INFINITY;
+            hi[k] = -INFINITY;
+        }
+    }
+    void grow(const float p[3]) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Aabb& b) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    float half_area() const {
+        float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0f;
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+    }
+};
+
+struct Prim {
+    Aabb box;
+    float c[3];
+    uint32_t id;
+};
+
+struct TmpNode {
+    Aabb box;
+    int left = -1, right = -1;   // interior
+    uint32_t first = 0, count = 0;   // leaf when count > 0
+};
+
+int balanced_height(size_t n, int leaf) {
+    int h = 1;
+    size_t leaves = (n + leaf - 1) / leaf;
+    while (leaves > 1) {
+        leaves = (leaves + 1) / 2;
+        ++h;
+    }
+    return h;
+}
+
+struct Builder {
+    std::vector<Prim>& prims;
+    std::vector<TmpNode> nodes;
+    int max_leaf, depth_cap, height = 0;
+    Builder(std::vector<Prim>& p, int leaf, int cap) : prims(p), max_leaf(leaf), depth_cap(cap) {}
+
+    int build(size_t start, size_t end, int depth) {
+        int me = static_cast<int>(nodes.size());
+        nodes.push_back(TmpNode());
+        Aabb box, cbox;
+        for (size_t i = start; i < end; ++i) {
+            box.grow(prims[i].box);
+            cbox.grow(prims[i].c);
+        }
+        nodes[me].box = box;
+        height = std::max(height, depth);
+        size_t n = end - start;
+        int room = depth_cap - depth;   // levels available below this node
+        // binned SAH over the centroid bounds, all three axes
+        const int B = 16;
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        float parent_area = box.half_area();
+        if (n > 1 && parent_area > 0.0f) {
+            for (int axis = 0; axis < 3; ++axis) {
+                float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
+                if (!(ext > 0.0f)) continue;
+                Aabb bb[B];
+                size_t bn[B] = {0};
+                float scale = B / ext;
+                for (size_t i = start; i < end; ++i) {
+                    int b = std::min(B - 1, static_cast<int>((prims[i].c[axis] - lo) * scale));
+                    bb[b].grow(prims[i].box);
+                    bn[b]++;
+                }
+                Aabb right_acc[B];
+                size_t right_n[B];
+                Aabb acc;
+                size_t cnt = 0;
+                for (int b = B - 1; b >= 1; --b) {
+                    acc.grow(bb[b]);
+                    cnt += bn[b];
+                    right_acc[b] = acc;
+                    right_n[b] = cnt;
+                }
+                Aabb left;
+                size_t ln = 0;
+                for (int b = 0; b < B - 1; ++b) {
+                    left.grow(bb[b]);
+                    ln += bn[b];
+                    size_t rn = right_n[b + 1];
+                    if (ln == 0 || rn == 0) continue;
+                    if (balanced_height(std::max(ln, rn), max_leaf) > room) continue;   // would break the depth cap
+                    float cost = 1.0f + (left.half_area() * ln + right_acc[b + 1].half_area() * rn) / parent_area;
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = axis;
+                        best_bin = b;
+                    }
+                }
+            }
+        }
+        bool can_leaf = n <= static_cast<size_t>(max_leaf);
+        if (can_leaf && (best_axis < 0 || static_cast<float>(n) <= best_cost)) {
+            nodes[me].first = static_cast<uint32_t>(start);
+            nodes[me].count = static_cast<uint32_t>(n);
+            return me;
+        }
+        size_t mid;
+        if (best_axis >= 0) {
+            float lo = cbox.lo[best_axis], scale = B / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+            int axis = best_axis, bin = best_bin;
+            auto it = std::partition(prims.begin() + start, prims.begin() + end, [&](const Prim& p) {
+                return std::min(B - 1, static_cast<int>((p.c[axis] - lo) * scale)) <= bin;
+            });
+            mid = static_cast<size_t>(it - prims.begin());
+        } else {
+            // object median on the widest centroid axis (also the depth-cap fallback)
+            int axis = 0;
+            float e[3] = {cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2]};
+            if (e[1] > e[axis]) axis = 1;
+            if (e[2] > e[axis]) axis = 2;
+            mid = (start + end) / 2;
+            std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end,
+                             [axis](const Prim& a, const Prim& b) { return a.c[axis] < b.c[axis]; });
+        }
+        if (mid == start || mid == end) mid = (start + end) / 2;
+        int l = build(start, mid, depth + 1);
+        int r = build(mid, end, depth + 1);
+        nodes[me].left = l;
+        nodes[me].right = r;
+        return me;
+    }
+};
+
+// one ulp-ish outward nudge so the fma-form slab test can never cull a triangle
+// the exact test would keep
+inline float nudge_down(float v) { return v - std::fabs(v) * 1.2e-7f - 1e-30f; }
+inline float nudge_up(float v) { return v + std::fabs(v) * 1.2e-7f + 1e-30f; }
+
+// Flatten interior TmpNodes into DevNodes (DFS preorder).  leaf_ref(first,count) encodes a leaf.
+template <class LeafRef>
+int32_t flatten(const Builder& b, int root, std::vector<DevNode>& out, LeafRef leaf_ref) {
+    const TmpNode& r = b.nodes[root];
+    if (r.count > 0) return leaf_ref(r.first, r.count);
+    int32_t me = static_cast<int32_t>(out.size());
+    out.push_back(DevNode());
+    const TmpNode& c0 = b.nodes[r.left];
+    const TmpNode& c1 = b.nodes[r.right];
+    int32_t ref0 = flatten(b, r.left, out, leaf_ref);
+    int32_t ref1 = flatten(b, r.right, out, leaf_ref);
+    DevNode& n = out[me];
+    n.c0x[0] = nudge_down(c0.box.lo[0]); n.c0x[1] = nudge_up(c0.box.hi[0]);
+    n.c0y[0] = nudge_down(c0.box.lo[1]); n.c0y[1] = nudge_up(c0.box.hi[1]);
+    n.c1x[0] = nudge_down(c1.box.lo[0]); n.c1x[1] = nudge_up(c1.box.hi[0]);
+    n.c1y[0] = nudge_down(c1.box.lo[1]); n.c1y[1] = nudge_up(c1.box.hi[1]);
+    n.c0z[0] = nudge_down(c0.box.lo[2]); n.c0z[1] = nudge_up(c0.box.hi[2]);
+    n.c1z[0] = nudge_down(c1.box.lo[2]); n.c1z[1] = nudge_up(c1.box.hi[2]);
+    n.child[0] = ref0;
+    n.child[1] = ref1;
+    n.pad[0] = n.pad[1] = 0;
+    return me;
+}
+
+// -------------------------------------------------------------------- filter
+struct Filter {
+    uint32_t type;
+    float wx, wy, alpha, ex, ey, b, c;
+    float gauss(float v, float base) const { return std::max(0.0f, expf(-alpha * v * v) - base); }
+    float mitchell1(float x) const {
+        x = std::fabs(2.0f * x);
+        if (x > 1.0f) return ((-b - 6 * c) * x * x * x + (6 * b + 30 * c) * x * x + (-12 * b - 48 * c) * x + (8 * b + 24 * c)) / 6.0f;
+        return ((12 - 9 * b - 6 * c) * x * x * x + (-18 + 12 * b + 6 * c) * x * x + (6 - 2 * b)) / 6.0f;
+    }
+    float eval(float x, float y) const {
+        if (type == GBL_FILTER_BOX) return 1.0f;
+        if (type == GBL_FILTER_TRIANGLE) return std::max(0.0f, wx - fabsf(x)) * std::max(0.0f, wy - fabsf(y));
+        if (type == GBL_FILTER_MITCHELL) return mitchell1(x * (1.0f / wx)) * mitchell1(y * (1.0f / wy));
+        return gauss(x, ex) * gauss(y, ey);
+    }
+    float norm() const {
+        if (type == GBL_FILTER_BOX) return 4.0f * wx * wy;
+        if (type == GBL_FILTER_TRIANGLE) return wx * wx * wy * wy;
+        if (type == GBL_FILTER_MITCHELL)
+            return 4.0f * ((12 - 9 * b - 6 * c) / 4 + (-18 + 12 * b + 6 * c) / 3 + (6 - 2 * b) + 15 * (-b - 6 * b) / 4 +
+                           7 * (6 * b + 30 * c) / 3 + 3 * (-12 * b - 48 * c) / 2 + (8 * b + 24 * c)) / 6.0f;
+        const size_t steps = 20;   // the reference integrates the gaussian numerically (GoblinFilter.cpp:48-64)
+        float dx = wx / static_cast<float>(steps), dy = wy / static_cast<float>(steps), sum = 0.0f;
+        for (size_t i = 0; i < steps; ++i)
+            for (size_t j = 0; j < steps; ++j) sum += 4.0f * dx * dy * gauss(i * dx, ex) * gauss(j * dy, ey);
+        return sum;
+    }
+};
+
+int ceil_i(float f) { return static_cast<int>(std::ceil(f)); }
+int floor_i(float f) { return static_cast<int>(std::floor(f)); }
+
+}  // namespace
+
+gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* err) {
+    if (!d || d->abi_version != GBL_ABI_VERSION) {
+        *err = "scene description has the wrong abi_version";
+        return GBL_ERR_INVALID;
+    }
+    if (d->camera.lens_radius != 0.0f) {
+        *err = "thin-lens camera is outside the device path";
+        return GBL_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < d->num_instances; ++i) {
+        if (d->instances[i].mesh >= d->num_meshes || d->instances[i].material >= d->num_materials ||
+            d->instances[i].area_light >= static_cast<int32_t>(d->num_lights)) {
+            *err = "instance " + std::to_string(i) + " references a mesh/material/light out of range";
+            return GBL_ERR_INVALID;
+        }
+    }
+    for (uint32_t i = 0; i < d->num_meshes; ++i) {
+        const gbl_mesh& m = d->meshes[i];
+        if (m.tri_count == 0 || static_cast<uint64_t>(m.vertex_offset) + m.vertex_count > d->num_vertices ||
+            static_cast<uint64_t>(m.tri_offset) + m.tri_count > d->num_triangles) {
+            *err = "mesh " + std::to_string(i) + " is empty or out of range";
+            return GBL_ERR_INVALID;
+        }
+        for (uint32_t t = 0; t < 3 * m.tri_count; ++t)
+            if (d->indices[3 * static_cast<size_t>(m.tri_offset) + t] >= m.vertex_count) {
+                *err = "mesh " + std::to_string(i) + " has a vertex index out of range";
+                return GBL_ERR_INVALID;
+            }
+    }
+
+    // ---- vertex attributes used at shading time
+    out->normals.assign(d->normals, d->normals + 3 * static_cast<size_t>(d->num_vertices));
+    out->uvs.assign(d->uvs, d->uvs + 2 * static_cast<size_t>(d->num_vertices));
+
+    // ---- one BLAS per mesh
+    const int kBlasCap = 40, kTlasCap = 22;
+    std::vector<int32_t> mesh_root(d->num_meshes);
+    std::vector<Aabb> mesh_bounds(d->num_meshes);
+    out->tris.clear();
+    out->tri_shade.assign(d->num_triangles, DevTriShade());
+    out->blas_max_depth = 0;
+    for (uint32_t mi = 0; mi < d->num_meshes; ++mi) {
+        const gbl_mesh& gm = d->meshes[mi];
+        const float* P = d->positions + 3 * static_cast<size_t>(gm.vertex_offset);
+        const uint32_t* I = d->indices + 3 * static_cast<size_t>(gm.tri_offset);
+        for (uint32_t v = 0; v < gm.vertex_count; ++v) mesh_bounds[mi].grow(P + 3 * v);
+        std::vector<Prim> prims(gm.tri_count);
+        for (uint32_t t = 0; t < gm.tri_count; ++t) {
+            Prim& p = prims[t];
+            for (int k = 0; k < 3; ++k) p.box.grow(P + 3 * I[3 * t + k]);
+            for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+            p.id = t;
+            DevTriShade& s = out->tri_shade[gm.tri_offset + t];
+            for (int k = 0; k < 3; ++k) s.v[k] = gm.vertex_offset + I[3 * t + k];
+            s.flags = (gm.has_normal ? 1u : 0u) | (gm.has_uv ? 2u : 0u);
+        }
+        Builder b(prims, GBL_MAX_LEAF_TRIS, kBlasCap);
+        int root = b.build(0, prims.size(), 1);
+        out->blas_max_depth = std::max(out->blas_max_depth, b.height);
+        uint32_t tri_base = static_cast<uint32_t>(out->tris.size());
+        for (const Prim& p : prims) {
+            const float* p0 = P + 3 * I[3 * p.id];
+            const float* p1 = P + 3 * I[3 * p.id + 1];
+            const float* p2 = P + 3 * I[3 * p.id + 2];
+            DevTri t;
+            memset(&t, 0, sizeof(t));
+            for (int k = 0; k < 3; ++k) {
+                t.p0[k] = p0[k];
+                t.e1[k] = p1[k] - p0[k];
+                t.e2[k] = p2[k] - p0[k];
+            }
+            t.shade = gm.tri_offset + p.id;
+            out->tris.push_back(t);
+        }
+        mesh_root[mi] = flatten(b, root, out->nodes, [&](uint32_t first, uint32_t count) {
+            return ~static_cast<int32_t>(((tri_base + first) << 2) | (count - 1));
+        });
+    }
+    out->blas_nodes = out->nodes.size();
+
+    // ---- instances + TLAS
+    out->instances.resize(d->num_instances);
+    std::vector<Prim> iprims(d->num_instances);
+    for (uint32_t i = 0; i < d->num_instances; ++i) {
+        const gbl_instance& gi = d->instances[i];
+        Trs t = compose(gi.to_world.position, gi.to_world.orientation, gi.to_world.scale);
+        if (!t.invertible) {
+            *err = "instance " + std::to_string(i) + ": |det(toWorld)| < 1e-5, the reference cannot invert this transform "
+                   "(GoblinMatrix.cpp:451); use a uniform scale >= 0.0216";
+            return GBL_ERR_INVALID;
+        }
+        DevInstance& di = out->instances[i];
+        memset(&di, 0, sizeof(di));
+        store3x4(t.m, di.m);
+        store3x4(t.inv, di.inv);
+        di.root = mesh_root[gi.mesh];
+        di.material = static_cast<int32_t>(gi.material);
+        di.area_light = gi.area_light;
+        di.mesh = static_cast<int32_t>(gi.mesh);
+        // Transform::onBBox: the 8 corners of the mesh bound
+        const Aabb& mb = mesh_bounds[gi.mesh];
+        Prim& p = iprims[i];
+        for (int c = 0; c < 8; ++c) {
+            float corner[3] = {(c & 1) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1], (c & 4) ? mb.hi[2] : mb.lo[2]};
+            float w[3];
+            point_by(t.m, corner, w);
+            p.box.grow(w);
+        }
+        for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+        p.id = i;
+    }
+    out->tlas_depth = 0;
+    out->tlas_root = 0;
+    if (d->num_instances > 0) {
+        Builder tb(iprims, 1, kTlasCap);
+        int root = tb.build(0, iprims.size(), 1);
+        out->tlas_depth = tb.height;
+        out->tlas_root = flatten(tb, root, out->nodes, [&](uint32_t first, uint32_t) {
+            return ~static_cast<int32_t>(iprims[first].id << 2);
+        });
+    }
+    out->tlas_nodes = out->nodes.size() - out->blas_nodes;
+    out->stack_entries = out->tlas_depth + out->blas_max_depth + 2;
+
+    // ---- materials
+    out->materials.resize(d->num_materials);
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const gbl_material& m = d->materials[i];
+        if (m.type > GBL_MAT_MIRROR) {
+            *err = "unknown material type";
+            return GBL_ERR_INVALID;
+        }
+        DevMaterial& dm = out->materials[i];
+        memset(&dm, 0, sizeof(dm));
+        dm.type = m.type;
+        for (int k = 0; k < 3; ++k) {
+            dm.color[k] = m.color[k];
+            dm.color2[k] = m.color2[k];
+        }
+        dm.index = m.index;
+        dm.k = m.k;
+        dm.exponent = m.exponent;
+    }
+
+    // ---- lights, power distribution (Scene ctor, CDF1D::init)
+    out->lights.resize(d->num_lights);
+    out->light_tris.clear();
+    std::vector<float> power(d->num_lights);
+    for (uint32_t i = 0; i < d->num_lights; ++i) {
+        const gbl_light& gl = d->lights[i];
+        DevLight& dl = out->lights[i];
+        memset(&dl, 0, sizeof(dl));
+        dl.type = gl.type;
+        for (int k = 0; k < 3; ++k) {
+            dl.color[k] = gl.color[k];
+            dl.pos[k] = gl.position[k];
+        }
+        dl.cos_max = gl.cos_theta_max;
+        dl.cos_falloff = gl.cos_falloff_start;
+        float pr, pg, pb;
+        if (gl.type == GBL_LIGHT_SPOT) {
+            // direction -> orthonormal basis -> quaternion -> matrix; the axis the
+            // falloff is measured against is that matrix's third column
+            float dir[3] = {gl.direction[0], gl.direction[1], gl.direction[2]};
+            float inv_len = 1.0f / std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            for (int k = 0; k < 3; ++k) dir[k] *= inv_len;
+            float xa[3], ya[3];
+            if (fabsf(dir[0]) > fabsf(dir[1])) {
+                float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[2] * dir[2]);
+                xa[0] = -dir[2] * il; xa[1] = 0.0f; xa[2] = dir[0] * il;
+            } else {
+                float il = 1.0f / sqrtf(dir[1] * dir[1] + dir[2] * dir[2]);
+                xa[0] = 0.0f; xa[1] = -dir[2] * il; xa[2] = dir[1] * il;
+            }
+            ya[0] = dir[1] * xa[2] - dir[2] * xa[1];
+            ya[1] = dir[2] * xa[0] - dir[0] * xa[2];
+            ya[2] = dir[0] * xa[1] - dir[1] * xa[0];
+            float R[3][3] = {{xa[0], ya[0], dir[0]}, {xa[1], ya[1], dir[1]}, {xa[2], ya[2], dir[2]}};
+            float qv[4];   // x y z w
+            float trace = R[0][0] + R[1][1] + R[2][2];
+            if (trace > 0.0f) {
+                float s = std::sqrt(trace + 1.0f);
+                qv[3] = s * 0.5f;
+                float t = 0.5f / s;
+                qv[0] = (R[2][1] - R[1][2]) * t;
+                qv[1] = (R[0][2] - R[2][0]) * t;
+                qv[2] = (R[1][0] - R[0][1]) * t;
+            } else {
+                int a = 0;
+                if (R[1][1] > R[0][0]) a = 1;
+                if (R[2][2] > R[a][a]) a = 2;
+                int b2 = (a + 1) % 3, c2 = (b2 + 1) % 3;
+                float s = std::sqrt(R[a][a] - R[b2][b2] - R[c2][c2] + 1.0f);
+                qv[a] = s * 0.5f;
+                float t = s != 0.0f ? 0.5f / s : s;
+                qv[3] = (R[c2][b2] - R[b2][c2]) * t;
+                qv[b2] = (R[b2][a] + R[a][b2]) * t;
+                qv[c2] = (R[c2][a] + R[a][c2]) * t;
+            }
+            float q[4] = {qv[3], qv[0], qv[1], qv[2]};
+            float one[3] = {1.0f, 1.0f, 1.0f};
+            Trs t = compose(gl.position, q, one);
+            for (int k = 0; k < 3; ++k) dl.axis[k] = t.m.v[k][0] * 0.0f + t.m.v[k][1] * 0.0f + t.m.v[k][2] * 1.0f;
+            float solid = kTwoPi;
+            float f = (1.0f - 0.5f * (dl.cos_max + dl.cos_falloff));
+            pr = dl.color[0] * solid * f; pg = dl.color[1] * solid * f; pb = dl.color[2] * solid * f;
+        } else if (gl.type == GBL_LIGHT_AREA) {
+            if (gl.mesh >= d->num_meshes) {
+                *err = "area light references a mesh out of range";
+                return GBL_ERR_INVALID;
+            }
+            Trs t = compose(gl.to_world.position, gl.to_world.orientation, gl.to_world.scale);
+            store3x4(t.m, dl.m);
+            store3x4(t.inv, dl.inv);
+            const gbl_mesh& gm = d->meshes[gl.mesh];
+            const float* P = d->positions + 3 * static_cast<size_t>(gm.vertex_offset);
+            const float* N = d->normals + 3 * static_cast<size_t>(gm.vertex_offset);
+            const uint32_t* I = d->indices + 3 * static_cast<size_t>(gm.tri_offset);
+            dl.tri_first = static_cast<uint32_t>(out->light_tris.size());
+            dl.tri_count = gm.tri_count;
+            std::vector<float> areas(gm.tri_count);
+            float sum = 0.0f;
+            for (uint32_t k = 0; k < gm.tri_count; ++k) {
+                const float* p0 = P + 3 * I[3 * k];
+                const float* p1 = P + 3 * I[3 * k + 1];
+                const float* p2 = P + 3 * I[3 * k + 2];
+                float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+                float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+                float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                areas[k] = 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz);
+                sum += areas[k];
+            }
+            dl.sum_area = sum;
+            // CDF1D over the triangle areas
+            float dx = 1.0f / gm.tri_count;
+            std::vector<float> cdf(gm.tri_count + 1, 0.0f);
+            for (uint32_t k = 1; k <= gm.tri_count; ++k) cdf[k] = cdf[k - 1] + (areas[k - 1] * dx);
+            float integral = cdf[gm.tri_count];
+            for (uint32_t k = 1; k <= gm.tri_count; ++k) cdf[k] /= integral;
+            for (uint32_t k = 0; k < gm.tri_count; ++k) {
+                DevLightTri lt;
+                memset(&lt, 0, sizeof(lt));
+                for (int c = 0; c < 3; ++c) {
+                    lt.p0[c] = P[3 * I[3 * k] + c];
+                    lt.p1[c] = P[3 * I[3 * k + 1] + c];
+                    lt.p2[c] = P[3 * I[3 * k + 2] + c];
+                    lt.n0[c] = N[3 * I[3 * k] + c];
+                    lt.n1[c] = N[3 * I[3 * k + 1] + c];
+                    lt.n2[c] = N[3 * I[3 * k + 2] + c];
+                }
+                lt.area = areas[k];
+                lt.cdf_lo = cdf[k];
+                lt.cdf_hi = cdf[k + 1];
+                lt.has_normal = gm.has_normal ? 1.0f : 0.0f;
+                out->light_tris.push_back(lt);
+            }
+            float world_area = sum * (gl.to_world.scale[0] * gl.to_world.scale[1]);
+            pr = dl.color[0] * kPi * world_area; pg = dl.color[1] * kPi * world_area; pb = dl.color[2] * kPi * world_area;
+        } else if (gl.type == GBL_LIGHT_POINT) {
+            float s = 4.0f * kPi;
+            pr = dl.color[0] * s; pg = dl.color[1] * s; pb = dl.color[2] * s;
+        } else {
+            *err = "unknown light type";
+            return GBL_ERR_INVALID;
+        }
+        power[i] = 0.212671f * pr + 0.715160f * pg + 0.072169f * pb;
+    }
+    out->light_cdf.assign(d->num_lights + 1, 0.0f);
+    out->light_pick_pdf.assign(std::max<uint32_t>(1, d->num_lights), 0.0f);
+    if (d->num_lights > 0) {
+        float dx = 1.0f / d->num_lights;
+        for (uint32_t i = 1; i <= d->num_lights; ++i) out->light_cdf[i] = out->light_cdf[i - 1] + (power[i - 1] * dx);
+        float integral = out->light_cdf[d->num_lights];
+        for (uint32_t i = 1; i <= d->num_lights; ++i) out->light_cdf[i] /= integral;
+        for (uint32_t i = 0; i < d->num_lights; ++i) out->light_pick_pdf[i] = (power[i] / integral) * dx;
+    }
+
+    // ---- camera
+    const gbl_camera& c = d->camera;
+    memset(&out->camera, 0, sizeof(out->camera));
+    for (int k = 0; k < 3; ++k) out->camera.pos[k] = c.position[k];
+    for (int k = 0; k < 4; ++k) out->camera.q[k] = c.orientation[k];
+    float aspect = static_cast<float>(d->film.xres) / static_cast<float>(d->film.yres);
+    float fov = kPi * (c.fov_degrees / 180.0f);
+    float ys = 1.0f / std::tan(fov / 2.0f);
+    out->camera.proj11 = ys;
+    out->camera.proj00 = ys / aspect;
+    out->camera.inv_xres = 1.0f / static_cast<float>(d->film.xres);
+    out->camera.inv_yres = 1.0f / static_cast<float>(d->film.yres);
+
+    // ---- film + filter table
+    const gbl_film& f = d->film;
+    if (f.xres <= 0 || f.yres <= 0) {
+        *err = "film resolution must be positive";
+        return GBL_ERR_INVALID;
+    }
+    DevFilm& df = out->film;
+    memset(&df, 0, sizeof(df));
+    df.xres = f.xres;
+    df.yres = f.yres;
+    df.xstart = ceil_i(f.xres * f.crop[0]);
+    df.xcount = std::max(1, ceil_i(f.xres * f.crop[1]) - df.xstart);
+    df.ystart = ceil_i(f.yres * f.crop[2]);
+    df.ycount = std::max(1, ceil_i(f.yres * f.crop[3]) - df.ystart);
+    df.wx = f.filter_width[0];
+    df.wy = f.filter_width[1];
+    df.window[0] = floor_i(df.xstart + 0.5f - df.wx);
+    df.window[1] = floor_i(df.xstart + 0.5f + df.xcount + df.wx);
+    df.window[2] = floor_i(df.ystart + 0.5f - df.wy);
+    df.window[3] = floor_i(df.ystart + 0.5f + df.ycount + df.wy);
+    df.halo = ceil_i(std::max(df.wx, df.wy) + 0.5f);
+    if (!(df.wx > 0.0f) || !(df.wy > 0.0f) || df.halo > GBL_MAX_FILTER_HALO) {
+        *err = "filter width must be in (0, " + std::to_string(GBL_MAX_FILTER_HALO - 0.5f) + "] pixels";
+        return GBL_ERR_UNSUPPORTED;
+    }
+    Filter flt;
+    flt.type = f.filter_type;
+    flt.wx = df.wx; flt.wy = df.wy;
+    flt.alpha = f.gaussian_falloff;
+    flt.ex = expf(-flt.alpha * flt.wx * flt.wx);
+    flt.ey = expf(-flt.alpha * flt.wy * flt.wy);
+    flt.b = f.mitchell_b; flt.c = f.mitchell_c;
+    float norm = flt.norm();
+    float dxs = flt.wx / 16, dys = flt.wy / 16;
+    for (int y = 0; y < 16; ++y)
+        for (int x = 0; x < 16; ++x) out->filter_table[16 * y + x] = flt.eval(x * dxs, y * dys) / norm;
+    return GBL_OK;
+}
