@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s of the HIP path tracer on BASELINE.json configs[1]
+(bunny.json, 512x512 film, 256 spp, max_ray_depth 8) on N MI355X GPUs.
+
+    python bench.py                      # 1 GPU, 5 steps, 1 warmup
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over the workload with the scene already
+resident in HBM: zero the film, trace every camera path of the sample window
+(516x516 pixels x 256 spp = 68,161,536 paths), splat, and -- for N > 1 -- sum the
+film over the ranks with one RCCL all-reduce.  Rank 0 prints ONE JSON line.
+
+Multi-GPU work split (goblin_amd/distributed.py):
+  --scaling weak   (default) every rank traces the whole window with its own sample
+                   set (seed + rank); the reduced film holds N x 256 spp.  Per-GPU
+                   work is fixed as N grows.
+  --scaling strong rank r traces every N-th 8x8 sample tile of the one 256-spp frame.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(st):
+    """per ray 32 B per child box tested + 48 B per triangle tested + 48 B
+    (32 B ray in, 16 B hit out); per path 4 B per sample dimension consumed + 16 B per
+    film pixel update."""
+    rays = st["extension_rays"] + st["shadow_rays"]
+    return 32 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["splats"]
+
+
+def cpu_baseline(workload_overrides, spp_sample, cores):
+    """Time the CPU path on a bounded sample of the same workload (same scene, film,
+    filter and depth; fewer samples per pixel).  Prefers the REAL reference built into
+    oracle/_ref (kind "reference"); falls back to the oracle port."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from goblin_amd import scene as gs
+    ov = json.loads(json.dumps(workload_overrides))
+    ov.setdefault("render_setting", {})["sample_per_pixel"] = spp_sample
+    harness = os.path.join(REPO, "oracle", "_ref", "ref_harness")
+    sample = "bunny.json 512x512, %d spp (of 256), max_ray_depth 8, %d threads" % (spp_sample, cores)
+    out = None
+    if os.path.exists(harness):
+        try:
+            src = gs.scene_path("bunny")
+            with open(src) as f:
+                doc = json.load(f)
+            gs._merge(doc, ov)
+            doc["render_setting"]["thread_num"] = cores
+            for g in doc.get("geometries", []):
+                if "file" in g:
+                    g["file"] = os.path.join(os.path.dirname(src), g["file"])
+            with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as tf:
+                json.dump(doc, tf)
+            try:
+                res = json.loads(subprocess.check_output([harness, "time", tf.name, str(cores)], timeout=600).decode())
+            finally:
+                os.unlink(tf.name)
+            out = {"value": round(res["mpaths_per_s"], 4), "unit": "Mpaths/s", "cores": cores, "kind": "reference",
+                   "sample": sample + ", %d paths in %.2f s (oracle/_ref/ref_harness = /root/reference/src compiled as-is)"
+                   % (res["paths"], res["seconds"])}
+        except Exception as e:  # the prebuilt binary may be absent or unusable on this box
+            print("cpu_baseline: reference harness failed (%s); using the oracle port" % e, file=sys.stderr)
+    try:
+        import oracle_binding as ob
+        scene = gs.load_scene("bunny", ov)
+        oracle = ob.Oracle(scene)
+        res = oracle.render(threads=cores, ref_faithful=1)
+        port = scene.num_paths() / res["seconds"] * 1e-6
+        if out is None:
+            out = {"value": round(port, 4), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+                   "sample": sample + ", %d paths in %.2f s (oracle port incl. the reference's redundant traversals)"
+                   % (scene.num_paths(), res["seconds"])}
+        else:
+            out["port_value"] = round(port, 4)
+    except Exception as e:
+        print("cpu_baseline: oracle port failed: %s" % e, file=sys.stderr)
+    return out
+
+
+def l2_vs_cpu(tracer, workload_overrides, spp_sample, cores, seed):
+    """Per-pixel L2 of the normalised film against the CPU oracle on identical samples
+    (native sampler, same seed), at the bounded spp."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_binding as ob
+    from goblin_amd import _abi
+    scene = tracer.scene
+    s = _abi.gbl_render_setting.from_buffer_copy(scene.desc.setting)
+    s.sample_per_pixel = spp_sample
+    oracle = ob.Oracle(scene)
+    cpu = oracle.render(setting=s, threads=cores, sampler=1, seed=seed)["film"]
+    gpu = tracer.render(setting=s, seed=seed)["film"].numpy()
+    a, b = ob.normalize_film(gpu).astype(np.float64), ob.normalize_film(cpu).astype(np.float64)
+    return {"rel_l2": float(np.linalg.norm(a - b) / np.linalg.norm(b)),
+            "rmse": float(np.sqrt(np.mean((a - b) ** 2))),
+            "sample": "512x512 film, %d spp, identical counter-based samples on both sides" % spp_sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--resolution", type=int, nargs=2, default=[512, 512])
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / l2 legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from goblin_amd import distributed as gd
+    from goblin_amd import scene as gs
+    from goblin_amd.renderer import HipPathTracer
+
+    rank, local_rank, world = gd.init()
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
+                  % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+
+    overrides = gs.config_overrides(resolution=tuple(args.resolution), spp=args.spp, depth=args.depth)
+    scene = gs.load_scene("bunny", overrides)
+    tracer = HipPathTracer(scene, local_rank)
+    film = tracer.new_film()
+    base_seed = 20261003
+    part = gd.shard_for(rank, world, "samples" if args.scaling == "weak" else "tiles", base_seed)
+
+    # counters for the roofline (one instrumented launch, outside the timed region;
+    # the sampler is counter-based so every timed launch does exactly this work)
+    counted = tracer.render(film=film, seed=part["seed"], shard=part["shard"], stats=True)["stats"]
+    my_paths = counted["paths"]
+
+    def step(ev=None):
+        film.zero_()
+        if ev is not None:
+            ev[0].record()
+        tracer.render(film=film, seed=part["seed"], shard=part["shard"])
+        if ev is not None:
+            ev[1].record()
+        if world > 1:
+            gd.allreduce_film(film.accum)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    gd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    gd.barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=tracer.device)
+    paths = torch.tensor([float(my_paths)], dtype=torch.float64, device=tracer.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(paths, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    job_paths = float(paths.item())   # paths all ranks traced in one step
+
+    if rank == 0:
+        kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in events)
+        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = algorithmic_bytes(counted)
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath) and args.spp == 256 and args.resolution == [512, 512] and args.depth == 8 and world == 1:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        rays = counted["extension_rays"] + counted["shadow_rays"]
+        value = job_paths * args.steps / elapsed * 1e-6
+        line = {
+            "metric": "Mpaths/sec at 512x512x256spp (GoblinPathtracer hot path, bunny.json, max_ray_depth 8)",
+            "value": round(value, 3),
+            "unit": "Mpaths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "bunny.json %dx%d film (%dx%d sampled px), %d spp, max_ray_depth %d, gaussian r=2, glass "
+                            "stand-in bunny (69120 tris) + spot light" % (
+                                args.resolution[0], args.resolution[1], tracer.window[1] - tracer.window[0],
+                                tracer.window[3] - tracer.window[2], scene.spp(), args.depth),
+                "paths_per_step": int(job_paths),
+                "rays_per_path": round(rays / max(1, my_paths), 3),
+                "mrays_per_s": round(value * rays / max(1, my_paths), 2),
+                "sampler": "native counter-based, reference stratification law",
+                "sharding": {"weak": "whole window per rank, seed+rank, RCCL film all-reduce",
+                             "strong": "8x8 tiles interleaved over ranks, RCCL film all-reduce"}[args.scaling]
+                if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "kernel": "path_trace_kernel<false,false>",
+                "kernel_ms_avg": round(avg_kernel_ms, 3),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "counters": {k: int(v) for k, v in counted.items() if k != "kernel_ms"},
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            cores = max(1, min(16, len(os.sched_getaffinity(0))))
+            line["cpu_baseline"] = cpu_baseline(overrides, 16, cores)
+            try:
+                line["l2_vs_cpu"] = l2_vs_cpu(tracer, overrides, 16, cores, base_seed)
+            except Exception as e:
+                print("l2_vs_cpu failed: %s" % e, file=sys.stderr)
+            if line["cpu_baseline"]:
+                line["config"]["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

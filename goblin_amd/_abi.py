@@ -84,6 +84,7 @@ class gbl_scene_desc(C.Structure):
 class gbl_render_params(C.Structure):
     _fields_ = [("integrator", C.c_uint32), ("sample_per_pixel", C.c_int32), ("max_ray_depth", C.c_int32),
                 ("ao_sample_num", C.c_int32), ("bssrdf_sample_num", C.c_int32), ("window", C.c_int32 * 4),
+                ("tile_shard_index", C.c_int32), ("tile_shard_count", C.c_int32),
                 ("sample_mode", C.c_uint32), ("seed", C.c_uint64), ("replay_samples", C.c_void_p),
                 ("li_out", C.c_void_p), ("russian_roulette", C.c_uint32), ("collect_stats", C.c_uint32),
                 ("stream", C.c_void_p)]
@@ -150,6 +151,10 @@ def hip_lib():
         if not os.path.exists(path):
             raise ImportError("%s is missing: the device integrator has no CPU fallback. Build it with "
                               "`python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        # PyTorch-ROCm ships its own libamdhip64; film buffers and streams come from
+        # torch, so the integrator must bind to THAT runtime, not to a second copy
+        # from /opt/rocm.  Importing torch first makes the loader reuse it (same soname).
+        import torch  # noqa: F401
         lib = C.CDLL(path)
         lib.gbl_create.argtypes = [C.POINTER(gbl_scene_desc), C.c_int, C.POINTER(C.c_void_p)]
         lib.gbl_render.argtypes = [C.c_void_p, C.POINTER(gbl_render_params), C.c_void_p, C.POINTER(gbl_stats)]

@@ -129,6 +129,8 @@ struct RenderArgs {
     int32_t off2_base;          // float offset of the first 2D pattern in a record
     int32_t window[4];          // sub-window being rendered x0 x1 y0 y1
     int32_t tiles_x, tiles_y;
+    int32_t shard_index, shard_count;   // this launch owns tiles t with t % count == index
+    int32_t local_tiles;        // number of tiles this launch owns
     int32_t chunks;             // each tile's spp split in `chunks` work items
     int32_t chunk_spp;
     uint32_t seed_key;

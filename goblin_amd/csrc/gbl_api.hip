@@ -246,10 +246,23 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     }
     ra.tiles_x = (ra.window[1] - ra.window[0] + GBL_TILE - 1) / GBL_TILE;
     ra.tiles_y = (ra.window[3] - ra.window[2] + GBL_TILE - 1) / GBL_TILE;
-    // Work granularity: split each tile's samples so that an item is ~4096 paths
-    // (64 px x 64 samples) and there are many more items than resident workgroups.
+    ra.shard_count = std::max(1, p->tile_shard_count);
+    ra.shard_index = p->tile_shard_count > 1 ? p->tile_shard_index : 0;
+    if (ra.shard_index < 0 || ra.shard_index >= ra.shard_count) {
+        ctx->error = "tile_shard_index out of range";
+        return GBL_ERR_INVALID;
+    }
+    int total_tiles = ra.tiles_x * ra.tiles_y;
+    ra.local_tiles = total_tiles > ra.shard_index ? (total_tiles - ra.shard_index + ra.shard_count - 1) / ra.shard_count : 0;
+    // Work granularity: a work item is one tile x one chunk of its samples.  Start
+    // at <= 64 samples per item (4096 paths) and keep halving while the launch
+    // would have fewer than ~16 items per resident workgroup (tail effect),
+    // down to 4 samples (256 paths) per item.
     int chunks = 1;
     while (ra.spp / chunks > 64 && ra.spp % (chunks * 2) == 0) chunks *= 2;
+    const uint64_t want_items = 16ull * ctx->num_cus * 4;
+    while (static_cast<uint64_t>(ra.local_tiles) * chunks < want_items && ra.spp / chunks > 4 && ra.spp % (chunks * 2) == 0)
+        chunks *= 2;
     ra.chunks = chunks;
     ra.chunk_spp = ra.spp / chunks;
     ra.seed_key = host_mix(static_cast<uint32_t>(p->seed), static_cast<uint32_t>(p->seed >> 32));
@@ -259,7 +272,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     ra.film = film_accum;
     ra.work_counter = ctx->work_counter;
     ra.stats = ctx->stats;
-    uint64_t n_items = static_cast<uint64_t>(ra.tiles_x) * ra.tiles_y * ra.chunks;
+    uint64_t n_items = static_cast<uint64_t>(ra.local_tiles) * ra.chunks;
     if (n_items == 0) {
         if (stats) memset(stats, 0, sizeof(*stats));
         return GBL_OK;
@@ -304,7 +317,14 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         memset(stats, 0, sizeof(*stats));
         stats->kernel_ms = ms;
-        stats->paths = npix * ra.spp;
+        uint64_t shard_pixels = 0;
+        for (int t = ra.shard_index; t < total_tiles; t += ra.shard_count) {
+            int tx = t % ra.tiles_x, ty = t / ra.tiles_x;
+            int tw = std::min(GBL_TILE, ra.window[1] - (ra.window[0] + GBL_TILE * tx));
+            int th = std::min(GBL_TILE, ra.window[3] - (ra.window[2] + GBL_TILE * ty));
+            shard_pixels += static_cast<uint64_t>(tw) * th;
+        }
+        stats->paths = shard_pixels * ra.spp;
         if (want_stats) {
             unsigned long long h[8];
             HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));

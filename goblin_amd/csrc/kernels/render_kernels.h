@@ -29,7 +29,7 @@ struct ItemInfo {
 
 __device__ __forceinline__ ItemInfo decode_item(const RenderArgs& ra, uint32_t item) {
     ItemInfo it;
-    uint32_t tile = item / ra.chunks, chunk = item % ra.chunks;
+    uint32_t tile = ra.shard_index + (item / ra.chunks) * ra.shard_count, chunk = item % ra.chunks;
     int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
     it.px0 = ra.window[0] + GBL_TILE * tx;
     it.py0 = ra.window[2] + GBL_TILE * ty;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void path_trace_kernel(DevScene sc, Rend
 
     LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     uint32_t paths_done = 0;
-    const uint32_t n_items = static_cast<uint32_t>(ra.tiles_x) * ra.tiles_y * ra.chunks;
+    const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];
     const int full_w = sc.film.window[1] - sc.film.window[0];
 
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
 
     LaneCounters cnt = {0, 0, 0, 0, 0, 0};
     uint32_t paths_done = 0;
-    const uint32_t n_items = static_cast<uint32_t>(ra.tiles_x) * ra.tiles_y * ra.chunks;
+    const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];
     const int full_w = sc.film.window[1] - sc.film.window[0];
 

@@ -74,7 +74,7 @@ class HipPathTracer:
     def new_film(self):
         return Film(self.info.xres, self.info.yres, self.device)
 
-    def _params(self, setting=None, window=None, seed=0, replay=None, li_out=None, stats=False, rr=False):
+    def _params(self, setting=None, window=None, seed=0, replay=None, li_out=None, stats=False, rr=False, shard=None):
         s = setting or self.scene.desc.setting
         p = _abi.gbl_render_params()
         p.integrator = s.integrator
@@ -85,6 +85,8 @@ class HipPathTracer:
         w = window or (0, 0, 0, 0)
         for i in range(4):
             p.window[i] = int(w[i])
+        if shard is not None:
+            p.tile_shard_index, p.tile_shard_count = int(shard[0]), int(shard[1])
         p.sample_mode = _abi.GBL_SAMPLES_REPLAY if replay is not None else _abi.GBL_SAMPLES_NATIVE
         p.seed = int(seed)
         p.replay_samples = replay.data_ptr() if replay is not None else None
@@ -96,11 +98,12 @@ class HipPathTracer:
         return p
 
     def render(self, film=None, setting=None, window=None, seed=0, replay_samples=None, want_li=False, stats=False,
-               timed=False, rr=False):
+               timed=False, rr=False, shard=None):
         """Accumulate one pass into ``film`` (created if None).
 
         replay_samples: (n, dims) float32 tensor/array of Sample records for the
         window, pixel-major (GBL_SAMPLES_REPLAY); otherwise the native sampler.
+        shard: (index, count) renders only every count-th 8x8 sample tile (multi-GPU).
         Returns dict(film=..., li=..., stats=...).
         """
         torch = _torch()
@@ -119,7 +122,7 @@ class HipPathTracer:
             if tuple(replay.shape) != (npaths, dims):
                 raise ValueError("replay_samples must have shape (%d, %d), got %s" % (npaths, dims, tuple(replay.shape)))
         li = torch.zeros((npaths, 4), dtype=torch.float32, device=self.device) if want_li else None
-        p = self._params(s, window, seed, replay, li, stats, rr)
+        p = self._params(s, window, seed, replay, li, stats, rr, shard)
         st_out = _abi.gbl_stats() if (stats or timed) else None
         st = self.lib.gbl_render(self.handle, C.byref(p), film.accum.data_ptr(), C.byref(st_out) if st_out else None)
         if st != _abi.GBL_OK:

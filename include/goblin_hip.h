@@ -238,6 +238,12 @@ typedef struct gbl_render_params {
     /* sub-window of the sample window to render, half-open pixel coords; the
      * multi-GPU shard unit.  {0,0,0,0} = the whole Film::getSampleRange. */
     int32_t window[4];        /* x0, x1, y0, y1 */
+    /* Interleaved tile sharding inside the window: this call renders only the
+     * 8x8-pixel sample tiles t (row-major over the window) with
+     * t % tile_shard_count == tile_shard_index.  count <= 1 renders every tile.
+     * One GPU per shard + gbl_film_allreduce reproduces the whole film. */
+    int32_t tile_shard_index;
+    int32_t tile_shard_count;
     uint32_t sample_mode;     /* gbl_sample_mode                              */
     uint64_t seed;            /* native mode                                  */
     const float* replay_samples; /* device pointer, replay mode               */
