@@ -1,0 +1,95 @@
+"""The C ABI: every function include/goblin_hip.h declares is exported by the library
+that implements it, the ctypes mirror has the C layout, and the device library refuses
+to work without a GPU instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from goblin_amd import _abi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "goblin_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gbl_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    host = [n for n in names if n.startswith("gbl_host_")]
+    hip = [n for n in names if not n.startswith("gbl_host_")]
+    assert sorted(host) == sorted(_abi.HOST_SYMBOLS)
+    assert sorted(hip) == sorted(_abi.HIP_SYMBOLS)
+    hl = _abi.host_lib()
+    for n in host:
+        assert hasattr(hl, n), n
+    dl = _abi.hip_lib()          # dlopen only; no compute without a GPU
+    for n in hip:
+        assert hasattr(dl, n), n
+    assert dl.gbl_abi_version() == _abi.GBL_ABI_VERSION
+
+
+def test_ctypes_mirror_has_the_c_layout(tmp_path):
+    structs = ["gbl_trs", "gbl_mesh", "gbl_material", "gbl_instance", "gbl_light", "gbl_camera", "gbl_film",
+               "gbl_render_setting", "gbl_scene_desc", "gbl_render_params", "gbl_stats", "gbl_info"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "goblin_hip.h"\nint main(void){\n' +
+                   "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (s, s) for s in structs) +
+                   'printf("off_film %zu\\n", offsetof(gbl_scene_desc, film));\n'
+                   'printf("off_seed %zu\\n", offsetof(gbl_render_params, seed));\nreturn 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])   # plain C
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for s in structs:
+        assert C.sizeof(getattr(_abi, s)) == int(out[s]), s
+    assert _abi.gbl_scene_desc.film.offset == int(out["off_film"])
+    assert _abi.gbl_render_params.seed.offset == int(out["off_seed"])
+
+
+def test_device_library_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    from goblin_amd import scene as gs
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(16, 16), spp=1, depth=2))
+    with pytest.raises(RuntimeError):
+        HipPathTracer(scene, 0)
+    h = C.c_void_p()
+    st = _abi.hip_lib().gbl_create(scene.desc_ptr, 0, C.byref(h))
+    assert st == _abi.GBL_ERR_DEVICE and not h
+    assert b"no CPU fallback" in _abi.hip_lib().gbl_last_error(None)
+
+
+def test_bad_descriptions_are_rejected_before_touching_the_device():
+    from goblin_amd import scene as gs
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(16, 16), spp=1, depth=2))
+    desc = _abi.gbl_scene_desc.from_buffer_copy(scene.desc)
+    desc.abi_version = 99
+    h = C.c_void_p()
+    assert _abi.hip_lib().gbl_create(C.byref(desc), 0, C.byref(h)) == _abi.GBL_ERR_INVALID
+    desc = _abi.gbl_scene_desc.from_buffer_copy(scene.desc)
+    desc.film.filter_width[0] = 9.0     # LDS film tile halo limit
+    assert _abi.hip_lib().gbl_create(C.byref(desc), 0, C.byref(h)) == _abi.GBL_ERR_UNSUPPORTED
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(REPO, "goblin_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                for needle in ("oracle_binding", "liboracle", "orc_", "oracle/"):
+                    if needle in text:
+                        # comments that merely point at the oracle's restated definition are fine; code use is not
+                        for line in text.splitlines():
+                            if needle in line:
+                                stripped = line.strip()
+                                assert stripped.startswith(("//", "#", "*", '"""')) or "oracle/goblin_oracle.cpp" in line, (f, line)

@@ -1,0 +1,95 @@
+"""N > 1 path on CPU: two gloo ranks shard the sample window exactly as the GPU
+ranks do (goblin_amd/distributed.py), each accumulates its own full-size film,
+one all-reduce(sum) rebuilds the whole film.  The per-rank compute here is the
+oracle (this is a test of sharding + reduction, which have no GPU dependency)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from goblin_amd import distributed as gd
+from goblin_amd import scene as gs
+
+OV = gs.config_overrides(resolution=(40, 24), spp=4, depth=4)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, mode, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import oracle_binding as ob
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    r, lr, w = gd.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    scene = gs.load_scene("bunny", OV)
+    oracle = ob.Oracle(scene)
+    part = gd.shard_for(rank, world, mode, base_seed=100)
+    film = np.zeros((scene.desc.film.yres, scene.desc.film.xres, 4), np.float32)
+    if part["shard"] is None:
+        windows = [oracle.window()]
+    else:
+        windows = gd.tiles_of(oracle.window(), *part["shard"])
+    paths = 0
+    for win in windows:
+        samples = oracle.native_samples(part["seed"], window=win)
+        li, _ = oracle.li_replay(samples)
+        oracle.splat(samples, li, film)
+        paths += samples.shape[0]
+    t = torch.from_numpy(film)
+    gd.allreduce_film(t)
+    total = torch.tensor([float(paths)], dtype=torch.float64)
+    dist.all_reduce(total)
+    gd.barrier()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "film_%s.npy" % mode), t.numpy())
+        np.save(os.path.join(out_dir, "paths_%s.npy" % mode), total.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["tiles", "samples"])
+def test_two_ranks_rebuild_the_film(tmp_path, mode):
+    import oracle_binding as ob
+    world = 2
+    mp.spawn(_rank_main, args=(world, free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    film = np.load(tmp_path / ("film_%s.npy" % mode))
+    paths = float(np.load(tmp_path / ("paths_%s.npy" % mode))[0])
+    scene = gs.load_scene("bunny", OV)
+    oracle = ob.Oracle(scene)
+
+    def whole(seed):
+        s = oracle.native_samples(seed)
+        li, _ = oracle.li_replay(s)
+        return oracle.splat(s, li)
+
+    if mode == "tiles":      # fixed job: the shards partition one frame
+        assert paths == scene.num_paths()
+        np.testing.assert_allclose(film, whole(100), rtol=2e-5, atol=1e-6)
+    else:                    # fixed work per rank: rank r contributes the sample set seeded 100 + r
+        assert paths == 2 * scene.num_paths()
+        np.testing.assert_allclose(film, whole(100) + whole(101), rtol=2e-5, atol=1e-6)
+
+
+def test_tile_shards_partition_the_window():
+    win = (-2, 43, -2, 27)   # ragged: 45 x 29 pixels
+    for world in (1, 2, 3, 8):
+        seen = np.zeros((29, 45), np.int32)
+        for r in range(world):
+            for (x0, x1, y0, y1) in gd.tiles_of(win, r, world):
+                assert 0 < x1 - x0 <= 8 and 0 < y1 - y0 <= 8
+                seen[y0 + 2:y1 + 2, x0 + 2:x1 + 2] += 1
+        assert (seen == 1).all()
+    assert gd.shard_for(3, 8, "tiles", 7) == {"shard": (3, 8), "seed": 7}
+    assert gd.shard_for(3, 8, "samples", 7) == {"shard": None, "seed": 10}
+    assert gd.shard_for(0, 1, "tiles", 7) == {"shard": None, "seed": 7}

@@ -137,6 +137,20 @@ def test_window_sharding_equals_whole_render(torch):
     np.testing.assert_allclose(film.numpy(), whole, rtol=2e-5, atol=1e-6)
 
 
+def test_interleaved_tile_shards_sum_to_whole(torch):
+    """The multi-GPU split: tile_shard_index/count partitions the 8x8 sample tiles."""
+    scene = gs.load_scene("grid", gs.config_overrides(resolution=(72, 56), spp=4, depth=4))
+    r = make_renderer(scene)
+    whole = r.render(seed=9, stats=True)
+    film = r.new_film()
+    paths = 0
+    for rank in range(3):
+        out = r.render(film=film, seed=9, shard=(rank, 3), stats=True)
+        paths += out["stats"]["paths"]
+    assert paths == whole["stats"]["paths"] == scene.num_paths()
+    np.testing.assert_allclose(film.numpy(), whole["film"].numpy(), rtol=2e-5, atol=1e-6)
+
+
 def test_stats_and_determinism(torch):
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(64, 64), spp=16, depth=6))
     r = make_renderer(scene)

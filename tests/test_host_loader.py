@@ -1,0 +1,202 @@
+"""libgoblin_host.so: same keys, defaults, strictness and error behaviour as the
+reference's ContextLoader / ParamSet / PolygonMesh loader for the hot-path subset
+(/root/reference/src/GoblinContextLoader.cpp, GoblinParamSet.cpp, GoblinPolygonMesh.cpp)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from goblin_amd import _abi
+from goblin_amd import scene as gs
+
+MODELS = os.path.join(gs.SCENE_DIR)
+
+
+def load(doc):
+    return gs.load_scene_text(json.dumps(doc), MODELS)
+
+
+def minimal(**extra):
+    doc = {
+        "camera": {"position": [0, 1, -4], "fov": 50.0},
+        "geometries": [{"name": "q", "type": "mesh", "file": "models/plane.obj"}],
+        "textures": [{"name": "w", "type": "constant", "color": [0.5, 0.6, 0.7]}],
+        "materials": [{"name": "m", "type": "lambert", "Kd": "w"}],
+        "primitives": [{"type": "model", "name": "mq", "geometry": "q", "material": "m"},
+                       {"type": "instance", "name": "i0", "model": "mq"}],
+        "lights": [{"type": "point", "name": "p", "intensity": [1, 2, 3], "position": [0, 3, 0]}],
+    }
+    doc.update(extra)
+    return doc
+
+
+def test_defaults_match_the_reference():
+    s = load(minimal())
+    d = s.desc
+    assert d.setting.integrator == _abi.GBL_INTEGRATOR_PATH          # unknown/absent render_method -> path tracing
+    assert (d.setting.sample_per_pixel, d.setting.max_ray_depth, d.setting.bssrdf_sample_num, d.setting.ao_sample_num) == (1, 5, 4, 25)
+    assert (d.film.xres, d.film.yres) == (512, 512) and list(d.film.crop) == [0, 1, 0, 1]
+    assert d.film.filter_type == _abi.GBL_FILTER_GAUSSIAN and list(d.film.filter_width) == [1, 1] and d.film.gaussian_falloff == 2.0
+    assert d.camera.fov_degrees == 50.0 and d.camera.near_plane == np.float32(0.1) and d.camera.far_plane == 1000.0
+    assert list(d.camera.orientation) == [1, 0, 0, 0] and d.camera.lens_radius == 0.0 and d.camera.focal_distance == 1.0
+    inst = d.instances[0]
+    assert list(inst.to_world.scale) == [1, 1, 1] and list(inst.to_world.position) == [0, 0, 0] and inst.area_light == -1
+    assert d.lights[0].type == _abi.GBL_LIGHT_POINT and list(d.lights[0].color) == [1, 2, 3]
+    assert s.sample_window() == (-1, 513, -1, 513)                     # gaussian width 1: film padded by the radius
+
+
+def test_integer_literals_are_invisible_to_float_params():
+    """ParamSet is strictly typed: `"fov": 45` is an int and getFloat("fov") keeps its default (GoblinContextLoader.cpp:40-45)."""
+    s = load(minimal(camera={"position": [0, 1, -4], "fov": 45, "filter": {"type": "gaussian", "width": [2, 2], "falloff": 3}}))
+    assert s.desc.camera.fov_degrees == 60.0
+    assert s.desc.film.gaussian_falloff == 2.0 and list(s.desc.film.filter_width) == [2, 2]   # arrays DO take ints
+    s = load(minimal(render_setting={"sample_per_pixel": 16.0, "max_ray_depth": 0}))
+    assert s.desc.setting.sample_per_pixel == 1                        # float literal invisible to getInt
+    assert s.desc.setting.max_ray_depth == 1                           # max(1, ...)
+
+
+def test_render_methods():
+    s = load(minimal(render_setting={"render_method": "ao"}))          # keep the Scene alive: desc points into it
+    assert s.desc.setting.integrator == _abi.GBL_INTEGRATOR_AO
+    s = load(minimal(render_setting={"render_method": "no such thing"}))
+    assert s.desc.setting.integrator == _abi.GBL_INTEGRATOR_PATH
+    for m in ("sppm", "bdpt", "whitted", "light_tracing"):
+        with pytest.raises(_abi.GoblinError) as e:
+            load(minimal(render_setting={"render_method": m}))
+        assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+    with pytest.raises(_abi.GoblinError) as e:   # the shipped reference example selects sppm
+        gs.load_scene_text(json.dumps({"render_setting": {"render_method": "sppm"}}), ".")
+    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+
+
+def test_out_of_scope_features_fail_loudly():
+    cases = [
+        minimal(volume={"type": "homogeneous"}),
+        minimal(camera={"type": "orthographic"}),
+        minimal(camera={"lens_radius": 0.1}),
+        minimal(lights=[{"type": "ibl", "name": "e", "file": "x.exr"}]),
+        minimal(lights=[{"type": "directional", "name": "d", "radiance": [1, 1, 1], "direction": [0, -1, 0]}]),
+        minimal(materials=[{"name": "m", "type": "subsurface"}]),
+        minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
+        minimal(textures=[{"name": "w", "type": "checkerboard"}]),
+        minimal(geometries=[{"name": "q", "type": "sphere", "radius": 1.0}]),
+    ]
+    for doc in cases:
+        with pytest.raises(_abi.GoblinError) as e:
+            load(doc)
+        assert e.value.status == _abi.GBL_ERR_UNSUPPORTED, doc
+
+
+def test_unused_out_of_scope_declarations_are_ignored():
+    """bunny.json declares a sphere geometry nothing uses (examples/bunny.json:36-40)."""
+    doc = minimal()
+    doc["geometries"].append({"name": "ball", "type": "sphere", "radius": 0.05})
+    doc["materials"].append({"name": "sss", "type": "subsurface"})
+    s = load(doc)
+    assert s.desc.num_instances == 1
+
+
+def test_missing_names_and_files():
+    for doc, code in [
+        (minimal(materials=[{"name": "m", "type": "lambert", "Kd": "nope"}]), _abi.GBL_ERR_INVALID),
+        (minimal(primitives=[{"type": "instance", "name": "i", "model": "nope"}]), _abi.GBL_ERR_INVALID),
+        (minimal(geometries=[{"name": "q", "type": "mesh", "file": "models/missing.obj"}]), _abi.GBL_ERR_IO),
+    ]:
+        with pytest.raises(_abi.GoblinError) as e:
+            load(doc)
+        assert e.value.status == code
+    with pytest.raises(_abi.GoblinError) as e:
+        gs.load_scene_text("{ not json", ".")
+    assert e.value.status == _abi.GBL_ERR_IO
+    with pytest.raises(_abi.GoblinError):
+        _abi.host_lib()   # make sure the lib is loaded for the next line
+        import ctypes as C
+        h = C.c_void_p()
+        st = _abi.host_lib().gbl_host_load_file(b"/no/such/scene.json", C.byref(h))
+        raise _abi.GoblinError(st, _abi.host_lib().gbl_host_last_error().decode())
+
+
+def test_first_definition_of_a_name_wins_and_only_instances_render():
+    """SceneCache::add* use map::insert; models and instances share one name map (bunny.json names both 'bunny')."""
+    doc = minimal()
+    doc["textures"].append({"name": "w", "type": "constant", "color": [9, 9, 9]})
+    doc["primitives"] = [{"type": "model", "name": "x", "geometry": "q", "material": "m"},
+                         {"type": "instance", "name": "x", "model": "x", "position": [1, 2, 3]},
+                         {"type": "whatever", "name": "y", "geometry": "q", "material": "m"}]   # unknown type -> model
+    s = load(doc)
+    assert s.desc.num_instances == 1 and list(s.desc.instances[0].to_world.position) == [1, 2, 3]
+    assert list(s.desc.materials[s.desc.instances[0].material].color) == pytest.approx([0.5, 0.6, 0.7])
+
+
+def test_area_light_auto_instances_an_emissive_black_model():
+    doc = minimal(lights=[{"type": "area", "name": "L", "geometry": "q", "radiance": [5, 4, 3], "position": [0, 2, 0],
+                           "orientation": [0, 1, 0, 0], "scale": [0.5, 0.5, 0.5]}])
+    s = load(doc)
+    d = s.desc
+    assert d.num_instances == 2 and d.num_lights == 1
+    emissive = d.instances[1]                       # appended after the scene's own instances
+    assert emissive.area_light == 0 and list(d.materials[emissive.material].color) == [0, 0, 0]
+    assert list(emissive.to_world.scale) == [0.5, 0.5, 0.5] and list(d.lights[0].to_world.orientation) == [0, 1, 0, 0]
+
+
+def test_spot_light_target_and_cosines():
+    doc = minimal(lights=[{"type": "spot", "name": "s", "intensity": [1, 1, 1], "position": [0, 4, 0], "target": [0, 0, 3],
+                           "theta_max": 30.0, "falloff_start": 20.0}])
+    s = load(doc)
+    l = s.desc.lights[0]
+    assert l.type == _abi.GBL_LIGHT_SPOT
+    np.testing.assert_allclose(list(l.direction), [0, -0.8, 0.6], rtol=1e-6)
+    np.testing.assert_allclose([l.cos_theta_max, l.cos_falloff_start], np.cos(np.radians([30.0, 20.0])), rtol=1e-6)
+
+
+def test_euler_orientation():
+    doc = minimal()
+    doc["primitives"][1].update({"euler": [0.0, 90.0, 0.0]})
+    s = load(doc)
+    q = list(s.desc.instances[0].to_world.orientation)
+    np.testing.assert_allclose(q, [np.cos(np.pi / 4), 0, np.sin(np.pi / 4), 0], atol=1e-6)
+
+
+def test_obj_loader(tmp_path):
+    """v/vn/vt/f, quads split (0,1,2)+(0,2,3), negative indices, (v,vn,vt) de-duplication, format from the first face."""
+    (tmp_path / "a.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf -4//1 -3//1 -2//1 -1//1\n")
+    (tmp_path / "b.obj").write_text("# tri soup\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/1 2/2 3/3\nf 3/3 2/2 4/1\n")
+    doc = minimal(geometries=[{"name": "q", "type": "mesh", "file": str(tmp_path / "a.obj")},
+                              {"name": "r", "type": "mesh", "file": str(tmp_path / "b.obj")}])
+    doc["primitives"] += [{"type": "model", "name": "mr", "geometry": "r", "material": "m"},
+                          {"type": "instance", "name": "i1", "model": "mr"}]
+    s = load(doc)
+    d = s.desc
+    a, b = d.meshes[0], d.meshes[1]
+    assert (a.vertex_count, a.tri_count, a.has_normal, a.has_uv) == (4, 2, 1, 0)
+    assert list(d.indices[0:6]) == [0, 1, 2, 0, 2, 3]
+    assert (b.vertex_count, b.tri_count, b.has_normal, b.has_uv) == (4, 2, 0, 1)    # (v4, vt1) is a new vertex
+    assert list(d.indices[6:12]) == [0, 1, 2, 2, 1, 3]
+    np.testing.assert_array_equal(np.ctypeslib.as_array(d.normals, (12,))[:3], [0, 0, 1])
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
+    with pytest.raises(_abi.GoblinError):
+        load(minimal(geometries=[{"name": "q", "type": "mesh", "file": str(tmp_path / "bad.obj")}]))
+
+
+def test_sample_bookkeeping_helpers():
+    s = gs.load_scene("bunny", gs.config_overrides(resolution=(512, 512), spp=250, depth=8))
+    assert s.spp() == 256 and s.sample_window() == (-2, 514, -2, 514)
+    assert s.num_paths() == 516 * 516 * 256 == 68161536
+    assert s.sample_dimension() == 92                                   # 4 + 7*8 + 32
+    s = gs.load_scene("bunny", gs.config_overrides(resolution=(256, 256), spp=16, depth=4))
+    assert s.sample_dimension() == 64 and s.num_paths() == 1081600
+    s = gs.load_scene("bunny", gs.config_overrides(spp=4, method="ao", ao_samples=25))
+    assert s.sample_dimension() == 4 + 50
+
+
+def test_film_normalize_and_pfm(tmp_path):
+    import ctypes as C
+    acc = np.array([[[2, 4, 6, 2], [1, 1, 1, 4]]], np.float32)
+    rgb = np.zeros((1, 2, 3), np.float32)
+    _abi.host_lib().gbl_host_film_normalize(acc.ctypes.data_as(C.c_void_p), 2, 1, rgb.ctypes.data_as(C.c_void_p))
+    np.testing.assert_array_equal(rgb, [[[1, 2, 3], [0.25, 0.25, 0.25]]])
+    p = str(tmp_path / "x.pfm")
+    assert _abi.host_lib().gbl_host_write_pfm(p.encode(), rgb.ctypes.data_as(C.c_void_p), 2, 1) == 0
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"PF\n2 1\n-1.0\n") and len(raw) == len(b"PF\n2 1\n-1.0\n") + 24
