@@ -56,8 +56,18 @@ def build_hip(force=False, extra_flags=()):
     return out
 
 
+def build_cli(force=False):
+    """g_ray_hip: the stand-alone `g_ray scene.json` equivalent, linked against both libraries."""
+    out = os.path.join(LIB, "g_ray_hip")
+    src = os.path.join(CSRC, "host", "g_ray_hip.cpp")
+    if force or _stale(out, [src, os.path.join(REPO, "include", "goblin_hip.h")]):
+        _run([HIPCC, "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", src, "-o", out, "-L" + LIB, "-lgoblin_hip",
+              "-lgoblin_host", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_all(force=False):
-    return build_host(force), build_hip(force)
+    return build_host(force), build_hip(force), build_cli(force)
 
 
 if __name__ == "__main__":

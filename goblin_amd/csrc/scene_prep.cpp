@@ -362,6 +362,23 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
                 *err = "mesh " + std::to_string(i) + " has a vertex index out of range";
                 return GBL_ERR_INVALID;
             }
+        if (m.has_uv) {
+            // A triangle whose uv determinant is 0 makes the reference build its tangent from
+            // whatever Fragment the caller passed in (GoblinTriangle.cpp:113-117): not reproducible.
+            const float* uv = d->uvs + 2 * static_cast<size_t>(m.vertex_offset);
+            const uint32_t* I = d->indices + 3 * static_cast<size_t>(m.tri_offset);
+            for (uint32_t t = 0; t < m.tri_count; ++t) {
+                const float* a = uv + 2 * I[3 * t];
+                const float* b = uv + 2 * I[3 * t + 1];
+                const float* c = uv + 2 * I[3 * t + 2];
+                float du1 = b[0] - a[0], dv1 = b[1] - a[1], du2 = c[0] - a[0], dv2 = c[1] - a[1];
+                if (du1 * dv2 - dv1 * du2 == 0.0f) {
+                    *err = "mesh " + std::to_string(i) + " triangle " + std::to_string(t) +
+                           " has degenerate texture coordinates (stale-fragment branch of the reference)";
+                    return GBL_ERR_UNSUPPORTED;
+                }
+            }
+        }
     }
 
     // ---- vertex attributes used at shading time
