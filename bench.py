@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / l2 legs")
+    ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel"], default="auto")
     args = ap.parse_args()
 
     import torch
@@ -145,14 +146,14 @@ def main():
 
     # counters for the roofline (one instrumented launch, outside the timed region;
     # the sampler is counter-based so every timed launch does exactly this work)
-    counted = tracer.render(film=film, seed=part["seed"], shard=part["shard"], stats=True)["stats"]
+    counted = tracer.render(film=film, seed=part["seed"], shard=part["shard"], stats=True, schedule=args.schedule)["stats"]
     my_paths = counted["paths"]
 
     def step(ev=None):
         film.zero_()
         if ev is not None:
             ev[0].record()
-        tracer.render(film=film, seed=part["seed"], shard=part["shard"])
+        tracer.render(film=film, seed=part["seed"], shard=part["shard"], schedule=args.schedule)
         if ev is not None:
             ev[1].record()
         if world > 1:

@@ -20,6 +20,7 @@ GBL_LIGHT_POINT, GBL_LIGHT_SPOT, GBL_LIGHT_AREA = 0, 2, 3
 GBL_FILTER_BOX, GBL_FILTER_TRIANGLE, GBL_FILTER_GAUSSIAN, GBL_FILTER_MITCHELL = range(4)
 GBL_INTEGRATOR_PATH, GBL_INTEGRATOR_AO = 0, 1
 GBL_SAMPLES_NATIVE, GBL_SAMPLES_REPLAY = 0, 1
+GBL_SCHEDULE_AUTO, GBL_SCHEDULE_MEGAKERNEL, GBL_SCHEDULE_WAVEFRONT = 0, 1, 2
 
 
 class GoblinError(RuntimeError):
@@ -87,7 +88,7 @@ class gbl_render_params(C.Structure):
                 ("tile_shard_index", C.c_int32), ("tile_shard_count", C.c_int32),
                 ("sample_mode", C.c_uint32), ("seed", C.c_uint64), ("replay_samples", C.c_void_p),
                 ("li_out", C.c_void_p), ("russian_roulette", C.c_uint32), ("collect_stats", C.c_uint32),
-                ("stream", C.c_void_p)]
+                ("schedule", C.c_uint32), ("stream", C.c_void_p)]
 
 
 class gbl_stats(C.Structure):
@@ -147,7 +148,7 @@ def hip_lib():
     library is missing the device path fails here, loudly."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "libgoblin_hip.so")
+        path = os.environ.get("GOBLIN_HIP_LIB") or os.path.join(LIB_DIR, "libgoblin_hip.so")
         if not os.path.exists(path):
             raise ImportError("%s is missing: the device integrator has no CPU fallback. Build it with "
                               "`python -c 'import __graft_entry__ as g; g.build()'`" % path)

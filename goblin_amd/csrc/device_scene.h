@@ -16,6 +16,9 @@
 #define GBL_BLOCK 256           // threads per workgroup (4 waves of 64)
 #define GBL_MAX_LEAF_TRIS 4
 #define GBL_STACK_SENTINEL 0x7fffffff
+#ifndef GBL_PT_WAVES
+#define GBL_PT_WAVES 1
+#endif
 #define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
 
 // child reference: >= 0 interior node index; < 0 leaf: ~ref = (first << 2) | (count - 1)

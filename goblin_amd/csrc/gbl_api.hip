@@ -17,6 +17,7 @@
 #include "../../include/goblin_hip.h"
 #include "device_scene.h"
 #include "kernels/render_kernels.h"
+#include "kernels/wavefront.h"
 #include "scene_prep.h"
 
 namespace {
@@ -35,6 +36,12 @@ struct gbl_ctx {
     int num_cus = 256;
     void* rccl = nullptr;
     void* rccl_allreduce = nullptr;
+    // wavefront pool (allocated on first use)
+    uint32_t wf_pool = 0;
+    WfArgs wf;
+    float4* wf_li = nullptr;
+    size_t wf_li_entries = 0;
+    uint32_t* wf_host_flags = nullptr;   // pinned
 };
 
 namespace {
@@ -79,6 +86,149 @@ uint32_t host_mix(uint32_t a, uint32_t b) {   // same integer hash as kernels/sa
     h *= 0x846CA68Bu;
     h ^= h >> 16;
     return h;
+}
+
+
+// ---------------------------------------------------------------------------
+// Wavefront schedule: host side of kernels/wavefront.h
+// ---------------------------------------------------------------------------
+template <class T>
+gbl_status wf_alloc(gbl_ctx* ctx, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->error = std::string("hipMalloc(wavefront pool): ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? GBL_ERR_OOM : GBL_ERR_DEVICE;
+    }
+    ctx->allocations.push_back(p);
+    *out = static_cast<T*>(p);
+    return GBL_OK;
+}
+
+gbl_status wf_ensure_pool(gbl_ctx* ctx) {
+    if (ctx->wf_pool) return GBL_OK;
+    const uint32_t pool = 1u << 21;   // 2 Mi path slots (~190 B each)
+    WfArgs& w = ctx->wf;
+    memset(&w, 0, sizeof(w));
+    gbl_status st;
+#define WF_A(field, n) if ((st = wf_alloc(ctx, &w.field, (n))) != GBL_OK) return st
+    WF_A(ray_o, pool); WF_A(ray_d, pool); WF_A(hit, pool); WF_A(hit_inst, pool);
+    WF_A(s_thr, pool); WF_A(s_li, pool); WF_A(s_ld, pool); WF_A(s_f, pool); WF_A(s_id, pool); WF_A(s_pixel, pool);
+    WF_A(ext_q, pool); WF_A(ext_count, pool / 64);
+    WF_A(sh_o, pool); WF_A(sh_d, pool); WF_A(sh_c, pool); WF_A(sh_count, pool / 64);
+    WF_A(live_flags, 8);
+    WF_A(wave_next, pool / 64);
+#undef WF_A
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_flags), 8 * sizeof(uint32_t)) != hipSuccess) {
+        ctx->error = "hipHostMalloc(wavefront flags) failed";
+        return GBL_ERR_OOM;
+    }
+    ctx->wf_pool = pool;
+    return GBL_OK;
+}
+
+gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render_params* p, hipStream_t stream, bool want_stats,
+                            bool replay) {
+    (void)p;
+    const DevScene& sc = ctx->scene;
+    gbl_status st = wf_ensure_pool(ctx);
+    if (st != GBL_OK) return st;
+    const uint64_t window_pixels = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * (ra.window[3] - ra.window[2]);
+    // samples per pass: bound the per-sample radiance buffer (16 B per sample) to ~2 GiB
+    int pass_spp = ra.spp;
+    if (!ra.li_out) {
+        const uint64_t budget = (2ull << 30) / 16;
+        while (window_pixels * pass_spp > budget && pass_spp % 2 == 0 && pass_spp > 1) pass_spp /= 2;
+    }
+    if (static_cast<uint64_t>(ra.local_tiles) * 64 * pass_spp >= (1ull << 32) || window_pixels * pass_spp >= (1ull << 32)) {
+        ctx->error = "too many paths per pass for 32-bit path ids: split the window";
+        return GBL_ERR_INVALID;
+    }
+    WfArgs wa = ctx->wf;
+    if (ra.li_out) {
+        wa.li_buf = reinterpret_cast<float4*>(ra.li_out);   // single pass: li_buf is the caller's buffer, in its order
+    } else {
+        size_t need = static_cast<size_t>(window_pixels) * pass_spp;
+        if (need > ctx->wf_li_entries) {
+            if (ctx->wf_li) (void)hipFree(ctx->wf_li);
+            ctx->wf_li = nullptr;
+            ctx->wf_li_entries = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->wf_li), need * sizeof(float4));
+            if (e != hipSuccess) {
+                ctx->error = std::string("hipMalloc(per-sample radiance): ") + hipGetErrorString(e);
+                return GBL_ERR_OOM;
+            }
+            ctx->wf_li_entries = need;
+        }
+        wa.li_buf = ctx->wf_li;
+    }
+    const uint32_t total = static_cast<uint32_t>(static_cast<uint64_t>(ra.local_tiles) * 64 * pass_spp);
+    uint32_t pool = std::min<uint32_t>(ctx->wf_pool, (total + GBL_BLOCK - 1) / GBL_BLOCK * GBL_BLOCK);
+    wa.pool_size = pool;
+    wa.total_paths = total;
+    wa.pass_spp = pass_spp;
+    {   // ids are dealt in blocks of 64, round-robin over the pool/64 shade-waves
+        const uint32_t waves = pool / 64, blocks = (total + 63) / 64;
+        wa.paths_per_wave = ((blocks + waves - 1) / waves) * 64;
+    }
+    const size_t lds_stack = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+    const int tp = GBL_TILE + 2 * sc.film.halo;
+    const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
+    auto k_ext = want_stats ? wf_trace<false, true> : wf_trace<false, false>;
+    auto k_shd = want_stats ? wf_trace<true, true> : wf_trace<true, false>;
+    // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
+    // workgroup that has to wait for a free CU would serialise its share), never more waves than regions
+    int occ_ext = 0, occ_shd = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ext, reinterpret_cast<const void*>(k_ext), GBL_BLOCK, lds_stack) != hipSuccess || occ_ext < 1) occ_ext = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_shd, reinterpret_cast<const void*>(k_shd), GBL_BLOCK, lds_stack) != hipSuccess || occ_shd < 1) occ_shd = 1;
+    const uint64_t max_wgs = (pool / 64 + 3) / 4;
+    unsigned ext_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_ext, max_wgs)));
+    unsigned shd_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_shd, max_wgs)));
+    dim3 block(GBL_BLOCK), grid_ext(ext_wgs), grid_shd(shd_wgs), grid_shade(pool / GBL_BLOCK);
+    auto k_shade = replay ? (want_stats ? wf_shade<true, true> : wf_shade<true, false>)
+                          : (want_stats ? wf_shade<false, true> : wf_shade<false, false>);
+    auto k_splat = replay ? (want_stats ? wf_splat<true, true> : wf_splat<true, false>)
+                          : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
+    if (lds_stack > 64 * 1024) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ext), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds_stack)));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_shd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds_stack)));
+    }
+    for (int k0 = 0; k0 < ra.spp; k0 += pass_spp) {
+        wa.pass_k0 = k0;
+        HIP_TRY(ctx, hipMemsetAsync(wa.wave_next, 0, (pool / 64) * sizeof(uint32_t), stream));
+        wa.init = 1;
+        wa.flag_index = 7;
+        hipLaunchKernelGGL(k_shade, grid_shade, block, 0, stream, sc, ra, wa);
+        wa.init = 0;
+        // slot s traces ceil((total - s) / pool) paths, each at least one iteration
+        uint64_t iter = 0, min_iters = total / pool;
+        bool done = false;
+        while (!done) {
+            HIP_TRY(ctx, hipMemsetAsync(wa.live_flags, 0, 8 * sizeof(uint32_t), stream));
+            int batch = iter + 4 <= min_iters ? static_cast<int>(std::min<uint64_t>(min_iters - iter, 64)) : 4;
+            for (int b = 0; b < batch; ++b) {
+                wa.flag_index = b & 7;
+                hipLaunchKernelGGL(k_ext, grid_ext, block, lds_stack, stream, sc, ra, wa);
+                hipLaunchKernelGGL(k_shade, grid_shade, block, 0, stream, sc, ra, wa);
+                hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, stream, sc, ra, wa);
+                ++iter;
+            }
+            if (iter >= min_iters) {
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->wf_host_flags, wa.live_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(ctx, hipStreamSynchronize(stream));
+                if (ctx->wf_host_flags[(batch - 1) & 7] == 0) done = true;
+            }
+            if (iter > (1u << 20)) {
+                ctx->error = "wavefront loop did not terminate";
+                return GBL_ERR_DEVICE;
+            }
+        }
+        hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), block, lds_tile, stream, sc, ra, wa);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return GBL_OK;
 }
 
 }  // namespace
@@ -177,6 +327,8 @@ void gbl_destroy(gbl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (void* p : ctx->allocations) (void)hipFree(p);
+    if (ctx->wf_li) (void)hipFree(ctx->wf_li);
+    if (ctx->wf_host_flags) (void)hipHostFree(ctx->wf_host_flags);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->rccl) dlclose(ctx->rccl);
@@ -290,26 +442,38 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ctx->error = "scene needs " + std::to_string(lds) + " bytes of LDS per workgroup (BVH too deep)";
         return GBL_ERR_UNSUPPORTED;
     }
-    // persistent grid: enough workgroups to fill every CU at the occupancy LDS allows, never more than items
-    int per_cu = static_cast<int>(std::min<size_t>(4, (160 * 1024) / lds));
-    per_cu = std::max(1, per_cu);
-    uint64_t grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * per_cu);
-    dim3 grid(static_cast<unsigned>(grid64)), block(GBL_BLOCK);
     const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY;
-    void (*kernel)(DevScene, RenderArgs) = nullptr;
-    if (p->integrator == GBL_INTEGRATOR_PATH) {
-        kernel = replay ? (want_stats ? path_trace_kernel<true, true> : path_trace_kernel<true, false>)
-                        : (want_stats ? path_trace_kernel<false, true> : path_trace_kernel<false, false>);
-    } else {
-        kernel = replay ? (want_stats ? ao_kernel<true, true> : ao_kernel<true, false>)
-                        : (want_stats ? ao_kernel<false, true> : ao_kernel<false, false>);
+    // schedule: the wavefront formulation for path tracing (unless the caller asks for the
+    // megakernel or uses the Russian-roulette extension); AO runs the persistent megakernel.
+    bool wavefront = p->integrator == GBL_INTEGRATOR_PATH && p->schedule != GBL_SCHEDULE_MEGAKERNEL && !p->russian_roulette;
+    if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
+        ctx->error = "the wavefront schedule covers the path tracer without Russian roulette";
+        return GBL_ERR_UNSUPPORTED;
     }
-    if (lds > 64 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)));
+    int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));
+    per_cu = std::max(1, per_cu);
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
-    HIP_TRY(ctx, hipGetLastError());
+    if (wavefront) {
+        gbl_status wst = render_wavefront(ctx, ra, p, stream, want_stats, replay);
+        if (wst != GBL_OK) return wst;
+    } else {
+        // persistent grid: enough workgroups to fill every CU at the occupancy LDS allows, never more than items
+        uint64_t grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * per_cu);
+        dim3 grid(static_cast<unsigned>(grid64)), block(GBL_BLOCK);
+        void (*kernel)(DevScene, RenderArgs) = nullptr;
+        if (p->integrator == GBL_INTEGRATOR_PATH) {
+            kernel = replay ? (want_stats ? path_trace_kernel<true, true> : path_trace_kernel<true, false>)
+                            : (want_stats ? path_trace_kernel<false, true> : path_trace_kernel<false, false>);
+        } else {
+            kernel = replay ? (want_stats ? ao_kernel<true, true> : ao_kernel<true, false>)
+                            : (want_stats ? ao_kernel<false, true> : ao_kernel<false, false>);
+        }
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds)));
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));

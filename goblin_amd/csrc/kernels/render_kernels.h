@@ -144,7 +144,7 @@ struct PathState {
 };
 
 template <bool REPLAY, bool STATS>
-__global__ __launch_bounds__(GBL_BLOCK) void path_trace_kernel(DevScene sc, RenderArgs ra) {
+__global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);

@@ -1,0 +1,652 @@
+// Wavefront formulation of the same integrator.  Paths live in a pool of P slots in
+// HBM; one iteration runs three kernels:
+//
+//   wf_trace<false>  extension rays : persistent waves; each wave owns a strided set of
+//                                     64-entry queue regions and refills its idle lanes
+//                                     from them while the busy lanes keep traversing
+//   wf_shade         lane == slot   : closes the previous bounce (MIS, Li, throughput),
+//                                     terminates + regenerates, samples light and BSDF,
+//                                     emits the shadow ray and the next extension ray
+//   wf_trace<true>   shadow rays    : any-hit; adds the deferred contribution to Ld
+//
+// and a final wf_splat per pass that filters the per-sample radiance into the film
+// through the LDS tile.  The arithmetic is the megakernel's (same shade.h / trace.h
+// device functions, same operation order): both schedules give the same per-sample
+// radiance bit for bit, and tests run both.
+//
+// There is NOT ONE same-address global atomic on the timed path (a returning atomic on
+// a single word saturates near 88 per microsecond on this chip, which throttled the
+// first version of this file): queues are compacted per wave with __ballot + prefix
+// popcount into that wave's own 64-entry region, consumers are assigned regions
+// statically, and slot s traces the paths s, s+P, s+2P, ... of the pass.
+#pragma once
+#include "../device_scene.h"
+#include "render_kernels.h"
+#include "sampler.h"
+#include "shade.h"
+#include "trace.h"
+#include "vecmath.h"
+
+#define WF_BOUNCE_EMPTY (-2)   // slot needs a new path
+#define WF_BOUNCE_DEAD (-3)    // slot has traced all its paths of this pass
+
+struct WfArgs {
+    // pool (one entry per slot)
+    float4* ray_o;      // o.xyz, mint
+    float4* ray_d;      // d.xyz, -
+    float4* hit;        // t, b1, b2, as_float(tri)
+    int32_t* hit_inst;  // -1: miss
+    float4* s_thr;      // throughput.xyz, cosw
+    float4* s_li;       // Li.xyz, fw
+    float4* s_ld;       // Ld.xyz, bsdf_pdf
+    float4* s_f;        // f.xyz, pick_pdf
+    uint4* s_id;        // (light | (bounce + 4) << 16, out_index, k, -)
+    uint32_t* s_pixel;  // pixel key of the native sampler
+    // per-wave queue regions: region w covers entries [64 w, 64 w + count[w])
+    uint32_t* ext_q;      // slot ids
+    uint32_t* ext_count;
+    float4* sh_o;         // o.xyz, mint
+    float4* sh_d;         // d.xyz, maxt
+    float4* sh_c;         // contrib.xyz, as_float(slot)
+    uint32_t* sh_count;
+    uint32_t* wave_next;  // per shade-wave cursor into that wave's contiguous list of path ids (no atomics:
+                          // only the owning wave ever touches its word)
+    uint32_t paths_per_wave;
+    uint32_t* live_flags; // [8]: set by wf_shade when any of its slots is still alive
+    float4* li_buf;       // per-sample radiance of the pass, pixel-major: pixel * pass_spp + kk
+    uint32_t pool_size;   // P, multiple of 256
+    uint32_t total_paths; // path ids in this pass: local_tiles * 64 * pass_spp
+    int32_t pass_k0, pass_spp;
+    int32_t init;         // first wf_shade of a pass: every slot is empty
+    int32_t flag_index;
+};
+
+__device__ __forceinline__ void wf_stats(unsigned long long* stats, const LaneCounters& c, uint32_t paths) {
+    unsigned long long v[7] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims};
+    for (int i = 0; i < 7; ++i) {
+        unsigned long long x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(stats + i, x);
+    }
+}
+
+// path id of a pass -> pixel / sample.  ids enumerate (owned tile, pixel in tile, sample in pass):
+// consecutive ids are samples of one pixel, so a freshly generated wave traces coherent primaries.
+struct PathId {
+    int px, py;
+    uint32_t k;          // sample index within the pixel (absolute)
+    uint32_t li_index;   // index into li_buf
+    bool valid;
+};
+__device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs& wa, uint32_t id) {
+    PathId p;
+    uint32_t per_tile = 64u * static_cast<uint32_t>(wa.pass_spp);
+    uint32_t lt = id / per_tile, r = id % per_tile;
+    uint32_t pix = r / wa.pass_spp, kk = r % wa.pass_spp;
+    uint32_t tile = ra.shard_index + lt * ra.shard_count;
+    int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
+    p.px = ra.window[0] + GBL_TILE * tx + static_cast<int>(pix % 8u);
+    p.py = ra.window[2] + GBL_TILE * ty + static_cast<int>(pix / 8u);
+    p.k = static_cast<uint32_t>(wa.pass_k0) + kk;
+    // pixel-major over the render window (the C ABI's li_out order when the pass is the whole render)
+    const int sub_w = ra.window[1] - ra.window[0];
+    p.li_index = static_cast<uint32_t>((p.py - ra.window[2]) * sub_w + (p.px - ra.window[0])) * wa.pass_spp + kk;
+    p.valid = p.px < ra.window[1] && p.py < ra.window[3];
+    return p;
+}
+
+// ---------------------------------------------------------------------------
+// wf_trace: persistent traversal with in-wave dynamic fetch.
+// ---------------------------------------------------------------------------
+#define WF_REFILL 16   // refill as soon as this many lanes of the wave are idle
+
+template <bool ANY, bool STATS>
+__global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_regions = wa.pool_size / 64u;
+    const uint32_t n_waves = gridDim.x * (GBL_BLOCK / 64);
+    // this wave's regions: w, w + n_waves, w + 2 n_waves, ...
+    uint32_t region = blockIdx.x * (GBL_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t* counts = ANY ? wa.sh_count : wa.ext_count;
+    uint32_t r_off = 0, r_cnt = region < n_regions ? counts[region] : 0u;
+
+    bool busy = false;
+    RaySpace world, r;
+    float mint = 0.0f, maxt = 0.0f;
+    int sp = 0, cur = 0, inst = -1;
+    uint32_t slot = 0;
+    Hit hit;
+    hit.t = INFINITY; hit.inst = -1; hit.tri = 0; hit.b1 = hit.b2 = 0.0f;
+    F3 contrib = f3(0, 0, 0);
+    bool occluded = false;
+    const DevNode* __restrict__ nodes = sc.nodes;
+
+    for (;;) {
+        // ---- refill idle lanes from this wave's regions (all scalar bookkeeping)
+        unsigned long long idle = __ballot(!busy);
+        int n_idle = __popcll(idle);
+        if (region < n_regions && n_idle >= WF_REFILL) {
+            int my_rank = __popcll(idle & ((1ull << lane) - 1ull));
+            int assigned = 0;
+            uint32_t my_entry = 0xffffffffu;
+            while (assigned < n_idle && region < n_regions) {
+                int avail = static_cast<int>(r_cnt - r_off);
+                int take = min(avail, n_idle - assigned);
+                if (!busy && my_rank >= assigned && my_rank < assigned + take)
+                    my_entry = region * 64u + r_off + static_cast<uint32_t>(my_rank - assigned);
+                assigned += take;
+                r_off += take;
+                if (r_off >= r_cnt) {
+                    region += n_waves;
+                    r_off = 0;
+                    r_cnt = region < n_regions ? counts[region] : 0u;
+                }
+            }
+            if (my_entry != 0xffffffffu) {
+                float4 a, b;
+                if (ANY) {
+                    a = wa.sh_o[my_entry];
+                    b = wa.sh_d[my_entry];
+                    float4 c = wa.sh_c[my_entry];
+                    contrib = f3(c.x, c.y, c.z);
+                    slot = __float_as_uint(c.w);
+                    maxt = b.w;
+                } else {
+                    slot = wa.ext_q[my_entry];
+                    a = wa.ray_o[slot];
+                    b = wa.ray_d[slot];
+                    maxt = INFINITY;
+                }
+                mint = a.w;
+                ray_space(world, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z));
+                r = world;
+                sp = 0;
+                stk[(sp++) * GBL_BLOCK] = GBL_STACK_EXIT;
+                cur = sc.num_instances > 0 ? sc.tlas_root : GBL_STACK_EXIT;
+                inst = -1;
+                hit.t = INFINITY;
+                hit.inst = -1;
+                occluded = false;
+                busy = true;
+                if (STATS) {
+                    if (ANY) cnt.shadow += 1; else cnt.ext += 1;
+                }
+            }
+        }
+        const bool drained = region >= n_regions;
+        if (__ballot(busy) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+        // ---- traverse while enough lanes are busy (or nothing is left to fetch)
+        const int keep = drained ? 1 : (64 - WF_REFILL + 1);
+        while (__popcll(__ballot(busy)) >= keep) {
+            if (busy) {
+                while (static_cast<uint32_t>(cur) < static_cast<uint32_t>(GBL_STACK_EXIT)) {
+                    const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+                    const float4 n0 = np[0];
+                    const float4 n1 = np[1];
+                    const float4 nz = np[2];
+                    const int2 ch = *reinterpret_cast<const int2*>(np + 3);
+                    float ax0 = __builtin_fmaf(n0.x, r.idir.x, -r.ood.x), ax1 = __builtin_fmaf(n0.y, r.idir.x, -r.ood.x);
+                    float ay0 = __builtin_fmaf(n0.z, r.idir.y, -r.ood.y), ay1 = __builtin_fmaf(n0.w, r.idir.y, -r.ood.y);
+                    float az0 = __builtin_fmaf(nz.x, r.idir.z, -r.ood.z), az1 = __builtin_fmaf(nz.y, r.idir.z, -r.ood.z);
+                    float bx0 = __builtin_fmaf(n1.x, r.idir.x, -r.ood.x), bx1 = __builtin_fmaf(n1.y, r.idir.x, -r.ood.x);
+                    float by0 = __builtin_fmaf(n1.z, r.idir.y, -r.ood.y), by1 = __builtin_fmaf(n1.w, r.idir.y, -r.ood.y);
+                    float bz0 = __builtin_fmaf(nz.z, r.idir.z, -r.ood.z), bz1 = __builtin_fmaf(nz.w, r.idir.z, -r.ood.z);
+                    float a_lo = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), mint));
+                    float a_hi = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), maxt));
+                    float b_lo = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), mint));
+                    float b_hi = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), maxt));
+                    bool ha = a_lo <= a_hi, hb = b_lo <= b_hi;
+                    if (STATS) cnt.nodes += 2;
+                    if (ha && hb) {
+                        bool a_first = a_lo <= b_lo;
+                        stk[(sp++) * GBL_BLOCK] = static_cast<uint32_t>(a_first ? ch.y : ch.x);
+                        cur = a_first ? ch.x : ch.y;
+                    } else if (ha) {
+                        cur = ch.x;
+                    } else if (hb) {
+                        cur = ch.y;
+                    } else {
+                        cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
+                    }
+                }
+                bool done = false;
+                if (cur == GBL_STACK_EXIT) {
+                    done = true;
+                } else if (cur == GBL_STACK_SENTINEL) {
+                    r = world;
+                    inst = -1;
+                    cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
+                } else {
+                    uint32_t ref = ~static_cast<uint32_t>(cur);
+                    if (inst < 0) {
+                        inst = static_cast<int>(ref >> 2);
+                        const DevInstance* ip = sc.instances + inst;
+                        ray_space(r, xf_point(ip->inv, world.o), xf_vector(ip->inv, world.d));
+                        stk[(sp++) * GBL_BLOCK] = GBL_STACK_SENTINEL;
+                        cur = ip->root;
+                    } else {
+                        uint32_t first = ref >> 2, n = (ref & 3u) + 1u;
+                        for (uint32_t i = 0; i < n; ++i) {
+                            float t, b1, b2;
+                            if (STATS) cnt.tris += 1;
+                            if (tri_test(sc.tris + first + i, r.o, r.d, mint, maxt, &t, &b1, &b2)) {
+                                if (ANY) {
+                                    occluded = true;
+                                    done = true;
+                                    break;
+                                }
+                                maxt = t;
+                                hit.t = t;
+                                hit.inst = inst;
+                                hit.tri = first + i;
+                                hit.b1 = b1;
+                                hit.b2 = b2;
+                            }
+                        }
+                        if (!done) cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
+                    }
+                }
+                if (done) {
+                    if (ANY) {
+                        if (!occluded) {
+                            float4 ld = wa.s_ld[slot];   // one shadow ray per slot per iteration: plain read-modify-write
+                            ld.x += contrib.x;
+                            ld.y += contrib.y;
+                            ld.z += contrib.z;
+                            wa.s_ld[slot] = ld;
+                        }
+                    } else {
+                        wa.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.tri));
+                        wa.hit_inst[slot] = hit.inst;
+                    }
+                    busy = false;
+                }
+            }
+        }
+    }
+    if (STATS) wf_stats(ra.stats, cnt, 0);
+}
+
+// ---------------------------------------------------------------------------
+// wf_shade: lane == slot.
+// ---------------------------------------------------------------------------
+template <bool REPLAY, bool STATS>
+__global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra, WfArgs wa) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;   // grid covers the pool exactly
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_gid = slot >> 6;
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    uint32_t paths_done = 0;
+    PathState ps;
+    ps.bounce = WF_BOUNCE_EMPTY;
+    ps.light = 0;
+    ps.path = 0;
+    uint32_t out_index = 0, k = 0, pixel_key = 0;
+    if (!wa.init) {
+        uint4 id = wa.s_id[slot];
+        ps.light = static_cast<int>(id.x & 0xffffu);
+        ps.bounce = static_cast<int>(id.x >> 16) - 4;
+        out_index = id.y;
+        k = id.z;
+    }
+    const bool alive = ps.bounce >= -1;
+    bool finished = false;
+    Hit hit;
+    hit.inst = -1;
+    bool got = false;
+    Frag fr;
+    if (alive) {
+        float4 o = wa.ray_o[slot], d = wa.ray_d[slot];
+        float4 h = wa.hit[slot];
+        float4 a = wa.s_thr[slot], b = wa.s_li[slot], c = wa.s_ld[slot], e = wa.s_f[slot];
+        ps.o = f3(o.x, o.y, o.z); ps.mint = o.w;
+        ps.d = f3(d.x, d.y, d.z);
+        ps.throughput = f3(a.x, a.y, a.z); ps.cosw = a.w;
+        ps.Li = f3(b.x, b.y, b.z); ps.fw = b.w;
+        ps.Ld = f3(c.x, c.y, c.z); ps.bsdf_pdf = c.w;
+        ps.f = f3(e.x, e.y, e.z); ps.pick_pdf = e.w;
+        pixel_key = wa.s_pixel[slot];
+        hit.t = h.x; hit.b1 = h.y; hit.b2 = h.z; hit.tri = __float_as_uint(h.w);
+        hit.inst = wa.hit_inst[slot];
+        got = hit.inst >= 0;
+    }
+    SampleSource src;
+    src.spp = ra.spp;
+    src.root = ra.root;
+    src.rec = nullptr;
+    src.pixel_key = pixel_key;
+    src.k = k;
+    if (REPLAY && alive)   // out_index = pixel * pass_spp + kk  ->  record pixel * spp + k
+        src.rec = ra.replay + (static_cast<size_t>(out_index / wa.pass_spp) * ra.spp + k) * ra.dims;
+
+    // ---- close the bounce whose extension ray was just traced (the megakernel's code)
+    if (alive) {
+        if (sc.num_lights == 0) {
+            finished = true;
+        } else {
+            if (got) make_fragment(sc, hit, ps.o, ps.d, fr);
+            if (ps.bounce < 0) {
+                if (!got) {
+                    finished = true;
+                } else {
+                    F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                    ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                    ps.bounce = 0;
+                }
+            } else {
+                if (got && sc.instances[hit.inst].area_light == ps.light) {
+                    F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                    if (!is_black(le)) {
+                        F3 term = div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
+                        ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
+                    }
+                }
+                F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
+                ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
+                F3 scale = div(ps.f * ps.cosw, ps.bsdf_pdf);
+                ps.throughput = ps.throughput * scale;
+                ps.bounce += 1;
+                if (!got) finished = true;
+            }
+            if (!finished && ps.bounce >= ra.max_depth - 1) finished = true;
+        }
+    }
+
+    // ---- shade: light sample -> shadow entry, BSDF sample -> next ray
+    bool need_shadow = false, has_ray = false, zombie = false;
+    F3 shadow_d = f3(0, 0, 1), contrib = f3(0, 0, 0);
+    float shadow_maxt = 0.0f;
+    if (alive && !finished) {
+        const int b = ps.bounce;
+        F3 wo = -ps.d;
+        float u_light_c, u_light_1, u_light_2, u_pick, u_bsdf_c, u_bsdf_1, u_bsdf_2;
+        if (REPLAY) {
+            const float* r1 = src.rec + 4 + 3 * b;
+            const float* r2 = src.rec + ra.off2_base + 4 * b;
+            u_light_c = r1[0]; u_bsdf_c = r1[1]; u_pick = r1[2];
+            u_light_1 = r2[0]; u_light_2 = r2[1]; u_bsdf_1 = r2[2]; u_bsdf_2 = r2[3];
+        } else {
+            u_light_c = src.native_1d(3u * b + 0u);
+            u_bsdf_c = src.native_1d(3u * b + 1u);
+            u_pick = src.native_1d(3u * b + 2u);
+            src.native_2d(0x10000u + 2u * b, 1u, 0u, true, &u_light_1, &u_light_2);
+            src.native_2d(0x10000u + 2u * b + 1u, 1u, 0u, true, &u_bsdf_1, &u_bsdf_2);
+        }
+        if (STATS) cnt.dims += 7;
+        int li = 0;
+        for (int i = 1; i <= sc.num_lights; ++i)
+            if (sc.light_cdf[i] < u_pick) li = i;
+        if (li >= sc.num_lights) li = sc.num_lights - 1;
+        ps.light = li;
+        ps.pick_pdf = sc.light_pick_pdf[li];
+        ps.Ld = f3(0, 0, 0);
+        const DevMaterial* mat = sc.materials + sc.instances[hit.inst].material;
+        const DevLight& light = sc.lights[li];
+        LightSampleOut ls;
+        light_sample(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
+        if (!is_black(ls.L) && ls.pdf > 0.0f) {
+            F3 f = mat_bsdf(*mat, fr.n, wo, ls.wi);
+            if (!is_black(f)) {
+                need_shadow = true;
+                shadow_d = ls.wi;
+                shadow_maxt = ls.maxt;
+                if (light.type != GBL_LIGHT_AREA) {
+                    contrib = div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);
+                } else {
+                    float bp = mat_pdf(*mat, fr.n, wo, ls.wi);
+                    float lw = power_heuristic(ls.pdf, bp);
+                    contrib = div(f * ls.L * absdot(fr.n, ls.wi) * lw, ls.pdf);
+                }
+            }
+        }
+        F3 wi;
+        float pdf;
+        bool specular;
+        F3 f = mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
+        if (!is_black(f) && pdf > 0.0f) {
+            float fw = 1.0f;
+            if (!specular) fw = power_heuristic(pdf, light_pdf(sc, sc.lights[ps.light], fr.p, wi));
+            ps.f = f;
+            ps.fw = fw;
+            ps.bsdf_pdf = pdf;
+            ps.cosw = absdot(wi, fr.n);
+            ps.o = fr.p;
+            ps.d = wi;
+            ps.mint = fr.eps;
+            has_ray = true;
+        } else if (need_shadow) {
+            // The path ends here but its direct light is still pending on the shadow ray.  Keep the
+            // slot one more iteration as a "zombie": no extension ray is traced, the hit is preset to
+            // a miss, and f = 0 makes the next close do exactly Li += throughput * Ld / pickPdf.
+            ps.f = f3(0, 0, 0);
+            ps.fw = 0.0f;
+            ps.bsdf_pdf = 1.0f;
+            ps.cosw = 0.0f;
+            zombie = true;
+        } else {
+            // Li += throughput * Ld / pickLightPdf with Ld == 0 (no shadow ray pending); break
+            F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
+            ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
+            finished = true;
+        }
+    }
+    // ---- shadow entries: compacted into this wave's region
+    {
+        unsigned long long m = __ballot(need_shadow);
+        if (need_shadow) {
+            uint32_t pos = wave_gid * 64u + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+            wa.sh_o[pos] = make_float4(fr.p.x, fr.p.y, fr.p.z, fr.eps);
+            wa.sh_d[pos] = make_float4(shadow_d.x, shadow_d.y, shadow_d.z, shadow_maxt);
+            wa.sh_c[pos] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+        }
+        if (lane == 0) wa.sh_count[wave_gid] = static_cast<uint32_t>(__popcll(m));
+    }
+
+    // ---- termination: publish the sample's radiance, then start this slot's next path
+    if (alive && finished) {
+        wa.li_buf[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
+        paths_done += 1;
+    }
+    bool started = false, dead = ps.bounce == WF_BOUNCE_DEAD;
+    const bool want_new = (alive && finished) || ps.bounce == WF_BOUNCE_EMPTY;
+    if (alive && finished) ps.bounce = WF_BOUNCE_EMPTY;
+    {
+        // Each shade-wave owns a contiguous list of path ids and hands them to its lanes in order:
+        // ballot + prefix popcount over a cursor only this wave touches (plain load / store).
+        unsigned long long wm = __ballot(want_new);
+        if (wm != 0ull) {
+            const uint32_t cursor = wa.wave_next[wave_gid];
+            const uint32_t local = cursor + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
+            if (lane == 0) wa.wave_next[wave_gid] = cursor + static_cast<uint32_t>(__popcll(wm));
+            if (want_new) {
+                // ids are dealt to the waves in blocks of 64 (= consecutive samples of one pixel), round-robin,
+                // so every wave's list is spread over the whole image and the waves finish together
+                const uint64_t id = (static_cast<uint64_t>(local >> 6) * (wa.pool_size >> 6) + wave_gid) * 64u + (local & 63u);
+                if (local < wa.paths_per_wave && id < wa.total_paths) {
+                    PathId pid = decode_path(ra, wa, static_cast<uint32_t>(id));
+                    if (pid.valid) {   // (a pixel clipped off an edge tile leaves the slot EMPTY: it asks again next iteration)
+                        const int full_w = sc.film.window[1] - sc.film.window[0];
+                        float image_x, image_y;
+                        out_index = pid.li_index;
+                        k = pid.k;
+                        src.k = k;
+                        if (REPLAY) {
+                            src.rec = ra.replay + (static_cast<size_t>(out_index / wa.pass_spp) * ra.spp + k) * ra.dims;
+                            image_x = src.rec[0];
+                            image_y = src.rec[1];
+                        } else {
+                            uint32_t pixel = static_cast<uint32_t>((pid.py - sc.film.window[2]) * full_w + (pid.px - sc.film.window[0]));
+                            pixel_key = nat_mix(ra.seed_key, pixel);
+                            src.pixel_key = pixel_key;
+                            float u, v;
+                            src.native_2d(0u, 1u, 0u, false, &u, &v);
+                            image_x = pid.px + u;
+                            image_y = pid.py + v;
+                        }
+                        camera_ray(sc.camera, image_x, image_y, &ps.o, &ps.d);
+                        ps.mint = 1e-3f;
+                        ps.throughput = f3(1.0f, 1.0f, 1.0f);
+                        ps.Li = f3(0.0f, 0.0f, 0.0f);
+                        ps.Ld = f3(0.0f, 0.0f, 0.0f);
+                        ps.f = f3(0.0f, 0.0f, 0.0f);
+                        ps.cosw = ps.fw = 0.0f;
+                        ps.bsdf_pdf = ps.pick_pdf = 1.0f;
+                        ps.light = 0;
+                        ps.bounce = -1;
+                        started = true;
+                        has_ray = true;
+                        if (STATS) cnt.dims += 2;
+                    }
+                } else {
+                    dead = true;
+                    ps.bounce = WF_BOUNCE_DEAD;
+                }
+            }
+        }
+    }
+    // ---- write back
+    const bool keep = (alive && !finished) || started;
+    if (keep) {
+        if (has_ray) {
+            wa.ray_o[slot] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.mint);
+            wa.ray_d[slot] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f);
+        }
+        if (zombie) wa.hit_inst[slot] = -1;
+        wa.s_thr[slot] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.cosw);
+        wa.s_li[slot] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, ps.fw);
+        wa.s_ld[slot] = make_float4(ps.Ld.x, ps.Ld.y, ps.Ld.z, ps.bsdf_pdf);
+        wa.s_f[slot] = make_float4(ps.f.x, ps.f.y, ps.f.z, ps.pick_pdf);
+        wa.s_pixel[slot] = pixel_key;
+    }
+    if (keep || dead || want_new || wa.init)
+        wa.s_id[slot] = make_uint4(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16), out_index, k, 0u);
+    // ---- extension queue: compacted into this wave's region
+    {
+        bool enq = keep && has_ray;
+        unsigned long long m = __ballot(enq);
+        if (enq) wa.ext_q[wave_gid * 64u + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)))] = slot;
+        if (lane == 0) wa.ext_count[wave_gid] = static_cast<uint32_t>(__popcll(m));
+        unsigned long long any_kept = __ballot(keep || ps.bounce == WF_BOUNCE_EMPTY);   // whole wave, not under `lane == 0`
+        if (lane == 0 && any_kept != 0ull) wa.live_flags[wa.flag_index] = 1u;   // benign race: everyone stores 1
+    }
+    if (STATS) wf_stats(ra.stats, cnt, paths_done);
+}
+
+// ---------------------------------------------------------------------------
+// wf_splat: one workgroup per owned tile, one lane per PIXEL of the tile (64 lanes of a
+// wave splat 64 different footprints: no same-address LDS atomic storms); the four waves
+// split the samples.  ImageTile::addSample (GoblinFilm.cpp:61-90).
+// ---------------------------------------------------------------------------
+template <bool REPLAY, bool STATS>
+__global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra, WfArgs wa) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tp = GBL_TILE + 2 * sc.film.halo;
+    float* tile = reinterpret_cast<float*>(smem);
+    float* ftab = tile + 4 * tp * tp;
+    for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+    for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
+    __syncthreads();
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    const uint32_t lt = blockIdx.x;
+    const uint32_t tile_id = ra.shard_index + lt * ra.shard_count;
+    const int tx = tile_id % ra.tiles_x, ty = tile_id / ra.tiles_x;
+    const int px0 = ra.window[0] + GBL_TILE * tx, py0 = ra.window[2] + GBL_TILE * ty;
+    const int tx0 = px0 - sc.film.halo, ty0 = py0 - sc.film.halo;
+    const int full_w = sc.film.window[1] - sc.film.window[0];
+    const int sub_w = ra.window[1] - ra.window[0];
+    const int pix = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = px0 + (pix & 7), py = py0 + (pix >> 3);
+    // Native samples lie inside their pixel, so with a filter half-width <= 2 the footprint of every
+    // sample of pixel (px,py) is inside the 5x5 block around it: accumulate the lane's samples in
+    // registers and touch LDS once per footprint pixel instead of once per sample.
+    const bool fast5 = !REPLAY && sc.film.wx <= 2.0f && sc.film.wy <= 2.0f;
+    if (px < ra.window[1] && py < ra.window[3]) {
+        SampleSource src;
+        src.spp = ra.spp;
+        src.root = ra.root;
+        src.rec = nullptr;
+        const uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
+        src.pixel_key = nat_mix(ra.seed_key, pixel);
+        const uint32_t local_pixel = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0]));
+        if (fast5) {
+            float acc[25][4];
+#pragma unroll
+            for (int i = 0; i < 25; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
+            const int xlo = sc.film.xstart, xhi = sc.film.xstart + sc.film.xcount - 1;
+            const int ylo = sc.film.ystart, yhi = sc.film.ystart + sc.film.ycount - 1;
+            for (int kk = wave; kk < wa.pass_spp; kk += GBL_BLOCK / 64) {
+                src.k = static_cast<uint32_t>(wa.pass_k0 + kk);
+                float u, v;
+                src.native_2d(0u, 1u, 0u, false, &u, &v);
+                const float image_x = px + u, image_y = py + v;
+                const float4 L = wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk];
+                if (L.x != L.x || L.y != L.y || L.z != L.z) continue;   // NaN sample: dropped
+                const float dx = image_x - 0.5f, dy = image_y - 0.5f;
+                const int x0 = max(static_cast<int>(ceilf(dx - sc.film.wx)), xlo), x1 = min(static_cast<int>(floorf(dx + sc.film.wx)), xhi);
+                const int y0 = max(static_cast<int>(ceilf(dy - sc.film.wy)), ylo), y1 = min(static_cast<int>(floorf(dy + sc.film.wy)), yhi);
+                int ix[5], iy[5];
+#pragma unroll
+                for (int o = 0; o < 5; ++o) {
+                    const int x = px + o - 2, y = py + o - 2;
+                    ix[o] = (x >= x0 && x <= x1) ? min(static_cast<int>(floorf(fabsf(16 * (x - dx) / sc.film.wx))), 15) : -1;
+                    iy[o] = (y >= y0 && y <= y1) ? min(static_cast<int>(floorf(fabsf(16 * (y - dy) / sc.film.wy))), 15) : -1;
+                }
+#pragma unroll
+                for (int oy = 0; oy < 5; ++oy) {
+#pragma unroll
+                    for (int ox = 0; ox < 5; ++ox) {
+                        if (ix[ox] >= 0 && iy[oy] >= 0) {
+                            const float w = ftab[iy[oy] * 16 + ix[ox]];
+                            acc[oy * 5 + ox][0] += w * L.x;
+                            acc[oy * 5 + ox][1] += w * L.y;
+                            acc[oy * 5 + ox][2] += w * L.z;
+                            acc[oy * 5 + ox][3] += w;
+                            if (STATS) cnt.splats += 1;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int oy = 0; oy < 5; ++oy) {
+#pragma unroll
+                for (int ox = 0; ox < 5; ++ox) {
+                    const float* a = acc[oy * 5 + ox];
+                    if (a[3] != 0.0f || a[0] != 0.0f || a[1] != 0.0f || a[2] != 0.0f) {
+                        float* q = tile + 4 * ((py + oy - 2 - ty0) * tp + (px + ox - 2 - tx0));
+                        atomicAdd(q + 0, a[0]);
+                        atomicAdd(q + 1, a[1]);
+                        atomicAdd(q + 2, a[2]);
+                        atomicAdd(q + 3, a[3]);
+                    }
+                }
+            }
+        } else {
+            for (int kk = wave; kk < wa.pass_spp; kk += GBL_BLOCK / 64) {
+                const uint32_t k = static_cast<uint32_t>(wa.pass_k0 + kk);
+                float image_x, image_y;
+                if (REPLAY) {
+                    const float* rec = ra.replay + (static_cast<size_t>(local_pixel) * ra.spp + k) * ra.dims;
+                    image_x = rec[0];
+                    image_y = rec[1];
+                } else {
+                    src.k = k;
+                    float u, v;
+                    src.native_2d(0u, 1u, 0u, false, &u, &v);
+                    image_x = px + u;
+                    image_y = py + v;
+                }
+                float4 L = wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk];
+                splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, f3(L.x, L.y, L.z), cnt);
+            }
+        }
+    }
+    __syncthreads();
+    flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
+    if (STATS) wf_stats(ra.stats, cnt, 0);
+}

@@ -74,7 +74,8 @@ class HipPathTracer:
     def new_film(self):
         return Film(self.info.xres, self.info.yres, self.device)
 
-    def _params(self, setting=None, window=None, seed=0, replay=None, li_out=None, stats=False, rr=False, shard=None):
+    def _params(self, setting=None, window=None, seed=0, replay=None, li_out=None, stats=False, rr=False, shard=None,
+                schedule=0):
         s = setting or self.scene.desc.setting
         p = _abi.gbl_render_params()
         p.integrator = s.integrator
@@ -93,12 +94,13 @@ class HipPathTracer:
         p.li_out = li_out.data_ptr() if li_out is not None else None
         p.russian_roulette = 1 if rr else 0
         p.collect_stats = 1 if stats else 0
+        p.schedule = {"auto": 0, "megakernel": 1, "wavefront": 2}.get(schedule, schedule)
         torch = _torch()
         p.stream = torch.cuda.current_stream(self.device).cuda_stream
         return p
 
     def render(self, film=None, setting=None, window=None, seed=0, replay_samples=None, want_li=False, stats=False,
-               timed=False, rr=False, shard=None):
+               timed=False, rr=False, shard=None, schedule="auto"):
         """Accumulate one pass into ``film`` (created if None).
 
         replay_samples: (n, dims) float32 tensor/array of Sample records for the
@@ -122,7 +124,7 @@ class HipPathTracer:
             if tuple(replay.shape) != (npaths, dims):
                 raise ValueError("replay_samples must have shape (%d, %d), got %s" % (npaths, dims, tuple(replay.shape)))
         li = torch.zeros((npaths, 4), dtype=torch.float32, device=self.device) if want_li else None
-        p = self._params(s, window, seed, replay, li, stats, rr, shard)
+        p = self._params(s, window, seed, replay, li, stats, rr, shard, schedule)
         st_out = _abi.gbl_stats() if (stats or timed) else None
         st = self.lib.gbl_render(self.handle, C.byref(p), film.accum.data_ptr(), C.byref(st_out) if st_out else None)
         if st != _abi.GBL_OK:

@@ -229,6 +229,15 @@ typedef enum gbl_sample_mode {
     GBL_SAMPLES_REPLAY = 1
 } gbl_sample_mode;
 
+/* How the device schedules the same arithmetic (identical per-sample radiance):
+ *  WAVEFRONT   path pool in HBM, compacted ray queues, extend / shade / shadow kernels
+ *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration */
+typedef enum gbl_schedule {
+    GBL_SCHEDULE_AUTO = 0,
+    GBL_SCHEDULE_MEGAKERNEL = 1,
+    GBL_SCHEDULE_WAVEFRONT = 2
+} gbl_schedule;
+
 typedef struct gbl_render_params {
     uint32_t integrator;      /* gbl_integrator                               */
     int32_t sample_per_pixel; /* rounded up to a square like the reference    */
@@ -254,6 +263,7 @@ typedef struct gbl_render_params {
                                   (the reference loop is fixed length,
                                   GoblinPathtracer.cpp:76)                    */
     uint32_t collect_stats;    /* fill node/triangle counters (slower)        */
+    uint32_t schedule;         /* gbl_schedule                                */
     void* stream;              /* hipStream_t, NULL = default stream          */
 } gbl_render_params;
 

@@ -35,9 +35,30 @@ def torch():
     return torch
 
 
-def make_renderer(scene):
+@pytest.fixture(params=["wavefront", "megakernel"])
+def schedule(request):
+    """Both device schedules run the same arithmetic and must both match the reference."""
+    return request.param
+
+
+class _Scheduled:
+    """HipPathTracer whose render() defaults to one schedule (AO always runs the persistent megakernel)."""
+
+    def __init__(self, tracer, schedule):
+        self._t, self._schedule = tracer, schedule
+
+    def __getattr__(self, name):
+        return getattr(self._t, name)
+
+    def render(self, **kw):
+        s = kw.get("setting") or self._t.scene.desc.setting
+        kw.setdefault("schedule", "auto" if (s.integrator == _abi.GBL_INTEGRATOR_AO or kw.get("rr")) else self._schedule)
+        return self._t.render(**kw)
+
+
+def make_renderer(scene, schedule="auto"):
     from goblin_amd.renderer import HipPathTracer
-    return HipPathTracer(scene, 0)
+    return _Scheduled(HipPathTracer(scene, 0), schedule)
 
 
 def fake_window(full, n_pixels):
@@ -51,11 +72,11 @@ def fake_window(full, n_pixels):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box"])
-def test_li_matches_reference_records(golden, torch, case):
+def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
     scene = gs.load_scene(meta["scene"], meta["overrides"])
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     samples, li_ref = data["samples"], data["li"]
     spp = meta["spp"]
     n = (samples.shape[0] // spp) * spp
@@ -72,7 +93,7 @@ def test_li_matches_reference_records(golden, torch, case):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell"])
-def test_film_matches_reference_film(golden, torch, case):
+def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
     meta, data = golden(case)
@@ -82,7 +103,7 @@ def test_film_matches_reference_film(golden, torch, case):
     np.testing.assert_allclose(res["film"], data["film"], rtol=1e-5, atol=1e-6)   # the oracle pin itself
     idx = helpers.tile_order_index(o.window(), meta["spp"])
     samples = res["samples"][idx]
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     out = r.render(replay_samples=samples, want_li=True)
     film = out["film"].numpy()
     ref = data["film"]
@@ -101,12 +122,12 @@ def test_film_matches_reference_film(golden, torch, case):
     ("cornell", gs.config_overrides(resolution=(32, 32), spp=9, depth=6)),
     ("bunny", gs.config_overrides(resolution=(32, 32), spp=4, method="ao", ao_samples=16)),
 ])
-def test_native_sampler_matches_oracle_restatement(torch, name, ov):
+def test_native_sampler_matches_oracle_restatement(torch, schedule, name, ov):
     """The device's counter-based sampler is integer hashing: the oracle restates
     it, so native-mode radiance can be checked sample by sample."""
     scene = gs.load_scene(name, ov)
     o = ob.Oracle(scene)
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     seed = 0x1234ABCD5678
     samples = o.native_samples(seed)
     li_ref, _ = o.li_replay(samples, threads=4)
@@ -123,11 +144,11 @@ def test_native_sampler_matches_oracle_restatement(torch, name, ov):
     np.testing.assert_allclose(out2["li"].cpu().numpy(), li, rtol=1e-6, atol=1e-7)
 
 
-def test_window_sharding_equals_whole_render(torch):
+def test_window_sharding_equals_whole_render(torch, schedule):
     """Tile-sharding property the multi-GPU path relies on: rendering the sample
     window in pieces and summing the films equals rendering it whole."""
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(64, 48), spp=4, depth=4))
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     whole = r.render(seed=7)["film"].numpy()
     x0, x1, y0, y1 = r.window
     film = r.new_film()
@@ -137,10 +158,10 @@ def test_window_sharding_equals_whole_render(torch):
     np.testing.assert_allclose(film.numpy(), whole, rtol=2e-5, atol=1e-6)
 
 
-def test_interleaved_tile_shards_sum_to_whole(torch):
+def test_interleaved_tile_shards_sum_to_whole(torch, schedule):
     """The multi-GPU split: tile_shard_index/count partitions the 8x8 sample tiles."""
     scene = gs.load_scene("grid", gs.config_overrides(resolution=(72, 56), spp=4, depth=4))
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     whole = r.render(seed=9, stats=True)
     film = r.new_film()
     paths = 0
@@ -151,9 +172,9 @@ def test_interleaved_tile_shards_sum_to_whole(torch):
     np.testing.assert_allclose(film.numpy(), whole["film"].numpy(), rtol=2e-5, atol=1e-6)
 
 
-def test_stats_and_determinism(torch):
+def test_stats_and_determinism(torch, schedule):
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(64, 64), spp=16, depth=6))
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     a = r.render(seed=3, stats=True, want_li=True)
     b = r.render(seed=3, want_li=True)
     np.testing.assert_array_equal(a["li"].cpu().numpy(), b["li"].cpu().numpy())   # per-sample radiance is deterministic
@@ -168,10 +189,10 @@ def test_stats_and_determinism(torch):
     assert abs(st["shadow_rays"] - cnt["anyhit_queries"]) <= 0.002 * cnt["anyhit_queries"]
 
 
-def test_linearity_two_passes(torch):
+def test_linearity_two_passes(torch, schedule):
     """Film accumulators are sum-decomposable: two passes with different seeds add."""
     scene = gs.load_scene("cornell", gs.config_overrides(resolution=(32, 32), spp=4, depth=4))
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     f1 = r.render(seed=1)["film"].numpy()
     f2 = r.render(seed=2)["film"].numpy()
     film = r.new_film()
@@ -180,9 +201,9 @@ def test_linearity_two_passes(torch):
     np.testing.assert_allclose(film.numpy(), f1 + f2, rtol=2e-5, atol=1e-6)
 
 
-def test_error_behaviour(torch):
+def test_error_behaviour(torch, schedule):
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(16, 16), spp=1, depth=2))
-    r = make_renderer(scene)
+    r = make_renderer(scene, schedule)
     with pytest.raises(_abi.GoblinError):
         r.render(window=(-100, 5, 0, 5))
     bad = np.zeros((3, 5), np.float32)
