@@ -1,9 +1,9 @@
 // Device-resident scene layout (HBM) shared by the host packer (scene_prep.cpp)
 // and the kernels.  Everything is POD and sized/aligned for 16-byte vector loads.
 //
-//   nodes[]      64 B  BVH2 node holding BOTH children's boxes (one fetch = two
-//                      32-byte box tests).  BLAS nodes of every mesh first, then
-//                      the TLAS nodes; all child references are absolute.
+//   nodes[]      64 B  4-wide BVH node, 8-bit quantised child boxes (one fetch = four
+//                      box tests).  BLAS nodes of every mesh first, then the TLAS
+//                      nodes; all child references are absolute.
 //   tris[]       48 B  p0, e1, e2 in object space, in BLAS leaf order; e1/e2 are
 //                      the same float32 differences the reference forms per test
 //                      (GoblinTriangle.cpp:52-53) so Moller-Trumbore is bit-equal.
@@ -22,14 +22,22 @@
 #define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
 
 // child reference: >= 0 interior node index; < 0 leaf: ~ref = (first << 2) | (count - 1)
-// (TLAS leaves: first = instance id, count = 1)
+// (TLAS leaves: first = instance id, count = 1); GBL_REF_NONE marks an unused child slot.
+//
+// 4-wide BVH node with 8-bit quantised child boxes, 64 bytes = four 16-byte loads per
+// traversal step for FOUR box tests.  A child's box on axis a is
+//   [o_a + qlo[a][c] * 2^(e_a - 127),  o_a + qhi[a][c] * 2^(e_a - 127)]
+// rounded outwards, so the test is conservative: it can only add candidates, never lose
+// a triangle the exact test would accept.
 struct DevNode {
-    float c0x[2], c0y[2];   // child 0: lo.x hi.x lo.y hi.y
-    float c1x[2], c1y[2];   // child 1
-    float c0z[2], c1z[2];   // lo.z hi.z of child 0, child 1
-    int32_t child[2];
-    int32_t pad[2];
+    float o[3];           // quantisation origin (the node's lower corner, nudged down)
+    uint32_t exps;        // e_x | e_y << 8 | e_z << 16 : biased float exponents of the grid step
+    uint32_t qlo[3];      // per axis: 4 child bytes, child c in byte c
+    uint32_t qhi[3];
+    int32_t child[4];
+    uint32_t pad[2];
 };
+#define GBL_REF_NONE 0x7ffffffd
 
 struct DevTri {
     float p0[3];
@@ -140,6 +148,8 @@ struct RenderArgs {
     uint32_t russian_roulette;
     const float* replay;        // Sample records for the sub-window, pixel-major
     float* li_out;
+    float* li_defer;            // when set, the render kernel stores per-sample radiance here (pixel-major)
+                                // and a separate splat kernel filters it into the film afterwards
     float* film;                // xres*yres float4 accumulators
     uint32_t* work_counter;     // zeroed before each launch
     unsigned long long* stats;  // 8 counters

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             ctrl[0] = atomicAdd(ra.work_counter, 1u);
             ctrl[1] = 0u;
         }
-        for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
+        if (!ra.li_defer)
+            for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
         __syncthreads();
         const uint32_t item = ctrl[0];
         if (item >= n_items) break;
@@ -360,17 +361,18 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             // ---- path end: splat and free the lane
             if (active && finished) {
                 // RenderTask::run: w * (tr * L + Lv), w = 1, tr = 1, Lv = 0
-                splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, ps.Li, cnt);
-                if (ra.li_out) {
-                    float4 v = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
-                    reinterpret_cast<float4*>(ra.li_out)[out_index] = v;
+                if (ra.li_defer) {
+                    reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
+                } else {
+                    splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, ps.Li, cnt);
+                    if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
                 }
                 active = false;
                 paths_done += 1;
             }
         }
         __syncthreads();
-        flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
+        if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
 }

@@ -114,15 +114,13 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
     uint32_t r_off = 0, r_cnt = region < n_regions ? counts[region] : 0u;
 
     bool busy = false;
-    RaySpace world, r;
-    float mint = 0.0f, maxt = 0.0f;
-    int sp = 0, cur = 0, inst = -1;
+    TravState st;
+    st.sp = 0;
+    st.cur = GBL_STACK_EXIT;
+    st.inst = -1;
+    st.mint = st.maxt = 0.0f;
     uint32_t slot = 0;
-    Hit hit;
-    hit.t = INFINITY; hit.inst = -1; hit.tri = 0; hit.b1 = hit.b2 = 0.0f;
     F3 contrib = f3(0, 0, 0);
-    bool occluded = false;
-    const DevNode* __restrict__ nodes = sc.nodes;
 
     for (;;) {
         // ---- refill idle lanes from this wave's regions (all scalar bookkeeping)
@@ -147,6 +145,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
             }
             if (my_entry != 0xffffffffu) {
                 float4 a, b;
+                float maxt;
                 if (ANY) {
                     a = wa.sh_o[my_entry];
                     b = wa.sh_d[my_entry];
@@ -160,16 +159,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
                     b = wa.ray_d[slot];
                     maxt = INFINITY;
                 }
-                mint = a.w;
-                ray_space(world, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z));
-                r = world;
-                sp = 0;
-                stk[(sp++) * GBL_BLOCK] = GBL_STACK_EXIT;
-                cur = sc.num_instances > 0 ? sc.tlas_root : GBL_STACK_EXIT;
-                inst = -1;
-                hit.t = INFINITY;
-                hit.inst = -1;
-                occluded = false;
+                trav_begin(sc, st, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), a.w, maxt, stk);
                 busy = true;
                 if (STATS) {
                     if (ANY) cnt.shadow += 1; else cnt.ext += 1;
@@ -184,75 +174,14 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
         // ---- traverse while enough lanes are busy (or nothing is left to fetch)
         const int keep = drained ? 1 : (64 - WF_REFILL + 1);
         while (__popcll(__ballot(busy)) >= keep) {
-            if (busy) {
-                while (static_cast<uint32_t>(cur) < static_cast<uint32_t>(GBL_STACK_EXIT)) {
-                    const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-                    const float4 n0 = np[0];
-                    const float4 n1 = np[1];
-                    const float4 nz = np[2];
-                    const int2 ch = *reinterpret_cast<const int2*>(np + 3);
-                    float ax0 = __builtin_fmaf(n0.x, r.idir.x, -r.ood.x), ax1 = __builtin_fmaf(n0.y, r.idir.x, -r.ood.x);
-                    float ay0 = __builtin_fmaf(n0.z, r.idir.y, -r.ood.y), ay1 = __builtin_fmaf(n0.w, r.idir.y, -r.ood.y);
-                    float az0 = __builtin_fmaf(nz.x, r.idir.z, -r.ood.z), az1 = __builtin_fmaf(nz.y, r.idir.z, -r.ood.z);
-                    float bx0 = __builtin_fmaf(n1.x, r.idir.x, -r.ood.x), bx1 = __builtin_fmaf(n1.y, r.idir.x, -r.ood.x);
-                    float by0 = __builtin_fmaf(n1.z, r.idir.y, -r.ood.y), by1 = __builtin_fmaf(n1.w, r.idir.y, -r.ood.y);
-                    float bz0 = __builtin_fmaf(nz.z, r.idir.z, -r.ood.z), bz1 = __builtin_fmaf(nz.w, r.idir.z, -r.ood.z);
-                    float a_lo = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), mint));
-                    float a_hi = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), maxt));
-                    float b_lo = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), mint));
-                    float b_hi = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), maxt));
-                    bool ha = a_lo <= a_hi, hb = b_lo <= b_hi;
-                    if (STATS) cnt.nodes += 2;
-                    if (ha && hb) {
-                        bool a_first = a_lo <= b_lo;
-                        stk[(sp++) * GBL_BLOCK] = static_cast<uint32_t>(a_first ? ch.y : ch.x);
-                        cur = a_first ? ch.x : ch.y;
-                    } else if (ha) {
-                        cur = ch.x;
-                    } else if (hb) {
-                        cur = ch.y;
-                    } else {
-                        cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
-                    }
-                }
-                bool done = false;
-                if (cur == GBL_STACK_EXIT) {
-                    done = true;
-                } else if (cur == GBL_STACK_SENTINEL) {
-                    r = world;
-                    inst = -1;
-                    cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
-                } else {
-                    uint32_t ref = ~static_cast<uint32_t>(cur);
-                    if (inst < 0) {
-                        inst = static_cast<int>(ref >> 2);
-                        const DevInstance* ip = sc.instances + inst;
-                        ray_space(r, xf_point(ip->inv, world.o), xf_vector(ip->inv, world.d));
-                        stk[(sp++) * GBL_BLOCK] = GBL_STACK_SENTINEL;
-                        cur = ip->root;
-                    } else {
-                        uint32_t first = ref >> 2, n = (ref & 3u) + 1u;
-                        for (uint32_t i = 0; i < n; ++i) {
-                            float t, b1, b2;
-                            if (STATS) cnt.tris += 1;
-                            if (tri_test(sc.tris + first + i, r.o, r.d, mint, maxt, &t, &b1, &b2)) {
-                                if (ANY) {
-                                    occluded = true;
-                                    done = true;
-                                    break;
-                                }
-                                maxt = t;
-                                hit.t = t;
-                                hit.inst = inst;
-                                hit.tri = first + i;
-                                hit.b1 = b1;
-                                hit.b2 = b2;
-                            }
-                        }
-                        if (!done) cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
-                    }
-                }
-                if (done) {
+            const bool at_int = busy && trav_at_interior(st);
+            const bool at_oth = busy && !at_int;
+            const unsigned long long mi = __ballot(at_int), mo = __ballot(at_oth);
+            if (mo == 0ull || __popcll(mi) >= GBL_TRAV_TH) {
+                if (at_int) trav_interior<STATS>(sc, st, stk, cnt);
+            } else if (at_oth) {
+                bool occluded = false;
+                if (trav_other<ANY, STATS>(sc, st, stk, cnt, &occluded)) {
                     if (ANY) {
                         if (!occluded) {
                             float4 ld = wa.s_ld[slot];   // one shadow ray per slot per iteration: plain read-modify-write
@@ -262,8 +191,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
                             wa.s_ld[slot] = ld;
                         }
                     } else {
-                        wa.hit[slot] = make_float4(hit.t, hit.b1, hit.b2, __uint_as_float(hit.tri));
-                        wa.hit_inst[slot] = hit.inst;
+                        wa.hit[slot] = make_float4(st.hit.t, st.hit.b1, st.hit.b2, __uint_as_float(st.hit.tri));
+                        wa.hit_inst[slot] = st.hit.inst;
                     }
                     busy = false;
                 }

@@ -270,34 +270,93 @@ struct Builder {
     }
 };
 
-// one ulp-ish outward nudge so the fma-form slab test can never cull a triangle
-// the exact test would keep
-inline float nudge_down(float v) { return v - std::fabs(v) * 1.2e-7f - 1e-30f; }
-inline float nudge_up(float v) { return v + std::fabs(v) * 1.2e-7f + 1e-30f; }
+// Collapse the binary tree into 4-wide nodes and quantise the child boxes to 8 bits on a
+// per-node power-of-two grid.  Boxes are first nudged outwards by a few ulps and then rounded
+// outwards to the grid, so the device slab test (fused multiply-add form) can never cull a
+// triangle the exact test would keep.
+inline float nudge_down(float v) { return v - std::fabs(v) * 4e-7f - 1e-30f; }
+inline float nudge_up(float v) { return v + std::fabs(v) * 4e-7f + 1e-30f; }
 
-// Flatten interior TmpNodes into DevNodes (DFS preorder).  leaf_ref(first,count) encodes a leaf.
-template <class LeafRef>
-int32_t flatten(const Builder& b, int root, std::vector<DevNode>& out, LeafRef leaf_ref) {
-    const TmpNode& r = b.nodes[root];
-    if (r.count > 0) return leaf_ref(r.first, r.count);
-    int32_t me = static_cast<int32_t>(out.size());
-    out.push_back(DevNode());
-    const TmpNode& c0 = b.nodes[r.left];
-    const TmpNode& c1 = b.nodes[r.right];
-    int32_t ref0 = flatten(b, r.left, out, leaf_ref);
-    int32_t ref1 = flatten(b, r.right, out, leaf_ref);
-    DevNode& n = out[me];
-    n.c0x[0] = nudge_down(c0.box.lo[0]); n.c0x[1] = nudge_up(c0.box.hi[0]);
-    n.c0y[0] = nudge_down(c0.box.lo[1]); n.c0y[1] = nudge_up(c0.box.hi[1]);
-    n.c1x[0] = nudge_down(c1.box.lo[0]); n.c1x[1] = nudge_up(c1.box.hi[0]);
-    n.c1y[0] = nudge_down(c1.box.lo[1]); n.c1y[1] = nudge_up(c1.box.hi[1]);
-    n.c0z[0] = nudge_down(c0.box.lo[2]); n.c0z[1] = nudge_up(c0.box.hi[2]);
-    n.c1z[0] = nudge_down(c1.box.lo[2]); n.c1z[1] = nudge_up(c1.box.hi[2]);
-    n.child[0] = ref0;
-    n.child[1] = ref1;
-    n.pad[0] = n.pad[1] = 0;
-    return me;
-}
+struct Flat4 {
+    const Builder& b;
+    std::vector<DevNode>& out;
+    int depth = 0;        // deepest 4-wide level reached (root = 1)
+    Flat4(const Builder& bb, std::vector<DevNode>& o) : b(bb), out(o) {}
+
+    template <class LeafRef>
+    int32_t emit(int node, int level, LeafRef& leaf_ref) {
+        const TmpNode& r = b.nodes[node];
+        depth = std::max(depth, level);
+        if (r.count > 0) return leaf_ref(r.first, r.count);
+        // gather up to 4 children: keep splitting the interior child with the largest area
+        int kids[4] = {r.left, r.right, -1, -1};
+        int n = 2;
+        while (n < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int i = 0; i < n; ++i) {
+                const TmpNode& c = b.nodes[kids[i]];
+                if (c.count == 0 && c.box.half_area() > best_area) {
+                    best_area = c.box.half_area();
+                    best = i;
+                }
+            }
+            if (best < 0) break;
+            const TmpNode& c = b.nodes[kids[best]];
+            kids[best] = c.left;
+            kids[n++] = c.right;
+        }
+        int32_t me = static_cast<int32_t>(out.size());
+        out.push_back(DevNode());
+        int32_t refs[4];
+        for (int i = 0; i < 4; ++i) refs[i] = i < n ? emit(kids[i], level + 1, leaf_ref) : static_cast<int32_t>(GBL_REF_NONE);
+        DevNode nd;
+        memset(&nd, 0, sizeof(nd));
+        // node bounds over the (nudged) children
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = INFINITY;
+            hi[a] = -INFINITY;
+            for (int i = 0; i < n; ++i) {
+                lo[a] = std::min(lo[a], nudge_down(b.nodes[kids[i]].box.lo[a]));
+                hi[a] = std::max(hi[a], nudge_up(b.nodes[kids[i]].box.hi[a]));
+            }
+        }
+        uint32_t exps = 0;
+        for (int a = 0; a < 3; ++a) {
+            nd.o[a] = lo[a];
+            // grid step 2^e with 255 * 2^e >= extent (plus headroom for the rounding of o + q * step)
+            float extent = (hi[a] - lo[a]) * 1.0001f + 1e-30f;
+            int e = 0;
+            std::frexp(extent / 255.0f, &e);   // extent/255 = m * 2^e, m in [0.5, 1)  ->  2^e >= extent/255
+            int biased = std::min(254, std::max(1, e + 127));
+            exps |= static_cast<uint32_t>(biased) << (8 * a);
+            float step = std::ldexp(1.0f, biased - 127);
+            uint32_t ql = 0, qh = 0;
+            for (int i = 0; i < 4; ++i) {
+                uint32_t l = 255, h = 0;   // unused slot: inverted box, never hit
+                if (i < n) {
+                    float cl = nudge_down(b.nodes[kids[i]].box.lo[a]), ch = nudge_up(b.nodes[kids[i]].box.hi[a]);
+                    double fl = std::floor((static_cast<double>(cl) - lo[a]) / step);
+                    double fh = std::ceil((static_cast<double>(ch) - lo[a]) / step);
+                    // guard the float evaluation o + q * step on the device against rounding inwards
+                    while (fl > 0 && lo[a] + static_cast<float>(fl) * step > cl) fl -= 1;
+                    while (fh < 255 && lo[a] + static_cast<float>(fh) * step < ch) fh += 1;
+                    l = static_cast<uint32_t>(std::min(255.0, std::max(0.0, fl)));
+                    h = static_cast<uint32_t>(std::min(255.0, std::max(0.0, fh)));
+                }
+                ql |= l << (8 * i);
+                qh |= h << (8 * i);
+            }
+            nd.qlo[a] = ql;
+            nd.qhi[a] = qh;
+        }
+        nd.exps = exps;
+        for (int i = 0; i < 4; ++i) nd.child[i] = refs[i];
+        out[me] = nd;
+        return me;
+    }
+};
 
 // -------------------------------------------------------------------- filter
 struct Filter {
@@ -409,7 +468,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         }
         Builder b(prims, GBL_MAX_LEAF_TRIS, kBlasCap);
         int root = b.build(0, prims.size(), 1);
-        out->blas_max_depth = std::max(out->blas_max_depth, b.height);
+        Flat4 f4(b, out->nodes);
         uint32_t tri_base = static_cast<uint32_t>(out->tris.size());
         for (const Prim& p : prims) {
             const float* p0 = P + 3 * I[3 * p.id];
@@ -425,9 +484,11 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             t.shade = gm.tri_offset + p.id;
             out->tris.push_back(t);
         }
-        mesh_root[mi] = flatten(b, root, out->nodes, [&](uint32_t first, uint32_t count) {
+        auto leaf_ref = [&](uint32_t first, uint32_t count) {
             return ~static_cast<int32_t>(((tri_base + first) << 2) | (count - 1));
-        });
+        };
+        mesh_root[mi] = f4.emit(root, 1, leaf_ref);
+        out->blas_max_depth = std::max(out->blas_max_depth, f4.depth);
     }
     out->blas_nodes = out->nodes.size();
 
@@ -467,13 +528,14 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     if (d->num_instances > 0) {
         Builder tb(iprims, 1, kTlasCap);
         int root = tb.build(0, iprims.size(), 1);
-        out->tlas_depth = tb.height;
-        out->tlas_root = flatten(tb, root, out->nodes, [&](uint32_t first, uint32_t) {
-            return ~static_cast<int32_t>(iprims[first].id << 2);
-        });
+        Flat4 t4(tb, out->nodes);
+        auto inst_ref = [&](uint32_t first, uint32_t) { return ~static_cast<int32_t>(iprims[first].id << 2); };
+        out->tlas_root = t4.emit(root, 1, inst_ref);
+        out->tlas_depth = t4.depth;
     }
     out->tlas_nodes = out->nodes.size() - out->blas_nodes;
-    out->stack_entries = out->tlas_depth + out->blas_max_depth + 2;
+    // every 4-wide level can leave up to 3 siblings on the stack; + exit marker + instance sentinel
+    out->stack_entries = 3 * (out->tlas_depth + out->blas_max_depth) + 2;
 
     // ---- materials
     out->materials.resize(d->num_materials);
