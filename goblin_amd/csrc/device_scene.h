@@ -17,7 +17,7 @@
 #define GBL_MAX_LEAF_TRIS 4
 #define GBL_STACK_SENTINEL 0x7fffffff
 #ifndef GBL_PT_WAVES
-#define GBL_PT_WAVES 1
+#define GBL_PT_WAVES 3
 #endif
 #define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
 
@@ -26,16 +26,15 @@
 //
 // 4-wide BVH node with 8-bit quantised child boxes, 64 bytes = four 16-byte loads per
 // traversal step for FOUR box tests.  A child's box on axis a is
-//   [o_a + qlo[a][c] * 2^(e_a - 127),  o_a + qhi[a][c] * 2^(e_a - 127)]
+//   [o_a + qlo[a][c] * scale_a,  o_a + qhi[a][c] * scale_a]
 // rounded outwards, so the test is conservative: it can only add candidates, never lose
 // a triangle the exact test would accept.
 struct DevNode {
     float o[3];           // quantisation origin (the node's lower corner, nudged down)
-    uint32_t exps;        // e_x | e_y << 8 | e_z << 16 : biased float exponents of the grid step
+    float scale[3];       // grid step per axis, a power of two
     uint32_t qlo[3];      // per axis: 4 child bytes, child c in byte c
     uint32_t qhi[3];
-    int32_t child[4];
-    uint32_t pad[2];
+    int32_t child[4];     // unused slots: GBL_REF_NONE with qlo = 255, qhi = 0 (an empty interval for every ray)
 };
 #define GBL_REF_NONE 0x7ffffffd
 

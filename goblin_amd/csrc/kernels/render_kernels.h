@@ -120,8 +120,8 @@ __device__ __forceinline__ int wave_fetch(bool want, uint32_t* next_path) {
 }
 
 __device__ __forceinline__ void accumulate_stats(const RenderArgs& ra, const LaneCounters& c, uint32_t paths) {
-    unsigned long long v[7] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims};
-    for (int i = 0; i < 7; ++i) {
+    unsigned long long v[11] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims, c.int_lane, c.int_wave, c.oth_lane, c.oth_wave};
+    for (int i = 0; i < 11; ++i) {
         unsigned long long x = v[i];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(ra.stats + i, x);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
     uint32_t* stk = stack + threadIdx.x;
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
 
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];
@@ -188,8 +188,13 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
 
         for (;;) {
             // ---- regeneration: idle lanes start a new camera path
-            int fetched = wave_fetch(!active && !exhausted, ctrl + 1);
-            if (!active && !exhausted) {
+#ifdef GBL_REGEN_WHOLE_WAVE
+            const bool may_fetch = __ballot(active) == 0ull;   // experiment: refill only a fully idle wave
+#else
+            const bool may_fetch = true;
+#endif
+            int fetched = wave_fetch(!active && !exhausted && may_fetch, ctrl + 1);
+            if (!active && !exhausted && may_fetch) {
                 if (fetched >= 0 && fetched < it.paths) {
                     int pix = fetched / ra.chunk_spp;
                     src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
     uint32_t* stk = stack + threadIdx.x;
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
 
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];

@@ -12,6 +12,7 @@
 //   memory round trips.  Boxes are rounded outwards: conservative, radiance unaffected.
 // * Slab test in fused multiply-add form on the quantisation grid:
 //       t = (o_a + q * s_a - ray.o_a) / d_a = fma(q, s_a * idir_a, fma(o_a, idir_a, -ray.o_a * idir_a))
+//   with the near / far plane bytes of all four children selected per ray direction once per node
 // * The world ray enters an instance by the same un-normalised inverse transform the
 //   reference uses (Transform::invertRay), so object-space t is world t and hits from
 //   different instances compare directly.
@@ -37,7 +38,17 @@ struct Hit {
 
 struct LaneCounters {
     uint32_t ext, shadow, nodes, tris, splats, dims;
+    // SIMD-efficiency probes (instrumented builds only): per phase, lane-steps executed and
+    // wave-steps issued; utilisation = lane / (64 * wave)
+    uint32_t int_lane, int_wave, oth_lane, oth_wave;
 };
+
+// first active lane of the current exec mask adds one wave-step
+__device__ __forceinline__ void probe(uint32_t& lane_ctr, uint32_t& wave_ctr) {
+    unsigned long long m = __ballot(1);
+    lane_ctr += 1;
+    if ((threadIdx.x & 63) == __ffsll(static_cast<long long>(m)) - 1) wave_ctr += 1;
+}
 
 struct RaySpace {
     F3 o, d, idir, ood;
@@ -104,16 +115,17 @@ __device__ __forceinline__ void trav_begin(const DevScene& sc, TravState& st, F3
     st.hit.b1 = st.hit.b2 = 0.0f;
 }
 
-// entry distance of child c on the node's quantisation grid, INFINITY if missed
-__device__ __forceinline__ float child_entry(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, F3 A, F3 B,
+// Entry distance of one child, INFINITY if the ray misses it.  `n*` / `f*` hold the grid
+// coordinates of the child's planes the ray crosses first / last on each axis (chosen per ray
+// direction once per node), so no per-child min/max is needed, and an unused slot
+// (qlo = 255 > qhi = 0) is an empty interval for every direction.
+__device__ __forceinline__ float child_entry(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, F3 A, F3 B,
                                              float mint, float maxt) {
-    // v_cvt_f32_ubyte0: the low byte of each word is this child's grid coordinate
-    float x0 = __builtin_fmaf(static_cast<float>(lx & 0xffu), B.x, A.x), x1 = __builtin_fmaf(static_cast<float>(hx & 0xffu), B.x, A.x);
-    float y0 = __builtin_fmaf(static_cast<float>(ly & 0xffu), B.y, A.y), y1 = __builtin_fmaf(static_cast<float>(hy & 0xffu), B.y, A.y);
-    float z0 = __builtin_fmaf(static_cast<float>(lz & 0xffu), B.z, A.z), z1 = __builtin_fmaf(static_cast<float>(hz & 0xffu), B.z, A.z);
-    float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), mint));
-    float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), maxt));
-    return lo <= hi ? lo : INFINITY;
+    float tn = fmaxf(fmaxf(__builtin_fmaf(static_cast<float>(nx & 0xffu), B.x, A.x), __builtin_fmaf(static_cast<float>(ny & 0xffu), B.y, A.y)),
+                     fmaxf(__builtin_fmaf(static_cast<float>(nz & 0xffu), B.z, A.z), mint));
+    float tf = fminf(fminf(__builtin_fmaf(static_cast<float>(fx & 0xffu), B.x, A.x), __builtin_fmaf(static_cast<float>(fy & 0xffu), B.y, A.y)),
+                     fminf(__builtin_fmaf(static_cast<float>(fz & 0xffu), B.z, A.z), maxt));
+    return tn <= tf ? tn : INFINITY;
 }
 
 #define GBL_CSWAP(ta, ra, tb, rb)            \
@@ -131,26 +143,28 @@ __device__ __forceinline__ float child_entry(uint32_t lx, uint32_t ly, uint32_t 
 template <bool STATS>
 __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st, uint32_t* stk, LaneCounters& cnt) {
     const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
-    const uint4 w0 = np[0];   // o.x o.y o.z exps
-    const uint4 w1 = np[1];   // qlo.x qlo.y qlo.z qhi.x
-    const uint4 w2 = np[2];   // qhi.y qhi.z child0 child1
-    const uint4 w3 = np[3];   // child2 child3 - -
+    const uint4 w0 = np[0];   // o.x o.y o.z scale.x
+    const uint4 w1 = np[1];   // scale.y scale.z qlo.x qlo.y
+    const uint4 w2 = np[2];   // qlo.z qhi.x qhi.y qhi.z
+    const uint4 w3 = np[3];   // child0..3
     const RaySpace& r = st.r;
     F3 A = f3(__builtin_fmaf(__uint_as_float(w0.x), r.idir.x, -r.ood.x), __builtin_fmaf(__uint_as_float(w0.y), r.idir.y, -r.ood.y),
               __builtin_fmaf(__uint_as_float(w0.z), r.idir.z, -r.ood.z));
-    F3 B = f3(__uint_as_float((w0.w & 0xffu) << 23) * r.idir.x, __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * r.idir.y,
-              __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * r.idir.z);
-    float t0 = child_entry(w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, A, B, st.mint, st.maxt);
-    float t1 = child_entry(w1.x >> 8, w1.y >> 8, w1.z >> 8, w1.w >> 8, w2.x >> 8, w2.y >> 8, A, B, st.mint, st.maxt);
-    float t2 = child_entry(w1.x >> 16, w1.y >> 16, w1.z >> 16, w1.w >> 16, w2.x >> 16, w2.y >> 16, A, B, st.mint, st.maxt);
-    float t3 = child_entry(w1.x >> 24, w1.y >> 24, w1.z >> 24, w1.w >> 24, w2.x >> 24, w2.y >> 24, A, B, st.mint, st.maxt);
-    int r0 = static_cast<int>(w2.z), r1 = static_cast<int>(w2.w), r2 = static_cast<int>(w3.x), r3 = static_cast<int>(w3.y);
-    // unused child slots (a min/max slab test cannot see an inverted box)
-    t0 = r0 == static_cast<int>(GBL_REF_NONE) ? INFINITY : t0;
-    t1 = r1 == static_cast<int>(GBL_REF_NONE) ? INFINITY : t1;
-    t2 = r2 == static_cast<int>(GBL_REF_NONE) ? INFINITY : t2;
-    t3 = r3 == static_cast<int>(GBL_REF_NONE) ? INFINITY : t3;
-    if (STATS) cnt.nodes += 4;
+    F3 B = f3(__uint_as_float(w0.w) * r.idir.x, __uint_as_float(w1.x) * r.idir.y, __uint_as_float(w1.y) * r.idir.z);
+    // planes crossed first / last per axis, for all four children at once (4 bytes per word)
+    const bool ngx = r.idir.x < 0.0f, ngy = r.idir.y < 0.0f, ngz = r.idir.z < 0.0f;
+    const uint32_t nx = ngx ? w2.y : w1.z, fx = ngx ? w1.z : w2.y;
+    const uint32_t ny = ngy ? w2.z : w1.w, fy = ngy ? w1.w : w2.z;
+    const uint32_t nz = ngz ? w2.w : w2.x, fz = ngz ? w2.x : w2.w;
+    float t0 = child_entry(nx, ny, nz, fx, fy, fz, A, B, st.mint, st.maxt);
+    float t1 = child_entry(nx >> 8, ny >> 8, nz >> 8, fx >> 8, fy >> 8, fz >> 8, A, B, st.mint, st.maxt);
+    float t2 = child_entry(nx >> 16, ny >> 16, nz >> 16, fx >> 16, fy >> 16, fz >> 16, A, B, st.mint, st.maxt);
+    float t3 = child_entry(nx >> 24, ny >> 24, nz >> 24, fx >> 24, fy >> 24, fz >> 24, A, B, st.mint, st.maxt);
+    int r0 = static_cast<int>(w3.x), r1 = static_cast<int>(w3.y), r2 = static_cast<int>(w3.z), r3 = static_cast<int>(w3.w);
+    if (STATS) {
+        cnt.nodes += 4;
+        probe(cnt.int_lane, cnt.int_wave);
+    }
     // sort the four (entry, ref) pairs by entry distance (5 compare-exchanges)
     GBL_CSWAP(t0, r0, t1, r1);
     GBL_CSWAP(t2, r2, t3, r3);
@@ -176,6 +190,7 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, uint32_t* stk, LaneCounters& cnt, bool* occluded) {
     const int cur = st.cur;
+    if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
     if (cur == GBL_STACK_EXIT) return true;
     if (cur == GBL_STACK_SENTINEL) {   // finished an instance: back to the world ray
         st.r = st.world;

@@ -62,8 +62,8 @@ struct WfArgs {
 };
 
 __device__ __forceinline__ void wf_stats(unsigned long long* stats, const LaneCounters& c, uint32_t paths) {
-    unsigned long long v[7] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims};
-    for (int i = 0; i < 7; ++i) {
+    unsigned long long v[11] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims, c.int_lane, c.int_wave, c.oth_lane, c.oth_wave};
+    for (int i = 0; i < 11; ++i) {
         unsigned long long x = v[i];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(stats + i, x);
@@ -104,7 +104,7 @@ template <bool ANY, bool STATS>
 __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int lane = threadIdx.x & 63;
     const uint32_t n_regions = wa.pool_size / 64u;
     const uint32_t n_waves = gridDim.x * (GBL_BLOCK / 64);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;   // grid covers the pool exactly
     const int lane = threadIdx.x & 63;
     const uint32_t wave_gid = slot >> 6;
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t paths_done = 0;
     PathState ps;
     ps.bounce = WF_BOUNCE_EMPTY;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
     __syncthreads();
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t lt = blockIdx.x;
     const uint32_t tile_id = ra.shard_index + lt * ra.shard_count;
     const int tx = tile_id % ra.tiles_x, ty = tile_id / ra.tiles_x;

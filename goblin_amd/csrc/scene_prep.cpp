@@ -322,7 +322,6 @@ struct Flat4 {
                 hi[a] = std::max(hi[a], nudge_up(b.nodes[kids[i]].box.hi[a]));
             }
         }
-        uint32_t exps = 0;
         for (int a = 0; a < 3; ++a) {
             nd.o[a] = lo[a];
             // grid step 2^e with 255 * 2^e >= extent (plus headroom for the rounding of o + q * step)
@@ -330,8 +329,8 @@ struct Flat4 {
             int e = 0;
             std::frexp(extent / 255.0f, &e);   // extent/255 = m * 2^e, m in [0.5, 1)  ->  2^e >= extent/255
             int biased = std::min(254, std::max(1, e + 127));
-            exps |= static_cast<uint32_t>(biased) << (8 * a);
             float step = std::ldexp(1.0f, biased - 127);
+            nd.scale[a] = step;
             uint32_t ql = 0, qh = 0;
             for (int i = 0; i < 4; ++i) {
                 uint32_t l = 255, h = 0;   // unused slot: inverted box, never hit
@@ -351,7 +350,6 @@ struct Flat4 {
             nd.qlo[a] = ql;
             nd.qhi[a] = qh;
         }
-        nd.exps = exps;
         for (int i = 0; i < 4; ++i) nd.child[i] = refs[i];
         out[me] = nd;
         return me;
