@@ -31,12 +31,23 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def algorithmic_bytes(st):
-    """per ray 32 B per child box tested + 48 B per triangle tested + 48 B
-    (32 B ray in, 16 B hit out); per path 4 B per sample dimension consumed + 16 B per
-    film pixel update."""
+def algorithmic_bytes(st, main_kernel_only=True):
+    """Algorithmic bytes of one launch: per ray 32 B per BVH box node tested +
+    48 B per triangle tested + 48 B (32 B ray in, 16 B hit out); per path 4 B per sample
+    dimension consumed + 16 B of radiance written.  The film splat (16 B per touched pixel)
+    belongs to the separate splat kernel and is excluded from the dominant kernel's figure."""
     rays = st["extension_rays"] + st["shadow_rays"]
-    return 32 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["splats"]
+    b = 32 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
+    if not main_kernel_only:
+        b += 16 * st["splats"]
+    return b
+
+
+def requested_bytes(st):
+    """Bytes the dominant kernel's loads/stores actually request for the same work: the 4-wide node is
+    64 B for four quantised boxes (16 B per box tested instead of 32)."""
+    rays = st["extension_rays"] + st["shadow_rays"]
+    return 16 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
 
 
 def cpu_baseline(workload_overrides, spp_sample, cores):
@@ -179,11 +190,15 @@ def main():
     elapsed = float(t.item())
     job_paths = float(paths.item())   # paths all ranks traced in one step
 
+    resolved = args.schedule if args.schedule != "auto" else ("wavefront" if args.depth >= 12 else "megakernel")
     if rank == 0:
-        kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in events)
-        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        call_ms = sorted(e0.elapsed_time(e1) for e0, e1 in events)          # torch events around gbl_render
+        timings = tracer.timings(args.steps)                                   # HIP events inside, per kernel class
+        main_ms = [t[0] for t in timings] or call_ms
+        avg_kernel_ms = sum(main_ms) / len(main_ms)
         alg_bytes = algorithmic_bytes(counted)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        req_bytes = requested_bytes(counted)
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
         if os.path.exists(tpath) and args.spp == 256 and args.resolution == [512, 512] and args.depth == 8 and world == 1:
@@ -209,6 +224,7 @@ def main():
                             "stand-in bunny (69120 tris) + spot light" % (
                                 args.resolution[0], args.resolution[1], tracer.window[1] - tracer.window[0],
                                 tracer.window[3] - tracer.window[2], scene.spp(), args.depth),
+                "schedule": resolved,
                 "paths_per_step": int(job_paths),
                 "rays_per_path": round(rays / max(1, my_paths), 3),
                 "mrays_per_s": round(value * rays / max(1, my_paths), 2),
@@ -224,9 +240,15 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "kernel": "path_trace_kernel<false,false>",
+                "kernel": "path_trace_kernel<false,false>" if resolved != "wavefront" else "wf_trace/wf_shade (all wavefront kernels of a step)",
                 "kernel_ms_avg": round(avg_kernel_ms, 3),
+                "call_ms_avg": round(sum(call_ms) / len(call_ms), 3),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
+                "requested_bytes_per_launch": int(req_bytes),
+                "achieved_requested": round(req_bytes / (avg_kernel_ms * 1e-3) / 1e9, 2),
+                "note": "algorithmic = SURVEY 8d convention (32 B per box node tested); requested = what the 4-wide "
+                        "quantised node layout really loads (16 B per box); traffic = HBM bytes from rocprofv3 PMC "
+                        "(profiles/), the scene is cache resident",
                 "counters": {k: int(v) for k, v in counted.items() if k != "kernel_ms"},
             },
         }

@@ -100,6 +100,10 @@ class gbl_stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class gbl_timing(C.Structure):
+    _fields_ = [("main_kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 class gbl_info(C.Structure):
     _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("window", C.c_int32 * 4), ("blas_nodes", C.c_uint64),
                 ("tlas_nodes", C.c_uint64), ("triangles", C.c_uint64), ("instances", C.c_uint64),
@@ -110,7 +114,7 @@ HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "
                 "gbl_host_last_error", "gbl_host_sample_window", "gbl_host_round_to_square",
                 "gbl_host_sample_dimension", "gbl_host_film_normalize", "gbl_host_write_pfm"]
 HIP_SYMBOLS = ["gbl_create", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
-               "gbl_last_error", "gbl_abi_version"]
+               "gbl_last_error", "gbl_abi_version", "gbl_get_timings"]
 
 _host = None
 _hip = None
@@ -162,6 +166,7 @@ def hip_lib():
         lib.gbl_film_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gbl_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gbl_get_info.argtypes = [C.c_void_p, C.POINTER(gbl_info)]
+        lib.gbl_get_timings.argtypes = [C.c_void_p, C.c_int, C.POINTER(gbl_timing)]
         lib.gbl_destroy.argtypes = [C.c_void_p]
         lib.gbl_destroy.restype = None
         lib.gbl_last_error.argtypes = [C.c_void_p]

@@ -42,6 +42,10 @@ struct gbl_ctx {
     float4* wf_li = nullptr;
     size_t wf_li_entries = 0;
     uint32_t* wf_host_flags = nullptr;   // pinned
+    // ring of event triples for gbl_get_timings
+    static const int kTimingRing = 64;
+    hipEvent_t t_ev[64][3] = {};
+    unsigned long long t_calls = 0;
 };
 
 namespace {
@@ -333,6 +337,9 @@ void gbl_destroy(gbl_ctx* ctx) {
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
     if (ctx->wf_host_flags) (void)hipHostFree(ctx->wf_host_flags);
+    for (int i = 0; i < gbl_ctx::kTimingRing; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (ctx->t_ev[i][k]) (void)hipEventDestroy(ctx->t_ev[i][k]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->rccl) dlclose(ctx->rccl);
@@ -447,9 +454,13 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         return GBL_ERR_UNSUPPORTED;
     }
     const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY;
-    // schedule: the wavefront formulation for path tracing (unless the caller asks for the
-    // megakernel or uses the Russian-roulette extension); AO runs the persistent megakernel.
-    bool wavefront = p->integrator == GBL_INTEGRATOR_PATH && p->schedule != GBL_SCHEDULE_MEGAKERNEL && !p->russian_roulette;
+    // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while paths are
+    // short (depth <= 8: configs 1, 2, 4), the wavefront formulation once they are long enough for its
+    // compaction to pay for the path pool traffic (Cornell box at depth 16: 4.6 s against 6.5 s).  AO and the
+    // Russian-roulette extension always run the megakernel.
+    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette;
+    bool wavefront = wf_capable && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
+                                    (p->schedule == GBL_SCHEDULE_AUTO && p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
         ctx->error = "the wavefront schedule covers the path tracer without Russian roulette";
         return GBL_ERR_UNSUPPORTED;
@@ -457,9 +468,14 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));
     per_cu = std::max(1, per_cu);
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+    hipEvent_t* tev = ctx->t_ev[ctx->t_calls % gbl_ctx::kTimingRing];
+    for (int k = 0; k < 3; ++k)
+        if (!tev[k]) HIP_TRY(ctx, hipEventCreate(&tev[k]));
+    HIP_TRY(ctx, hipEventRecord(tev[0], stream));
     if (wavefront) {
         gbl_status wst = render_wavefront(ctx, ra, p, stream, want_stats, replay);
         if (wst != GBL_OK) return wst;
+        HIP_TRY(ctx, hipEventRecord(tev[1], stream));
     } else {
         // persistent grid: enough workgroups to fill every CU at the occupancy LDS allows, never more than items
         uint64_t grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * per_cu);
@@ -493,6 +509,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         }
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(tev[1], stream));
         if (defer) {
             WfArgs wa;
             memset(&wa, 0, sizeof(wa));
@@ -506,6 +523,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             HIP_TRY(ctx, hipGetLastError());
         }
     }
+    HIP_TRY(ctx, hipEventRecord(tev[2], stream));
+    ctx->t_calls += 1;
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
@@ -537,6 +556,22 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         }
     }
     return GBL_OK;
+}
+
+int gbl_get_timings(gbl_ctx* ctx, int n, gbl_timing* out) {
+    if (!ctx || !out || n <= 0) return 0;
+    int have = static_cast<int>(std::min<unsigned long long>(ctx->t_calls, gbl_ctx::kTimingRing));
+    n = std::min(n, have);
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t* ev = ctx->t_ev[(ctx->t_calls - 1 - i) % gbl_ctx::kTimingRing];
+        float a = 0.0f, b = 0.0f;
+        if (hipEventSynchronize(ev[2]) != hipSuccess || hipEventElapsedTime(&a, ev[0], ev[1]) != hipSuccess ||
+            hipEventElapsedTime(&b, ev[0], ev[2]) != hipSuccess)
+            return i;
+        out[i].main_kernel_ms = a;
+        out[i].total_ms = b;
+    }
+    return n;
 }
 
 gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_out, void* stream) {

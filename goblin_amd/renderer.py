@@ -71,6 +71,12 @@ class HipPathTracer:
             except Exception:
                 pass
 
+    def timings(self, n=1):
+        """Device times (ms) of the last n render() calls, most recent first: list of (main_kernel_ms, total_ms)."""
+        buf = (_abi.gbl_timing * n)()
+        got = self.lib.gbl_get_timings(self.handle, n, buf)
+        return [(buf[i].main_kernel_ms, buf[i].total_ms) for i in range(got)]
+
     def new_film(self):
         return Film(self.info.xres, self.info.yres, self.device)
 

@@ -232,6 +232,7 @@ typedef enum gbl_sample_mode {
 /* How the device schedules the same arithmetic (identical per-sample radiance):
  *  WAVEFRONT   path pool in HBM, compacted ray queues, extend / shade / shadow kernels
  *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration */
+#define GBL_AUTO_WAVEFRONT_DEPTH 12 /* AUTO: max_ray_depth >= this -> WAVEFRONT, else MEGAKERNEL */
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,
     GBL_SCHEDULE_MEGAKERNEL = 1,
@@ -298,6 +299,17 @@ gbl_status gbl_film_allreduce(gbl_ctx* ctx, void* rccl_comm, float* film_accum, 
 
 /* Device-side Film::writeImage normalise: rgb_out[W*H*3] = rgb / weight. */
 gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_out, void* stream);
+
+/* Device time of recent gbl_render calls, from HIP events recorded on the render stream
+ * around the dominant kernel and around the whole call (no host synchronisation happens
+ * inside gbl_render for this).  out[0] is the most recent call.  Blocks until those events
+ * have completed.  Returns the number of entries filled (at most 64 calls are remembered). */
+typedef struct gbl_timing {
+    double main_kernel_ms; /* path_trace_kernel / ao_kernel (megakernel schedule) or all
+                              wf_* kernels of the call (wavefront schedule)            */
+    double total_ms;       /* main kernel(s) + film splat kernel                        */
+} gbl_timing;
+int gbl_get_timings(gbl_ctx* ctx, int n, gbl_timing* out);
 
 /* Scene facts the caller needs for buffer sizing and reporting. */
 typedef struct gbl_info {
