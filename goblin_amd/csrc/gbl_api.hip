@@ -122,6 +122,10 @@ gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     WF_A(sh_o, pool); WF_A(sh_d, pool); WF_A(sh_c, pool); WF_A(sh_count, pool / 64);
     WF_A(live_flags, 8);
     WF_A(wave_next, pool / 64);
+    {   // stack levels beyond the LDS part, one column per thread of the largest persistent trace grid (8 WGs per CU)
+        const size_t deep = ctx->scene.stack_entries > GBL_WF_STACK_LDS ? ctx->scene.stack_entries - GBL_WF_STACK_LDS : 1;
+        WF_A(stack_spill, deep * static_cast<size_t>(ctx->num_cus) * 8 * GBL_BLOCK);
+    }
 #undef WF_A
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_flags), 8 * sizeof(uint32_t)) != hipSuccess) {
         ctx->error = "hipHostMalloc(wavefront flags) failed";
@@ -179,7 +183,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
         const uint32_t waves = pool / 64, blocks = (total + 63) / 64;
         wa.paths_per_wave = ((blocks + waves - 1) / waves) * 64;
     }
-    const size_t lds_stack = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+    const size_t lds_stack = static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t);
     const int tp = GBL_TILE + 2 * sc.film.halo;
     const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
     auto k_ext = want_stats ? wf_trace<false, true> : wf_trace<false, false>;
@@ -189,6 +193,8 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     int occ_ext = 0, occ_shd = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ext, reinterpret_cast<const void*>(k_ext), GBL_BLOCK, lds_stack) != hipSuccess || occ_ext < 1) occ_ext = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_shd, reinterpret_cast<const void*>(k_shd), GBL_BLOCK, lds_stack) != hipSuccess || occ_shd < 1) occ_shd = 1;
+    occ_ext = std::min(occ_ext, 8);   // stack_spill is sized for 8 workgroups per CU
+    occ_shd = std::min(occ_shd, 8);
     const uint64_t max_wgs = (pool / 64 + 3) / 4;
     unsigned ext_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_ext, max_wgs)));
     unsigned shd_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_shd, max_wgs)));

@@ -100,13 +100,38 @@ struct TravState {
     Hit hit;
 };
 
-__device__ __forceinline__ void trav_begin(const DevScene& sc, TravState& st, F3 o, F3 d, float mint, float maxt, uint32_t* stk) {
+// Traversal stacks.  LdsStack: the whole per-lane stack in LDS, column-major over the workgroup (megakernel, AO).
+// SplitStack: the first GBL_WF_STACK_LDS levels in LDS and the (rarely reached) deeper ones in a global backing
+// column, so the trace kernels of the wavefront schedule fit more workgroups per CU (44 KB -> 16 KB of LDS).
+struct LdsStack {
+    uint32_t* p;
+    __device__ __forceinline__ void store(int i, uint32_t v) const { p[i * GBL_BLOCK] = v; }
+    __device__ __forceinline__ uint32_t load(int i) const { return p[i * GBL_BLOCK]; }
+};
+#ifndef GBL_WF_STACK_LDS
+#define GBL_WF_STACK_LDS 16
+#endif
+struct SplitStack {
+    uint32_t* p;        // LDS column of this lane
+    uint32_t* g;        // global backing column of this thread
+    uint32_t gstride;   // threads in the grid
+    __device__ __forceinline__ void store(int i, uint32_t v) const {
+        if (i < GBL_WF_STACK_LDS) p[i * GBL_BLOCK] = v;
+        else g[static_cast<size_t>(i - GBL_WF_STACK_LDS) * gstride] = v;
+    }
+    __device__ __forceinline__ uint32_t load(int i) const {
+        return i < GBL_WF_STACK_LDS ? p[i * GBL_BLOCK] : g[static_cast<size_t>(i - GBL_WF_STACK_LDS) * gstride];
+    }
+};
+
+template <class STK>
+__device__ __forceinline__ void trav_begin(const DevScene& sc, TravState& st, F3 o, F3 d, float mint, float maxt, const STK& stk) {
     ray_space(st.world, o, d);
     st.r = st.world;
     st.mint = mint;
     st.maxt = maxt;
     st.sp = 0;
-    stk[(st.sp++) * GBL_BLOCK] = GBL_STACK_EXIT;
+    stk.store(st.sp++, GBL_STACK_EXIT);
     st.cur = sc.num_instances > 0 ? sc.tlas_root : GBL_STACK_EXIT;
     st.inst = -1;
     st.hit.t = INFINITY;
@@ -140,8 +165,8 @@ __device__ __forceinline__ float child_entry(uint32_t nx, uint32_t ny, uint32_t 
     } while (0)
 
 // Interior step: st.cur must be an interior node reference.
-template <bool STATS>
-__device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st, uint32_t* stk, LaneCounters& cnt) {
+template <bool STATS, class STK>
+__device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt) {
     const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
     const uint4 w0 = np[0];   // o.x o.y o.z scale.x
     const uint4 w1 = np[1];   // scale.y scale.z qlo.x qlo.y
@@ -173,13 +198,13 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
     GBL_CSWAP(t1, r1, t2, r2);
     // nearest child next; push the others farthest first
     int sp = st.sp;
-    if (t3 < INFINITY) stk[(sp++) * GBL_BLOCK] = static_cast<uint32_t>(r3);
-    if (t2 < INFINITY) stk[(sp++) * GBL_BLOCK] = static_cast<uint32_t>(r2);
-    if (t1 < INFINITY) stk[(sp++) * GBL_BLOCK] = static_cast<uint32_t>(r1);
+    if (t3 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r3));
+    if (t2 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r2));
+    if (t1 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r1));
     if (t0 < INFINITY) {
         st.cur = r0;
     } else {
-        st.cur = static_cast<int>(stk[(--sp) * GBL_BLOCK]);
+        st.cur = static_cast<int>(stk.load(--sp));
     }
     st.sp = sp;
 }
@@ -187,15 +212,15 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
 // Everything that is not an interior node: exit marker, instance sentinel, instance entry,
 // triangle leaf.  Returns true when the ray is finished (for ANY: as soon as a triangle is
 // accepted, with *occluded set).
-template <bool ANY, bool STATS>
-__device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, uint32_t* stk, LaneCounters& cnt, bool* occluded) {
+template <bool ANY, bool STATS, class STK>
+__device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded) {
     const int cur = st.cur;
     if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
     if (cur == GBL_STACK_EXIT) return true;
     if (cur == GBL_STACK_SENTINEL) {   // finished an instance: back to the world ray
         st.r = st.world;
         st.inst = -1;
-        st.cur = static_cast<int>(stk[(--st.sp) * GBL_BLOCK]);
+        st.cur = static_cast<int>(stk.load(--st.sp));
         return false;
     }
     const uint32_t ref = ~static_cast<uint32_t>(cur);
@@ -203,7 +228,7 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, ui
         st.inst = static_cast<int>(ref >> 2);
         const DevInstance* ip = sc.instances + st.inst;
         ray_space(st.r, xf_point(ip->inv, st.world.o), xf_vector(ip->inv, st.world.d));
-        stk[(st.sp++) * GBL_BLOCK] = GBL_STACK_SENTINEL;
+        stk.store(st.sp++, GBL_STACK_SENTINEL);
         st.cur = ip->root;
         return false;
     }
@@ -224,7 +249,7 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, ui
             st.hit.b2 = b2;
         }
     }
-    st.cur = static_cast<int>(stk[(--st.sp) * GBL_BLOCK]);
+    st.cur = static_cast<int>(stk.load(--st.sp));
     return false;
 }
 
@@ -242,8 +267,8 @@ __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
 
 // ANY = true : Scene::occluded (first accepted triangle ends the query)
 // ANY = false: Scene::intersect (closest hit; hit.t shrinks like ray.maxt)
-template <bool ANY, bool STATS>
-__device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, uint32_t* stk, Hit& hit,
+template <bool ANY, bool STATS, class STK>
+__device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
                                       LaneCounters& cnt) {
     TravState st;
     trav_begin(sc, st, o, d, mint, maxt, stk);

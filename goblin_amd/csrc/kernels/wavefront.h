@@ -52,6 +52,7 @@ struct WfArgs {
     uint32_t* wave_next;  // per shade-wave cursor into that wave's contiguous list of path ids (no atomics:
                           // only the owning wave ever touches its word)
     uint32_t paths_per_wave;
+    uint32_t* stack_spill; // global backing of the trace kernels' stacks beyond GBL_WF_STACK_LDS levels (SplitStack)
     uint32_t* live_flags; // [8]: set by wf_shade when any of its slots is still alive
     float4* li_buf;       // per-sample radiance of the pass, pixel-major: pixel * pass_spp + kk
     uint32_t pool_size;   // P, multiple of 256
@@ -103,7 +104,8 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 template <bool ANY, bool STATS>
 __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+    const SplitStack stk = {reinterpret_cast<uint32_t*>(smem) + threadIdx.x, wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x,
+                            gridDim.x * GBL_BLOCK};
     LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int lane = threadIdx.x & 63;
     const uint32_t n_regions = wa.pool_size / 64u;

@@ -2,7 +2,8 @@
 import sys, os, subprocess, json
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
-import sys, json, torch
+import sys, json, torch, os
+SCHED = os.environ.get('GBL_SCHED', 'megakernel')
 sys.path.insert(0, %r)
 from goblin_amd import scene as gs
 from goblin_amd.renderer import HipPathTracer
@@ -14,10 +15,10 @@ for sc_name, ov in [("bunny", gs.config_overrides(resolution=(512, 512), spp=256
     best = 1e30
     for i in range(3):
         film.zero_()
-        out = tr.render(film=film, seed=1, stats=False, timed=True, schedule="megakernel")
+        out = tr.render(film=film, seed=1, stats=False, timed=True, schedule=SCHED)
         torch.cuda.synchronize()
         best = min(best, out["stats"]["kernel_ms"])
-    print(json.dumps({"scene": sc_name, "ms": round(best, 2), "mean": float(film.normalized().mean())}), flush=True)
+    print(json.dumps({"scene": sc_name, "schedule": SCHED, "ms": round(best, 2), "mean": float(film.normalized().mean())}), flush=True)
 ''' % REPO
 for lib in sys.argv[1:]:
     env = dict(os.environ, GOBLIN_HIP_LIB=os.path.join(REPO, "goblin_amd", "lib", lib))
