@@ -10,13 +10,15 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 1
+GBL_ABI_VERSION = 2
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM = range(6)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM"}
 
 GBL_MAT_LAMBERT, GBL_MAT_BLINN, GBL_MAT_TRANSPARENT, GBL_MAT_MIRROR = range(4)
-GBL_LIGHT_POINT, GBL_LIGHT_SPOT, GBL_LIGHT_AREA = 0, 2, 3
+GBL_LIGHT_POINT, GBL_LIGHT_DIRECTIONAL, GBL_LIGHT_SPOT, GBL_LIGHT_AREA = 0, 1, 2, 3
+GBL_SHAPE_MESH, GBL_SHAPE_SPHERE, GBL_SHAPE_DISK = 0, 1, 2
+GBL_CAMERA_PERSPECTIVE, GBL_CAMERA_ORTHOGRAPHIC = 0, 1
 GBL_FILTER_BOX, GBL_FILTER_TRIANGLE, GBL_FILTER_GAUSSIAN, GBL_FILTER_MITCHELL = range(4)
 GBL_INTEGRATOR_PATH, GBL_INTEGRATOR_AO = 0, 1
 GBL_SAMPLES_NATIVE, GBL_SAMPLES_REPLAY = 0, 1
@@ -35,7 +37,8 @@ class gbl_trs(C.Structure):
 
 class gbl_mesh(C.Structure):
     _fields_ = [("vertex_offset", C.c_uint32), ("vertex_count", C.c_uint32), ("tri_offset", C.c_uint32),
-                ("tri_count", C.c_uint32), ("has_normal", C.c_uint32), ("has_uv", C.c_uint32)]
+                ("tri_count", C.c_uint32), ("has_normal", C.c_uint32), ("has_uv", C.c_uint32),
+                ("shape", C.c_uint32), ("radius", C.c_float)]
 
 
 class gbl_material(C.Structure):
@@ -56,7 +59,7 @@ class gbl_light(C.Structure):
 class gbl_camera(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("orientation", C.c_float * 4), ("fov_degrees", C.c_float),
                 ("near_plane", C.c_float), ("far_plane", C.c_float), ("lens_radius", C.c_float),
-                ("focal_distance", C.c_float)]
+                ("focal_distance", C.c_float), ("type", C.c_uint32), ("film_width", C.c_float)]
 
 
 class gbl_film(C.Structure):

@@ -37,6 +37,11 @@ struct DevNode {
     int32_t child[4];     // unused slots: GBL_REF_NONE with qlo = 255, qhi = 0 (an empty interval for every ray)
 };
 #define GBL_REF_NONE 0x7ffffffd
+// BLAS "roots" of analytic shapes: leaf references whose first-triangle field is out of range
+#define GBL_SHAPE_FIRST_SPHERE 0x1fffffffu
+#define GBL_SHAPE_FIRST_DISK 0x1ffffffeu
+#define GBL_REF_SPHERE (~static_cast<int32_t>(GBL_SHAPE_FIRST_SPHERE << 2))
+#define GBL_REF_DISK (~static_cast<int32_t>(GBL_SHAPE_FIRST_DISK << 2))
 
 struct DevTri {
     float p0[3];
@@ -59,7 +64,9 @@ struct DevInstance {
     int32_t material;
     int32_t area_light;
     int32_t mesh;
-    int32_t pad[4];
+    uint32_t shape;     // gbl_shape: 0 triangles below `root`; sphere / disk are tested analytically (root = GBL_REF_SPHERE/DISK)
+    float radius;
+    int32_t pad[2];
 };
 
 struct DevMaterial {
@@ -90,14 +97,18 @@ struct DevLight {
     float m[12], inv[12];   // area: light toWorld / inverse
     uint32_t tri_first, tri_count;   // into light_tris
     float sum_area;
-    float pad;
+    uint32_t shape;         // area: gbl_shape of the emitting geometry
+    float radius;           // area: sphere / disk radius
+    float pad[3];
 };
 
 struct DevCamera {
     float pos[3];
     float proj00;
     float q[4];       // w x y z
-    float proj11, inv_xres, inv_yres, pad;
+    float proj11, inv_xres, inv_yres;
+    uint32_t type;    // gbl_camera_type
+    float lens_radius, focal_distance, film_w, film_h;   // thin lens; orthographic film size in world units
 };
 
 struct DevFilm {
@@ -126,6 +137,7 @@ struct DevScene {
     int32_t num_instances;
     int32_t num_lights;
     int32_t stack_entries;        // traversal stack depth this scene needs
+    int32_t extended;             // scene uses analytic shapes, a directional light or a non-pinhole camera: EXT kernels
     DevCamera camera;
     DevFilm film;
 };

@@ -186,8 +186,11 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     const size_t lds_stack = static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t);
     const int tp = GBL_TILE + 2 * sc.film.halo;
     const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
-    auto k_ext = want_stats ? wf_trace<false, true> : wf_trace<false, false>;
-    auto k_shd = want_stats ? wf_trace<true, true> : wf_trace<true, false>;
+    // EXT kernels carry the analytic shapes / directional light / non-pinhole cameras; plain scenes run the lean
+    // build.  Instrumented launches always use the EXT build (same work, same counters).
+    const bool ext = sc.extended != 0;
+    auto k_ext = want_stats ? wf_trace<false, true, true> : (ext ? wf_trace<false, false, true> : wf_trace<false, false, false>);
+    auto k_shd = want_stats ? wf_trace<true, true, true> : (ext ? wf_trace<true, false, true> : wf_trace<true, false, false>);
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
     // workgroup that has to wait for a free CU would serialise its share), never more waves than regions
     int occ_ext = 0, occ_shd = 0;
@@ -199,8 +202,8 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     unsigned ext_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_ext, max_wgs)));
     unsigned shd_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_shd, max_wgs)));
     dim3 block(GBL_BLOCK), grid_ext(ext_wgs), grid_shd(shd_wgs), grid_shade(pool / GBL_BLOCK);
-    auto k_shade = replay ? (want_stats ? wf_shade<true, true> : wf_shade<true, false>)
-                          : (want_stats ? wf_shade<false, true> : wf_shade<false, false>);
+    auto k_shade = replay ? (want_stats ? wf_shade<true, true, true> : (ext ? wf_shade<true, false, true> : wf_shade<true, false, false>))
+                          : (want_stats ? wf_shade<false, true, true> : (ext ? wf_shade<false, false, true> : wf_shade<false, false, false>));
     auto k_splat = replay ? (want_stats ? wf_splat<true, true> : wf_splat<true, false>)
                           : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
     if (lds_stack > 64 * 1024) {
@@ -307,6 +310,7 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     sc.num_instances = static_cast<int32_t>(packed.instances.size());
     sc.num_lights = static_cast<int32_t>(packed.lights.size());
     sc.stack_entries = packed.stack_entries;
+    sc.extended = packed.extended;
     sc.camera = packed.camera;
     sc.film = packed.film;
     void* p = nullptr;
@@ -486,13 +490,14 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         // persistent grid: enough workgroups to fill every CU at the occupancy LDS allows, never more than items
         uint64_t grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * per_cu);
         dim3 grid(static_cast<unsigned>(grid64)), block(GBL_BLOCK);
+        const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
         if (p->integrator == GBL_INTEGRATOR_PATH) {
-            kernel = replay ? (want_stats ? path_trace_kernel<true, true> : path_trace_kernel<true, false>)
-                            : (want_stats ? path_trace_kernel<false, true> : path_trace_kernel<false, false>);
+            kernel = replay ? (want_stats ? path_trace_kernel<true, true, true> : (ext ? path_trace_kernel<true, false, true> : path_trace_kernel<true, false, false>))
+                            : (want_stats ? path_trace_kernel<false, true, true> : (ext ? path_trace_kernel<false, false, true> : path_trace_kernel<false, false, false>));
         } else {
-            kernel = replay ? (want_stats ? ao_kernel<true, true> : ao_kernel<true, false>)
-                            : (want_stats ? ao_kernel<false, true> : ao_kernel<false, false>);
+            kernel = replay ? (want_stats ? ao_kernel<true, true, true> : (ext ? ao_kernel<true, false, true> : ao_kernel<true, false, false>))
+                            : (want_stats ? ao_kernel<false, true, true> : (ext ? ao_kernel<false, false, true> : ao_kernel<false, false, false>));
         }
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -331,6 +331,7 @@ namespace {
 
 struct GeometryDecl {
     std::string type, file;
+    float radius = 1.0f;
     int mesh_id = -1;
 };
 struct TextureDecl {
@@ -352,6 +353,7 @@ public:
         gbl_status st;
         if ((st = read_setting()) != GBL_OK) return st;
         if ((st = read_camera()) != GBL_OK) return st;
+        if ((st = add_lens()) != GBL_OK) return st;
         if (root_.find("volume")) return fail(GBL_ERR_UNSUPPORTED, "participating media (\"volume\") are outside the device path");
         read_geometries();
         read_textures();
@@ -370,6 +372,7 @@ private:
     std::map<std::string, int> material_ids_;  // resolved materials by name
     std::map<std::string, ModelDecl> primitives_;
     std::map<std::string, int> area_lights_;   // name -> light index
+    std::string camera_type_;
 
     std::string resolve(const std::string& f) const {
         if (!f.empty() && (f[0] == '/' || (f.size() > 1 && f[1] == ':'))) return f;
@@ -406,8 +409,10 @@ private:
         const gbl_json::Value* cam = root_.find("camera");
         Params p(cam);
         std::string type = p.get_string("type");
-        if (type == "orthographic") return fail(GBL_ERR_UNSUPPORTED, "orthographic camera is outside the device path");
         gbl_camera& c = s_->desc.camera;
+        c.type = type == "orthographic" ? GBL_CAMERA_ORTHOGRAPHIC : GBL_CAMERA_PERSPECTIVE;   // unknown -> perspective
+        c.film_width = p.get_float("film_width", 35.0f);
+        camera_type_ = type;
         Vec pos = p.get_vec(p.vec3s, "position", vec(0, 0, 0));
         for (int i = 0; i < 3; ++i) c.position[i] = pos.v[i];
         std::string err;
@@ -417,8 +422,6 @@ private:
         c.far_plane = p.get_float("far_plane", 1000.0f);
         c.lens_radius = p.get_float("lens_radius", 0.0f);
         c.focal_distance = p.get_float("focal_distance", 1.0f);
-        if (c.lens_radius != 0.0f)
-            return fail(GBL_ERR_UNSUPPORTED, "thin-lens camera (lens_radius != 0) adds a Disk primitive to the scene; outside the device path");
 
         Params fp(cam ? cam->find("film") : nullptr);
         gbl_film& f = s_->desc.film;
@@ -444,6 +447,41 @@ private:
         return GBL_OK;
     }
 
+    // createCamera (GoblinContextLoader.cpp:146-176): a camera with "lens_radius" != 0 -- whatever its type --
+    // puts a black-lambert Disk of that radius into the scene, instanced with the camera's own transform.
+    // It is the first geometry, material and instance of the scene.
+    gbl_status add_lens() {
+        const gbl_json::Value* cam = root_.find("camera");
+        Params p(cam);
+        float lens_radius = p.get_float("lens_radius", 0.0f);
+        if (lens_radius == 0.0f) return GBL_OK;
+        GeometryDecl g;
+        g.type = "disk";
+        g.radius = lens_radius;
+        const std::string gname = camera_type_ + "_lens_geom";
+        geometries_.insert({gname, g});
+        gbl_material black;
+        memset(&black, 0, sizeof(black));
+        black.type = GBL_MAT_LAMBERT;
+        material_ids_[camera_type_ + "_lens_material"] = static_cast<int>(s_->materials.size());
+        s_->materials.push_back(black);
+        ModelDecl d;
+        d.geometry = gname;
+        d.material = camera_type_ + "_lens_material";
+        primitives_.insert({camera_type_ + "_lens_model", d});
+        gbl_instance inst;
+        memset(&inst, 0, sizeof(inst));
+        int mesh;
+        gbl_status st = mesh_id(gname, &mesh);
+        if (st != GBL_OK) return st;
+        inst.mesh = mesh;
+        inst.material = material_ids_[d.material];
+        inst.area_light = -1;
+        read_trs(p, &inst.to_world);   // createInstance(cameraParams): position / orientation / scale of the camera block
+        s_->instances.push_back(inst);
+        return GBL_OK;
+    }
+
     void read_geometries() {
         const gbl_json::Value* l = list("geometries");
         if (!l) return;
@@ -452,6 +490,7 @@ private:
             GeometryDecl d;
             d.type = p.get_string("type");
             d.file = p.get_string("file");
+            d.radius = p.get_float("radius", 1.0f);
             geometries_.insert({p.get_string("name"), d});
         }
     }
@@ -551,13 +590,25 @@ private:
         auto it = geometries_.find(geometry);
         if (it == geometries_.end()) return fail(GBL_ERR_INVALID, "Geometry " + geometry + " not defined!");
         GeometryDecl& g = it->second;
-        if (g.type != "mesh") return fail(GBL_ERR_UNSUPPORTED, "geometry type \"" + g.type + "\" is outside the device path (mesh only)");
+        if (g.mesh_id < 0 && g.type != "mesh") {
+            // createGeometries (:226-234): "sphere", "disk", and a sphere for any unknown type
+            gbl_mesh m;
+            memset(&m, 0, sizeof(m));
+            m.shape = g.type == "disk" ? GBL_SHAPE_DISK : GBL_SHAPE_SPHERE;
+            m.radius = g.radius;
+            m.vertex_offset = static_cast<uint32_t>(s_->positions.size() / 3);
+            m.tri_offset = static_cast<uint32_t>(s_->indices.size() / 3);
+            g.mesh_id = static_cast<int>(s_->meshes.size());
+            s_->meshes.push_back(m);
+        }
         if (g.mesh_id < 0) {
             MeshData md;
             std::string err;
             if (!load_obj(resolve(g.file), &md, &err)) return fail(GBL_ERR_IO, err);
             if (md.idx.empty()) return fail(GBL_ERR_INVALID, "mesh " + g.file + " has no faces");
             gbl_mesh m;
+            memset(&m, 0, sizeof(m));
+            m.shape = GBL_SHAPE_MESH;
             m.vertex_offset = static_cast<uint32_t>(s_->positions.size() / 3);
             m.vertex_count = static_cast<uint32_t>(md.pos.size() / 3);
             m.tri_offset = static_cast<uint32_t>(s_->indices.size() / 3);
@@ -642,8 +693,16 @@ private:
             memset(&lt, 0, sizeof(lt));
             lt.to_world.orientation[0] = 1.0f;
             lt.to_world.scale[0] = lt.to_world.scale[1] = lt.to_world.scale[2] = 1.0f;
-            if (type == "directional" || type == "ibl") {
+            if (type == "ibl") {
                 return fail(GBL_ERR_UNSUPPORTED, "light type \"" + type + "\" is outside the device path");
+            } else if (type == "directional") {
+                lt.type = GBL_LIGHT_DIRECTIONAL;   // createDirectionalLight, GoblinLight.cpp:640-646
+                Vec R = p.get_vec(p.vec3s, "radiance", vec(0, 0, 0));
+                Vec D = p.get_vec(p.vec3s, "direction", vec(0, 0, 0));
+                for (int i = 0; i < 3; ++i) {
+                    lt.color[i] = R.v[i];
+                    lt.direction[i] = D.v[i];
+                }
             } else if (type == "spot") {
                 lt.type = GBL_LIGHT_SPOT;
                 Vec I = p.get_vec(p.vec3s, "intensity", vec(0, 0, 0));

@@ -40,21 +40,48 @@ __device__ __forceinline__ ItemInfo decode_item(const RenderArgs& ra, uint32_t i
     return it;
 }
 
-// PerspectiveCamera::generateRay, pinhole branch
-__device__ __forceinline__ void camera_ray(const DevCamera& c, float image_x, float image_y, F3* o, F3* d) {
-    float xndc = +2.0f * image_x * c.inv_xres - 1.0f;
-    float yndc = -2.0f * image_y * c.inv_yres + 1.0f;
-    float xv = xndc / c.proj00;
-    float yv = yndc / c.proj11;
-    F3 v = normalize(f3(xv, yv, 1.0f));
-    // Quaternion * Vector3 (GoblinQuaternion.cpp:86-92)
-    F3 qv = f3(c.q[1], c.q[2], c.q[3]);
+// Quaternion * Vector3 (GoblinQuaternion.cpp:86-92)
+__device__ __forceinline__ F3 quat_rotate(const float q[4], F3 v) {
+    F3 qv = f3(q[1], q[2], q[3]);
     F3 uv = cross(qv, v);
     F3 uuv = cross(qv, uv);
-    uv = uv * (2.0f * c.q[0]);
+    uv = uv * (2.0f * q[0]);
     uuv = uuv * 2.0f;
-    *o = f3(c.pos[0], c.pos[1], c.pos[2]);
-    *d = v + uv + uuv;
+    return v + uv + uuv;
+}
+
+// Camera::generateRay: PerspectiveCamera pinhole / thin lens (GoblinCamera.cpp:97-148) and, in EXT builds,
+// OrthographicCamera (:298-326).  lens_u* are Sample::lensU1/2 (only read by the thin lens).
+template <bool EXT>
+__device__ __forceinline__ void camera_ray(const DevCamera& c, float image_x, float image_y, float lens_u1, float lens_u2, F3* o, F3* d,
+                                           float* mint) {
+    float xndc = +2.0f * image_x * c.inv_xres - 1.0f;
+    float yndc = -2.0f * image_y * c.inv_yres + 1.0f;
+    const F3 pos = f3(c.pos[0], c.pos[1], c.pos[2]);
+    *mint = 1e-3f;
+    if (EXT && c.type == 1u) {
+        float xv = 0.5f * c.film_w * xndc;
+        float yv = 0.5f * c.film_h * yndc;
+        *o = pos + quat_rotate(c.q, f3(xv, yv, 0.0f));
+        *d = quat_rotate(c.q, f3(0.0f, 0.0f, 1.0f));
+        *mint = 0.0f;
+        return;
+    }
+    float xv = xndc / c.proj00;
+    float yv = yndc / c.proj11;
+    F3 view = f3(xv, yv, 1.0f);
+    if (EXT && c.lens_radius != 0.0f) {
+        float ft = c.focal_distance / view.z;
+        F3 p_focus = view * ft;
+        float lx, ly;
+        uniform_sample_disk(lens_u1, lens_u2, &lx, &ly);
+        F3 view_origin = f3(c.lens_radius * lx, c.lens_radius * ly, 0.0f);
+        *o = quat_rotate(c.q, view_origin) + pos;
+        *d = quat_rotate(c.q, normalize(p_focus - view_origin));
+        return;
+    }
+    *o = pos;
+    *d = quat_rotate(c.q, normalize(view));
 }
 
 // ImageTile::addSample into the LDS tile.  tile origin (tx0, ty0), row pitch tp pixels.
@@ -143,7 +170,7 @@ struct PathState {
     uint32_t path;      // index of this path inside the work item
 };
 
-template <bool REPLAY, bool STATS>
+template <bool REPLAY, bool STATS, bool EXT>
 __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
@@ -212,8 +239,16 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                         image_x = px + u;
                         image_y = py + v;
                     }
-                    camera_ray(sc.camera, image_x, image_y, &ps.o, &ps.d);
-                    ps.mint = 1e-3f;
+                    float lens_u1 = 0.0f, lens_u2 = 0.0f;
+                    if (EXT && sc.camera.lens_radius != 0.0f) {
+                        if (REPLAY) {
+                            lens_u1 = src.rec[2];
+                            lens_u2 = src.rec[3];
+                        } else {
+                            src.native_2d(1u, 1u, 0u, true, &lens_u1, &lens_u2);
+                        }
+                    }
+                    camera_ray<EXT>(sc.camera, image_x, image_y, lens_u1, lens_u2, &ps.o, &ps.d, &ps.mint);
                     ps.throughput = f3(1.0f, 1.0f, 1.0f);
                     ps.Li = f3(0.0f, 0.0f, 0.0f);
                     ps.bounce = -1;
@@ -233,13 +268,13 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 if (sc.num_lights == 0) {
                     finished = true;   // PathTracer::Li returns Black without lights (:53-56)
                 } else {
-                    got = trace<false, STATS>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
+                    got = trace<false, STATS, EXT>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
                     if (STATS) cnt.ext += 1;
                 }
             }
             Frag fr;
             if (active && !finished) {
-                if (got) make_fragment(sc, hit, ps.o, ps.d, fr);
+                if (got) make_fragment<EXT>(sc, hit, ps.o, ps.d, fr);
                 if (ps.bounce < 0) {
                     if (!got) {
                         finished = true;   // no image based light on this path: evalEnvironmentLight == 0
@@ -302,7 +337,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 mat = sc.materials + sc.instances[hit.inst].material;
                 const DevLight& light = sc.lights[li];
                 LightSampleOut ls;
-                light_sample(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
+                light_sample<EXT>(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
                 if (!is_black(ls.L) && ls.pdf > 0.0f) {
                     F3 f = mat_bsdf(*mat, fr.n, wo, ls.wi);
                     if (!is_black(f)) {
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             // ---- shadow query (any-hit)
             if (need_shadow) {
                 Hit dummy;
-                bool occluded = trace<true, STATS>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt);
+                bool occluded = trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt);
                 if (STATS) cnt.shadow += 1;
                 if (!occluded) ps.Ld = f3(ps.Ld.x + contrib.x, ps.Ld.y + contrib.y, ps.Ld.z + contrib.z);
             }
@@ -334,7 +369,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 F3 f = mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
                 if (!is_black(f) && pdf > 0.0f) {
                     float fw = 1.0f;
-                    if (!specular) fw = power_heuristic(pdf, light_pdf(sc, sc.lights[ps.light], fr.p, wi));
+                    if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
                     ps.f = f;
                     ps.fw = fw;
                     ps.bsdf_pdf = pdf;
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
 // Ambient occlusion (AORenderer::Li): one closest hit, N uniform-hemisphere
 // any-hit rays, unoccluded fraction as grey radiance.
 // ---------------------------------------------------------------------------
-template <bool REPLAY, bool STATS>
+template <bool REPLAY, bool STATS, bool EXT>
 __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
@@ -444,17 +479,26 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
                 image_y = py + v;
             }
             F3 o, d;
-            camera_ray(sc.camera, image_x, image_y, &o, &d);
+            float cam_mint, lens_u1 = 0.0f, lens_u2 = 0.0f;
+            if (EXT && sc.camera.lens_radius != 0.0f) {
+                if (REPLAY) {
+                    lens_u1 = src.rec[2];
+                    lens_u2 = src.rec[3];
+                } else {
+                    src.native_2d(1u, 1u, 0u, true, &lens_u1, &lens_u2);
+                }
+            }
+            camera_ray<EXT>(sc.camera, image_x, image_y, lens_u1, lens_u2, &o, &d, &cam_mint);
             Hit hit;
             F3 L = f3(0, 0, 0);
-            bool got = trace<false, STATS>(sc, o, d, 1e-3f, INFINITY, stk, hit, cnt);
+            bool got = trace<false, STATS, EXT>(sc, o, d, cam_mint, INFINITY, stk, hit, cnt);
             if (STATS) {
                 cnt.ext += 1;
                 cnt.dims += 2;
             }
             if (got) {
                 Frag fr;
-                make_fragment(sc, hit, o, d, fr);
+                make_fragment<EXT>(sc, hit, o, d, fr);
                 uint32_t occluded = 0;
                 for (int i = 0; i < ra.ao_n; ++i) {
                     float u1, u2;
@@ -466,7 +510,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
                     }
                     F3 dir = shade_to_world(fr, uniform_sample_hemisphere(u1, u2));
                     Hit dummy;
-                    if (trace<true, STATS>(sc, fr.p, dir, fr.eps, INFINITY, stk, dummy, cnt)) occluded += 1;
+                    if (trace<true, STATS, EXT>(sc, fr.p, dir, fr.eps, INFINITY, stk, dummy, cnt)) occluded += 1;
                     if (STATS) cnt.shadow += 1;
                 }
                 if (STATS) cnt.dims += 2 * ra.ao_n;

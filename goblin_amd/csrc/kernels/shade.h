@@ -17,6 +17,7 @@
 #define GBL_MAT_TRANSPARENT 2u
 #define GBL_MAT_MIRROR 3u
 #define GBL_LIGHT_POINT 0u
+#define GBL_LIGHT_DIRECTIONAL 1u
 #define GBL_LIGHT_SPOT 2u
 #define GBL_LIGHT_AREA 3u
 
@@ -27,10 +28,25 @@ struct Frag {
 };
 
 // Rebuild the reference's Fragment for the closest hit and move it to world space.
+template <bool EXT>
 __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, F3 wo_origin, F3 w_dir, Frag& fr) {
     const DevInstance* ip = sc.instances + h.inst;
     // the object-space ray the triangle test saw (Transform::invertRay)
     F3 ro = xf_point(ip->inv, wo_origin), rd = xf_vector(ip->inv, w_dir);
+    if (EXT && ip->shape != 0u) {
+        // Sphere::intersect (GoblinSphere.cpp:32-86) / Disk::intersect (GoblinDisk.cpp:33-60): position, normal and
+        // dpdu are algebraic in the hit point; uv and dpdv (atan2 / acos) only feed textures and bump maps
+        F3 pos = ro + h.t * rd;
+        F3 nrm = ip->shape == 1u ? normalize(pos) : f3(0.0f, 0.0f, 1.0f);
+        F3 dpdu = f3(-GBL_TWO_PI * pos.y, GBL_TWO_PI * pos.x, 0.0f);
+        fr.p = xf_point(ip->m, pos);
+        fr.n = normalize(xf_normal(ip->inv, nrm));
+        F3 dpdu_w = xf_vector(ip->m, dpdu);
+        fr.t = normalize(dpdu_w - fr.n * dot(dpdu_w, fr.n));
+        fr.b = cross(fr.n, fr.t);
+        fr.eps = 1e-3f * h.t;
+        return;
+    }
     const DevTri* tp = sc.tris + h.tri;
     const float4 q0 = reinterpret_cast<const float4*>(tp)[0];
     const float4 q1 = reinterpret_cast<const float4*>(tp)[1];
@@ -272,10 +288,126 @@ struct LightSampleOut {
     float pdf, maxt;
 };
 
+// coordinateAxises, GoblinUtils.cpp:58-69
+__device__ __forceinline__ void coordinate_axes(F3 a1, F3* a2, F3* a3) {
+    if (fabsf(a1.x) > fabsf(a1.y)) {
+        float inv = 1.0f / sqrtf(a1.x * a1.x + a1.z * a1.z);
+        *a2 = f3(-a1.z * inv, 0.0f, a1.x * inv);
+    } else {
+        float inv = 1.0f / sqrtf(a1.y * a1.y + a1.z * a1.z);
+        *a2 = f3(0.0f, -a1.z * inv, a1.y * inv);
+    }
+    *a3 = cross(a1, *a2);
+}
+// uniformSampleDisk, GoblinSampler.cpp:565-602
+__device__ __forceinline__ void uniform_sample_disk(float u1, float u2, float* ox, float* oy) {
+    float r, theta;
+    float x = 2.0f * u1 - 1.0f;
+    float y = 2.0f * u2 - 1.0f;
+    if (x + y > 0) {
+        if (x > y) {
+            r = x;
+            theta = 0.25f * GBL_PI * (y / x);
+        } else {
+            r = y;
+            theta = 0.25f * GBL_PI * (2.0f - x / y);
+        }
+    } else {
+        if (x < y) {
+            r = -x;
+            theta = 0.25f * GBL_PI * (4.0f + y / x);
+        } else {
+            r = -y;
+            theta = y != 0.0f ? 0.25f * GBL_PI * (6.0f - x / y) : 0.0f;
+        }
+    }
+    *ox = r * cosf(theta);
+    *oy = r * sinf(theta);
+}
+// Geometry::pdf for an analytic emitter, light-local space (GoblinGeometry.cpp:44-62)
+__device__ __forceinline__ float light_shape_area_pdf(const DevLight& l, F3 p, F3 wi) {
+    float t;
+    const bool got = l.shape == 1u ? sphere_test(l.radius, p, wi, 1e-3f, INFINITY, &t) : disk_test(l.radius, p, wi, 1e-3f, INFINITY, &t);
+    if (!got) return 0.0f;
+    F3 pos = p + t * wi;
+    F3 nrm = l.shape == 1u ? normalize(pos) : f3(0.0f, 0.0f, 1.0f);
+    float pdf = sqlen(p - pos) / (l.sum_area * absdot(-wi, nrm));
+    if (isinf(pdf)) pdf = 0.0f;
+    return pdf;
+}
+// GeometrySet::pdf over one Sphere (Sphere::pdf, GoblinSphere.cpp:126-138) or Disk (Geometry::pdf)
+__device__ __forceinline__ float light_shape_pdf(const DevLight& l, F3 p, F3 wi) {
+    float g;
+    const float r2 = l.radius * l.radius, d2 = sqlen(p);
+    if (l.shape == 1u && !(d2 - r2 < 1e-4f)) {
+        float sin_max2 = r2 / d2;
+        float cos_max = sqrtf(fmaxf(0.0f, 1.0f - sin_max2));
+        g = 1.0f / (GBL_TWO_PI * (1.0f - cos_max));   // uniformConePdf
+    } else {
+        g = light_shape_area_pdf(l, p, wi);
+    }
+    float pdf = 0.0f;
+    pdf += l.sum_area * g;
+    pdf /= l.sum_area;
+    return pdf;
+}
+// Sphere::sample(p, u1, u2, &n) (GoblinSphere.cpp:109-124) / Disk::sample (GoblinDisk.cpp:76-80)
+__device__ __forceinline__ F3 light_shape_sample(const DevLight& l, F3 p, float u1, float u2, F3* normal) {
+    if (l.shape != 1u) {
+        *normal = f3(0.0f, 0.0f, 1.0f);
+        float x, y;
+        uniform_sample_disk(u1, u2, &x, &y);
+        return f3(l.radius * x, l.radius * y, 0.0f);
+    }
+    const float r2 = l.radius * l.radius, d2 = sqlen(p);
+    if (d2 - r2 < 1e-4f) {   // uniformSampleSphere
+        float z = 1.0f - 2.0f * u1;
+        float sin_t = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        float phi = GBL_TWO_PI * u2;
+        *normal = f3(sin_t * cosf(phi), sin_t * sinf(phi), z);
+        return l.radius * (*normal);
+    }
+    F3 z_axis = normalize(-p), x_axis, y_axis;
+    coordinate_axes(z_axis, &x_axis, &y_axis);
+    float sin_max2 = r2 / d2;
+    float cos_max = sqrtf(fmaxf(0.0f, 1.0f - sin_max2));
+    float cos_t = 1.0f - u1 + u1 * cos_max;
+    float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    float phi = GBL_TWO_PI * u2;
+    F3 d = x_axis * sin_t * cosf(phi) + y_axis * sin_t * sinf(phi) + z_axis * cos_t;
+    float t;
+    F3 p_hit;
+    if (sphere_test(l.radius, p, d, 1e-3f, INFINITY, &t)) p_hit = p + t * d;
+    else p_hit = p + (sqrtf(d2) * cos_max) * d;   // the ray scratches over the sphere's surface
+    *normal = normalize(p_hit);
+    return p_hit;
+}
+
 // light->sampleL(p, epsilon, ls, ...)
+template <bool EXT>
 __device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight& l, F3 p, float epsilon, float u_comp, float u1,
                                              float u2, LightSampleOut& o) {
     F3 color = f3(l.color[0], l.color[1], l.color[2]);
+    if (EXT && l.type == GBL_LIGHT_DIRECTIONAL) {   // DirectionalLight::sampleL, GoblinLight.cpp:145-154
+        o.wi = -f3(l.axis[0], l.axis[1], l.axis[2]);
+        o.pdf = 1.0f;
+        o.maxt = INFINITY;
+        o.L = color;
+        return;
+    }
+    if (EXT && l.type == GBL_LIGHT_AREA && l.shape != 0u) {   // AreaLight::sampleL over one analytic geometry
+        F3 p_local = xf_point(l.inv, p);
+        F3 ns_local;
+        F3 ps_local = light_shape_sample(l, p_local, u1, u2, &ns_local);
+        F3 wi_local = normalize(ps_local - p_local);
+        o.pdf = light_shape_pdf(l, p_local, wi_local);
+        F3 ps = xf_point(l.m, ps_local);
+        F3 ns = normalize(xf_normal(l.inv, ns_local));
+        o.wi = normalize(ps - p);
+        o.maxt = length(ps - p) - epsilon;
+        o.L = dot(ns, -o.wi) > 0.0f ? color : f3(0, 0, 0);
+        return;
+    }
     if (l.type == GBL_LIGHT_AREA) {
         F3 p_local = xf_point(l.inv, p);
         // CDF1D::sampleDiscrete: lower_bound(cdf, u) - 1, clamped at 0
@@ -321,8 +453,10 @@ __device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight&
 }
 
 // light->pdf(p, wi): 0 for delta lights, AreaLight::pdf otherwise (wi is NOT renormalised in light space)
+template <bool EXT>
 __device__ __forceinline__ float light_pdf(const DevScene& sc, const DevLight& l, F3 p, F3 wi) {
     if (l.type != GBL_LIGHT_AREA) return 0.0f;
+    if (EXT && l.shape != 0u) return light_shape_pdf(l, xf_point(l.inv, p), xf_vector(l.inv, wi));
     return light_geoset_pdf(sc, l, xf_point(l.inv, p), xf_vector(l.inv, wi));
 }
 

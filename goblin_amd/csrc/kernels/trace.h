@@ -212,7 +212,44 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
 // Everything that is not an interior node: exit marker, instance sentinel, instance entry,
 // triangle leaf.  Returns true when the ray is finished (for ANY: as soon as a triangle is
 // accepted, with *occluded set).
-template <bool ANY, bool STATS, class STK>
+// Sphere::intersect / occluded up to the accepted distance (GoblinSphere.cpp:12-31; quadratic, GoblinUtils.cpp:93-113)
+__device__ __forceinline__ bool sphere_test(float radius, F3 o, F3 d, float mint, float maxt, float* t_out) {
+    float A = sqlen(d);
+    float B = 2.0f * dot(d, o);
+    float C = sqlen(o) - radius * radius;
+    float disc = B * B - 4.0f * A * C;
+    if (disc < 0.0f) return false;
+    float root = sqrtf(disc);
+    float q = B < 0 ? -0.5f * (B - root) : -0.5f * (B + root);
+    float t1 = q / A, t2 = C / q;
+    if (t1 > t2) {
+        float tmp = t1;
+        t1 = t2;
+        t2 = tmp;
+    }
+    if (t1 > maxt || t2 < mint) return false;
+    float t_hit = t1;
+    if (t_hit < mint) {
+        t_hit = t2;
+        if (t_hit > maxt) return false;
+    }
+    *t_out = t_hit;
+    return true;
+}
+// Disk::intersect / occluded (GoblinDisk.cpp:12-31, 63-74)
+__device__ __forceinline__ bool disk_test(float radius, F3 o, F3 d, float mint, float maxt, float* t_out) {
+    if (fabsf(d.z) < 1e-7f) return false;
+    float t = -o.z / d.z;
+    F3 p = o + t * d;
+    if (t < mint || t > maxt) return false;
+    float square_r = p.x * p.x + p.y * p.y;
+    if (square_r > radius * radius) return false;
+    *t_out = t;
+    return true;
+}
+
+// EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
+template <bool ANY, bool STATS, bool EXT, class STK>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded) {
     const int cur = st.cur;
     if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
@@ -233,6 +270,26 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, co
         return false;
     }
     const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
+    if (EXT && first >= GBL_SHAPE_FIRST_DISK) {   // Model::intersect of an intersectable geometry (GoblinModel.cpp:46-54)
+        const float radius = sc.instances[st.inst].radius;
+        float t;
+        if (STATS) cnt.tris += 1;
+        const bool got = first == GBL_SHAPE_FIRST_SPHERE ? sphere_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t)
+                                                         : disk_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t);
+        if (got) {
+            if (ANY) {
+                *occluded = true;
+                return true;
+            }
+            st.maxt = t;
+            st.hit.t = t;
+            st.hit.inst = st.inst;
+            st.hit.tri = 0;
+            st.hit.b1 = st.hit.b2 = 0.0f;
+        }
+        st.cur = static_cast<int>(stk.load(--st.sp));
+        return false;
+    }
     for (uint32_t i = 0; i < count; ++i) {
         float t, b1, b2;
         if (STATS) cnt.tris += 1;
@@ -267,7 +324,7 @@ __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
 
 // ANY = true : Scene::occluded (first accepted triangle ends the query)
 // ANY = false: Scene::intersect (closest hit; hit.t shrinks like ray.maxt)
-template <bool ANY, bool STATS, class STK>
+template <bool ANY, bool STATS, bool EXT, class STK>
 __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
                                       LaneCounters& cnt) {
     TravState st;
@@ -280,7 +337,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
     for (;;) {
         if (trav_at_interior(st)) {
             trav_interior<STATS>(sc, st, stk, cnt);
-        } else if (trav_other<ANY, STATS>(sc, st, stk, cnt, &occluded)) {
+        } else if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded)) {
             break;
         }
     }

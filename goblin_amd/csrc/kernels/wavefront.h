@@ -101,7 +101,7 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 // ---------------------------------------------------------------------------
 #define WF_REFILL 16   // refill as soon as this many lanes of the wave are idle
 
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool EXT>
 __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     const SplitStack stk = {reinterpret_cast<uint32_t*>(smem) + threadIdx.x, wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x,
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
                 if (at_int) trav_interior<STATS>(sc, st, stk, cnt);
             } else if (at_oth) {
                 bool occluded = false;
-                if (trav_other<ANY, STATS>(sc, st, stk, cnt, &occluded)) {
+                if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded)) {
                     if (ANY) {
                         if (!occluded) {
                             float4 ld = wa.s_ld[slot];   // one shadow ray per slot per iteration: plain read-modify-write
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
 // ---------------------------------------------------------------------------
 // wf_shade: lane == slot.
 // ---------------------------------------------------------------------------
-template <bool REPLAY, bool STATS>
+template <bool REPLAY, bool STATS, bool EXT>
 __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra, WfArgs wa) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;   // grid covers the pool exactly
     const int lane = threadIdx.x & 63;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         if (sc.num_lights == 0) {
             finished = true;
         } else {
-            if (got) make_fragment(sc, hit, ps.o, ps.d, fr);
+            if (got) make_fragment<EXT>(sc, hit, ps.o, ps.d, fr);
             if (ps.bounce < 0) {
                 if (!got) {
                     finished = true;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         const DevMaterial* mat = sc.materials + sc.instances[hit.inst].material;
         const DevLight& light = sc.lights[li];
         LightSampleOut ls;
-        light_sample(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
+        light_sample<EXT>(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
         if (!is_black(ls.L) && ls.pdf > 0.0f) {
             F3 f = mat_bsdf(*mat, fr.n, wo, ls.wi);
             if (!is_black(f)) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         F3 f = mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
         if (!is_black(f) && pdf > 0.0f) {
             float fw = 1.0f;
-            if (!specular) fw = power_heuristic(pdf, light_pdf(sc, sc.lights[ps.light], fr.p, wi));
+            if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
             ps.f = f;
             ps.fw = fw;
             ps.bsdf_pdf = pdf;
@@ -420,8 +420,16 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                             image_x = pid.px + u;
                             image_y = pid.py + v;
                         }
-                        camera_ray(sc.camera, image_x, image_y, &ps.o, &ps.d);
-                        ps.mint = 1e-3f;
+                        float lens_u1 = 0.0f, lens_u2 = 0.0f;
+                        if (EXT && sc.camera.lens_radius != 0.0f) {
+                            if (REPLAY) {
+                                lens_u1 = src.rec[2];
+                                lens_u2 = src.rec[3];
+                            } else {
+                                src.native_2d(1u, 1u, 0u, true, &lens_u1, &lens_u2);
+                            }
+                        }
+                        camera_ray<EXT>(sc.camera, image_x, image_y, lens_u1, lens_u2, &ps.o, &ps.d, &ps.mint);
                         ps.throughput = f3(1.0f, 1.0f, 1.0f);
                         ps.Li = f3(0.0f, 0.0f, 0.0f);
                         ps.Ld = f3(0.0f, 0.0f, 0.0f);

@@ -396,9 +396,10 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         *err = "scene description has the wrong abi_version";
         return GBL_ERR_INVALID;
     }
-    if (d->camera.lens_radius != 0.0f) {
-        *err = "thin-lens camera is outside the device path";
-        return GBL_ERR_UNSUPPORTED;
+    out->extended = (d->camera.lens_radius != 0.0f || d->camera.type != GBL_CAMERA_PERSPECTIVE) ? 1 : 0;
+    if (d->camera.type > GBL_CAMERA_ORTHOGRAPHIC) {
+        *err = "unknown camera type";
+        return GBL_ERR_INVALID;
     }
     for (uint32_t i = 0; i < d->num_instances; ++i) {
         if (d->instances[i].mesh >= d->num_meshes || d->instances[i].material >= d->num_materials ||
@@ -409,6 +410,14 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     }
     for (uint32_t i = 0; i < d->num_meshes; ++i) {
         const gbl_mesh& m = d->meshes[i];
+        if (m.shape == GBL_SHAPE_SPHERE || m.shape == GBL_SHAPE_DISK) {
+            out->extended = 1;
+            continue;
+        }
+        if (m.shape != GBL_SHAPE_MESH) {
+            *err = "mesh " + std::to_string(i) + " has an unknown shape";
+            return GBL_ERR_INVALID;
+        }
         if (m.tri_count == 0 || static_cast<uint64_t>(m.vertex_offset) + m.vertex_count > d->num_vertices ||
             static_cast<uint64_t>(m.tri_offset) + m.tri_count > d->num_triangles) {
             *err = "mesh " + std::to_string(i) + " is empty or out of range";
@@ -451,6 +460,16 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->blas_max_depth = 0;
     for (uint32_t mi = 0; mi < d->num_meshes; ++mi) {
         const gbl_mesh& gm = d->meshes[mi];
+        if (gm.shape != GBL_SHAPE_MESH) {
+            // Sphere / Disk::getObjectBound (GoblinSphere.cpp:140-143, GoblinDisk.cpp:81-84); no BLAS: the
+            // instance's root is a marker reference and the traversal tests the shape analytically
+            const float r = gm.radius, z = gm.shape == GBL_SHAPE_SPHERE ? gm.radius : 0.0f;
+            float hi[3] = {r, r, z}, lo[3] = {-r, -r, -z};
+            mesh_bounds[mi].grow(hi);
+            mesh_bounds[mi].grow(lo);
+            mesh_root[mi] = gm.shape == GBL_SHAPE_SPHERE ? GBL_REF_SPHERE : GBL_REF_DISK;
+            continue;
+        }
         const float* P = d->positions + 3 * static_cast<size_t>(gm.vertex_offset);
         const uint32_t* I = d->indices + 3 * static_cast<size_t>(gm.tri_offset);
         for (uint32_t v = 0; v < gm.vertex_count; ++v) mesh_bounds[mi].grow(P + 3 * v);
@@ -509,6 +528,8 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         di.material = static_cast<int32_t>(gi.material);
         di.area_light = gi.area_light;
         di.mesh = static_cast<int32_t>(gi.mesh);
+        di.shape = d->meshes[gi.mesh].shape;
+        di.radius = d->meshes[gi.mesh].radius;
         // Transform::onBBox: the 8 corners of the mesh bound
         const Aabb& mb = mesh_bounds[gi.mesh];
         Prim& p = iprims[i];
@@ -520,6 +541,11 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         }
         for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
         p.id = i;
+    }
+    Aabb scene_bound;   // BVH::getAABB of the scene BVH: the union of the instance boxes (GoblinBVH.cpp:46-50)
+    for (const Prim& p : iprims) {
+        scene_bound.grow(p.box.lo);
+        scene_bound.grow(p.box.hi);
     }
     out->tlas_depth = 0;
     out->tlas_root = 0;
@@ -571,12 +597,15 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         dl.cos_max = gl.cos_theta_max;
         dl.cos_falloff = gl.cos_falloff_start;
         float pr, pg, pb;
-        if (gl.type == GBL_LIGHT_SPOT) {
-            // direction -> orthonormal basis -> quaternion -> matrix; the axis the
-            // falloff is measured against is that matrix's third column
+        if (gl.type == GBL_LIGHT_SPOT || gl.type == GBL_LIGHT_DIRECTIONAL) {
+            // Light::setOrientation (GoblinLight.cpp:66-76): direction -> basis -> quaternion -> matrix; the axis
+            // the light works with is that matrix's third column.  The spot light's ctor normalises the direction,
+            // the directional light's does not (:136-143).
             float dir[3] = {gl.direction[0], gl.direction[1], gl.direction[2]};
-            float inv_len = 1.0f / std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-            for (int k = 0; k < 3; ++k) dir[k] *= inv_len;
+            if (gl.type == GBL_LIGHT_SPOT) {
+                float inv_len = 1.0f / std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+                for (int k = 0; k < 3; ++k) dir[k] *= inv_len;
+            }
             float xa[3], ya[3];
             if (fabsf(dir[0]) > fabsf(dir[1])) {
                 float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[2] * dir[2]);
@@ -611,12 +640,42 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
                 qv[c2] = (R[c2][a] + R[a][c2]) * t;
             }
             float q[4] = {qv[3], qv[0], qv[1], qv[2]};
-            float one[3] = {1.0f, 1.0f, 1.0f};
-            Trs t = compose(gl.position, q, one);
+            float one[3] = {1.0f, 1.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
+            Trs t = compose(gl.type == GBL_LIGHT_SPOT ? gl.position : zero, q, one);
             for (int k = 0; k < 3; ++k) dl.axis[k] = t.m.v[k][0] * 0.0f + t.m.v[k][1] * 0.0f + t.m.v[k][2] * 1.0f;
-            float solid = kTwoPi;
-            float f = (1.0f - 0.5f * (dl.cos_max + dl.cos_falloff));
-            pr = dl.color[0] * solid * f; pg = dl.color[1] * solid * f; pb = dl.color[2] * solid * f;
+            if (gl.type == GBL_LIGHT_SPOT) {
+                float solid = kTwoPi;
+                float f = (1.0f - 0.5f * (dl.cos_max + dl.cos_falloff));
+                pr = dl.color[0] * solid * f; pg = dl.color[1] * solid * f; pb = dl.color[2] * solid * f;
+            } else {
+                // DirectionalLight::power (:203-210): radius^2 * PI * radiance over Scene::getBoundingSphere, whose
+                // radius is the full diagonal of the scene bound (GoblinBBox.h:51-54)
+                out->extended = 1;
+                float dx = scene_bound.hi[0] - scene_bound.lo[0], dy = scene_bound.hi[1] - scene_bound.lo[1],
+                      dz = scene_bound.hi[2] - scene_bound.lo[2];
+                float radius = std::sqrt(dx * dx + dy * dy + dz * dz);
+                float a = radius * radius * kPi;
+                pr = a * dl.color[0]; pg = a * dl.color[1]; pb = a * dl.color[2];
+            }
+        } else if (gl.type == GBL_LIGHT_AREA && gl.mesh >= d->num_meshes) {
+            *err = "area light references a mesh out of range";
+            return GBL_ERR_INVALID;
+        } else if (gl.type == GBL_LIGHT_AREA && d->meshes[gl.mesh].shape != GBL_SHAPE_MESH) {
+            // GeometrySet over one intersectable geometry (GoblinLight.cpp:289-303)
+            out->extended = 1;
+            Trs t = compose(gl.to_world.position, gl.to_world.orientation, gl.to_world.scale);
+            store3x4(t.m, dl.m);
+            store3x4(t.inv, dl.inv);
+            const gbl_mesh& gm = d->meshes[gl.mesh];
+            dl.shape = gm.shape;
+            dl.radius = gm.radius;
+            float a = gm.shape == GBL_SHAPE_SPHERE ? 4.0f * kPi * gm.radius * gm.radius : kPi * gm.radius * gm.radius;
+            float sum = 0.0f;
+            sum += a;
+            dl.sum_area = sum;
+            dl.tri_first = dl.tri_count = 0;
+            float world_area = sum * (gl.to_world.scale[0] * gl.to_world.scale[1]);
+            pr = dl.color[0] * kPi * world_area; pg = dl.color[1] * kPi * world_area; pb = dl.color[2] * kPi * world_area;
         } else if (gl.type == GBL_LIGHT_AREA) {
             if (gl.mesh >= d->num_meshes) {
                 *err = "area light references a mesh out of range";
@@ -700,6 +759,11 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->camera.proj00 = ys / aspect;
     out->camera.inv_xres = 1.0f / static_cast<float>(d->film.xres);
     out->camera.inv_yres = 1.0f / static_cast<float>(d->film.yres);
+    out->camera.type = c.type;
+    out->camera.lens_radius = c.lens_radius;
+    out->camera.focal_distance = c.focal_distance;
+    out->camera.film_w = c.film_width;              // OrthographicCamera ctor, GoblinCamera.cpp:288-296
+    out->camera.film_h = c.film_width / aspect;
 
     // ---- film + filter table
     const gbl_film& f = d->film;

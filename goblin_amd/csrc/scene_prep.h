@@ -19,6 +19,7 @@ struct PackedScene {
     float filter_table[256];
     int32_t tlas_root = 0;
     int32_t stack_entries = 0;
+    int32_t extended = 0;   // DevScene::extended
     uint64_t blas_nodes = 0, tlas_nodes = 0;
     int blas_max_depth = 0, tlas_depth = 0;
     DevCamera camera;

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 1
+#define GBL_ABI_VERSION 2
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -52,9 +52,17 @@ typedef struct gbl_trs {
     float scale[3];
 } gbl_trs;
 
-/* One PolygonMesh after OBJ loading and (v,vn,vt) de-duplication
- * (GoblinPolygonMesh.cpp:58-262).  Vertex attributes live in the shared
- * arrays of gbl_scene_desc; indices are mesh-local. */
+typedef enum gbl_shape {
+    GBL_SHAPE_MESH = 0,   /* PolygonMesh, refined into triangles (GoblinPolygonMesh.cpp) */
+    GBL_SHAPE_SPHERE = 1, /* Sphere(radius), intersected analytically (GoblinSphere.cpp:12-150) */
+    GBL_SHAPE_DISK = 2    /* Disk(radius) in the local z = 0 plane (GoblinDisk.cpp:12-91)     */
+} gbl_shape;
+
+/* One Geometry.  A PolygonMesh after OBJ loading and (v,vn,vt) de-duplication
+ * (GoblinPolygonMesh.cpp:58-262) -- vertex attributes live in the shared
+ * arrays of gbl_scene_desc, indices are mesh-local -- or an analytic shape
+ * (createGeometries, GoblinContextLoader.cpp:210-243), for which only
+ * `shape` and `radius` are read. */
 typedef struct gbl_mesh {
     uint32_t vertex_offset; /* first vertex in positions/normals/uvs          */
     uint32_t vertex_count;
@@ -62,6 +70,8 @@ typedef struct gbl_mesh {
     uint32_t tri_count;
     uint32_t has_normal;    /* PolygonMesh::hasNormal()                       */
     uint32_t has_uv;        /* PolygonMesh::hasTexCoord()                     */
+    uint32_t shape;         /* gbl_shape                                      */
+    float radius;           /* sphere / disk ("radius", default 1.0)          */
 } gbl_mesh;
 
 typedef enum gbl_material_type {
@@ -93,30 +103,39 @@ typedef struct gbl_instance {
 
 /* Values follow Light::Type (GoblinLight.h:62-68). */
 typedef enum gbl_light_type {
-    GBL_LIGHT_POINT = 0, /* GoblinLight.cpp:78-134  */
-    GBL_LIGHT_SPOT = 2,  /* GoblinLight.cpp:212-287 */
+    GBL_LIGHT_POINT = 0,       /* GoblinLight.cpp:78-134  */
+    GBL_LIGHT_DIRECTIONAL = 1, /* GoblinLight.cpp:136-210 */
+    GBL_LIGHT_SPOT = 2,        /* GoblinLight.cpp:212-287 */
     GBL_LIGHT_AREA = 3   /* GoblinLight.cpp:345-461 */
 } gbl_light_type;
 
 typedef struct gbl_light {
     uint32_t type;           /* gbl_light_type                                 */
-    float color[3];          /* intensity (point/spot) or radiance Le (area)   */
+    float color[3];          /* intensity (point/spot) or radiance (directional/area) */
     float position[3];       /* point/spot                                     */
-    float direction[3];      /* spot: as given to the SpotLight ctor           */
+    float direction[3];      /* spot/directional: as given to the light's ctor */
     float cos_theta_max;     /* spot: cos(radians(theta_max))                  */
     float cos_falloff_start; /* spot                                           */
     uint32_t mesh;           /* area: emitting geometry                        */
     gbl_trs to_world;        /* area                                           */
 } gbl_light;
 
-/* PerspectiveCamera (GoblinCamera.cpp:83-148, 377-387). lens_radius must be 0
- * (pinhole); the thin-lens branch is listed under SURVEY 8f. */
+typedef enum gbl_camera_type {
+    GBL_CAMERA_PERSPECTIVE = 0, /* GoblinCamera.cpp:83-148, 377-387 */
+    GBL_CAMERA_ORTHOGRAPHIC = 1 /* GoblinCamera.cpp:288-326, 390-398 */
+} gbl_camera_type;
+
+/* PerspectiveCamera (pinhole, or thin lens when lens_radius != 0: the loader
+ * then also adds the lens Disk instance, GoblinContextLoader.cpp:146-176) or
+ * OrthographicCamera. */
 typedef struct gbl_camera {
     float position[3];
     float orientation[4]; /* w, x, y, z */
     float fov_degrees;
     float near_plane, far_plane;
     float lens_radius, focal_distance;
+    uint32_t type;        /* gbl_camera_type */
+    float film_width;     /* orthographic ("film_width", default 35) */
 } gbl_camera;
 
 typedef enum gbl_filter_type {

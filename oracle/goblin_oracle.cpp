@@ -400,8 +400,10 @@ struct Mesh {
     const uint32_t* idx;
     uint32_t ntris;
     bool has_n, has_uv;
+    uint32_t shape = GBL_SHAPE_MESH;   // sphere / disk are intersectable geometries: no BLAS (GoblinModel.cpp:14)
+    float radius = 1.0f;
     Bvh bvh;
-    Box bounds;   // PolygonMesh::mBBox over de-duplicated vertices
+    Box bounds;   // PolygonMesh::mBBox over de-duplicated vertices | Sphere/Disk::getObjectBound
     V3 P(uint32_t i) const { return V3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]); }
     V3 N(uint32_t i) const { return V3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]); }
 };
@@ -465,6 +467,8 @@ struct orc_scene {
     V3 cam_pos;
     float cam_q[4];
     float proj00, proj11;
+    uint32_t cam_type = 0;
+    float lens_radius = 0.0f, focal_distance = 1.0f, film_w = 0.0f, film_h = 0.0f;
     // film
     int xres, yres, xstart, ystart, xcount, ycount;
     float inv_xres, inv_yres;
@@ -644,7 +648,21 @@ void prepare(orc_scene* s) {
         m.ntris = gm.tri_count;
         m.has_n = gm.has_normal != 0;
         m.has_uv = gm.has_uv != 0;
+        m.shape = gm.shape;
+        m.radius = gm.radius;
         m.bounds = Box();
+        if (m.shape == GBL_SHAPE_SPHERE) {   // Sphere::getObjectBound, GoblinSphere.cpp:140-143
+            m.ntris = 0;
+            m.bounds.expand(V3(m.radius, m.radius, m.radius));
+            m.bounds.expand(V3(-m.radius, -m.radius, -m.radius));
+            continue;
+        }
+        if (m.shape == GBL_SHAPE_DISK) {     // Disk::getObjectBound, GoblinDisk.cpp:81-84
+            m.ntris = 0;
+            m.bounds.expand(V3(m.radius, m.radius, 0.0f));
+            m.bounds.expand(V3(-m.radius, -m.radius, 0.0f));
+            continue;
+        }
         for (uint32_t v = 0; v < gm.vertex_count; ++v) m.bounds.expand(m.P(v));
         std::vector<Box> boxes(m.ntris);
         for (uint32_t t = 0; t < m.ntris; ++t) {   // Triangle::getObjectBound, GoblinTriangle.cpp:191-205
@@ -696,15 +714,38 @@ void prepare(orc_scene* s) {
             l.spot_axis = l.xf.on_vector(V3(0.0f, 0.0f, 1.0f));
             // SpotLight::power, GoblinLight.cpp:269-275
             power = l.color * TWO_PI * (1.0f - 0.5f * (l.cos_max + l.cos_falloff));
+        } else if (gl.type == GBL_LIGHT_DIRECTIONAL) {
+            // DirectionalLight ctor -> Light::setOrientation (GoblinLight.cpp:136-143,66-76); getDirection() is
+            // mToWorld.onVector(UnitZ) (GoblinLight.h:199).  The ctor does NOT normalise D (the spot light's does).
+            V3 dir = V3(gl.direction[0], gl.direction[1], gl.direction[2]);
+            V3 xa, ya;
+            coordinate_axes(dir, &xa, &ya);
+            float R[3][3] = {{xa.x, ya.x, dir.x}, {xa.y, ya.y, dir.y}, {xa.z, ya.z, dir.z}};
+            float q[4];
+            quat_from_matrix3(R, q);
+            float one[3] = {1.0f, 1.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
+            l.xf.set(zero, q, one);
+            l.spot_axis = l.xf.on_vector(V3(0.0f, 0.0f, 1.0f));
+            // DirectionalLight::power (:203-210) over Scene::getBoundingSphere = the TLAS bound (GoblinScene.cpp:63-65,
+            // GoblinBBox.h:51-54: radius is the full diagonal)
+            float radius = length(s->tlas.bounds.hi - s->tlas.bounds.lo);
+            power = radius * radius * PI * l.color;
         } else if (gl.type == GBL_LIGHT_AREA) {
             l.xf.set(gl.to_world.position, gl.to_world.orientation, gl.to_world.scale);
             const Mesh& m = s->meshes[gl.mesh];
-            l.geo.area.resize(m.ntris);
-            l.geo.sum_area = 0.0f;
-            for (uint32_t t = 0; t < m.ntris; ++t) {
-                float a = tri_area(m, t);
-                l.geo.area[t] = a;
+            if (m.shape != GBL_SHAPE_MESH) {   // GeometrySet over one intersectable geometry (:291-292)
+                float a = m.shape == GBL_SHAPE_SPHERE ? 4.0f * PI * m.radius * m.radius : PI * m.radius * m.radius;
+                l.geo.area.assign(1, a);
+                l.geo.sum_area = 0.0f;
                 l.geo.sum_area += a;
+            } else {
+                l.geo.area.resize(m.ntris);
+                l.geo.sum_area = 0.0f;
+                for (uint32_t t = 0; t < m.ntris; ++t) {
+                    float a = tri_area(m, t);
+                    l.geo.area[t] = a;
+                    l.geo.sum_area += a;
+                }
             }
             // AreaLight::power, GoblinLight.cpp:446-455
             float world_area = l.geo.sum_area * (l.xf.scale.x * l.xf.scale.y);
@@ -728,6 +769,11 @@ void prepare(orc_scene* s) {
     float yscale = 1.0f / std::tan(fov / 2.0f);
     s->proj11 = yscale;
     s->proj00 = yscale / aspect;
+    s->cam_type = c.type;
+    s->lens_radius = c.lens_radius;
+    s->focal_distance = c.focal_distance;
+    s->film_w = c.film_width;            // OrthographicCamera ctor, GoblinCamera.cpp:288-296
+    s->film_h = c.film_width / aspect;
     // film (GoblinFilm.cpp:92-112,131-138)
     const gbl_film& f = d.film;
     s->xres = f.xres;
@@ -748,15 +794,61 @@ void prepare(orc_scene* s) {
 // ---------------------------------------------------------------------------
 // Camera (PerspectiveCamera::generateRay pinhole branch, GoblinCamera.cpp:97-148)
 // ---------------------------------------------------------------------------
-inline Ray camera_ray(const orc_scene* s, float image_x, float image_y) {
+// uniformSampleDisk, GoblinSampler.cpp:565-602
+inline void uniform_sample_disk(float u1, float u2, float* ox, float* oy) {
+    float r, theta;
+    float x = 2.0f * u1 - 1.0f;
+    float y = 2.0f * u2 - 1.0f;
+    if (x + y > 0) {
+        if (x > y) {
+            r = x;
+            theta = 0.25f * PI * (y / x);
+        } else {
+            r = y;
+            theta = 0.25f * PI * (2.0f - x / y);
+        }
+    } else {
+        if (x < y) {
+            r = -x;
+            theta = 0.25f * PI * (4.0f + y / x);
+        } else {
+            r = -y;
+            if (y != 0.0f) theta = 0.25f * PI * (6.0f - x / y);
+            else theta = 0.0f;
+        }
+    }
+    *ox = r * std::cos(theta);
+    *oy = r * std::sin(theta);
+}
+
+inline Ray camera_ray(const orc_scene* s, float image_x, float image_y, float lens_u1 = 0.0f, float lens_u2 = 0.0f) {
     float xndc = +2.0f * image_x * s->inv_xres - 1.0f;
     float yndc = -2.0f * image_y * s->inv_yres + 1.0f;
+    Ray r;
+    if (s->cam_type == GBL_CAMERA_ORTHOGRAPHIC) {   // OrthographicCamera::generateRay, GoblinCamera.cpp:298-326
+        float xv = 0.5f * s->film_w * xndc;
+        float yv = 0.5f * s->film_h * yndc;
+        r.o = s->cam_pos + quat_rotate(s->cam_q, V3(xv, yv, 0.0f));
+        r.d = quat_rotate(s->cam_q, V3(0.0f, 0.0f, 1.0f));
+        r.mint = 0.0f;
+        r.maxt = INF;
+        return r;
+    }
     float xv = xndc / s->proj00;
     float yv = yndc / s->proj11;
     V3 view(xv, yv, 1.0f);
-    Ray r;
-    r.o = s->cam_pos;
-    r.d = quat_rotate(s->cam_q, normalize(view));
+    if (s->lens_radius == 0.0f) {
+        r.o = s->cam_pos;
+        r.d = quat_rotate(s->cam_q, normalize(view));
+    } else {   // thin lens, :127-141
+        float ft = s->focal_distance / view.z;
+        V3 p_focus = view * ft;
+        float lx, ly;
+        uniform_sample_disk(lens_u1, lens_u2, &lx, &ly);
+        V3 view_origin(s->lens_radius * lx, s->lens_radius * ly, 0.0f);
+        r.o = quat_rotate(s->cam_q, view_origin) + s->cam_pos;
+        r.d = quat_rotate(s->cam_q, normalize(p_focus - view_origin));
+    }
     r.mint = 1e-3f;
     r.maxt = INF;
     return r;
@@ -829,6 +921,87 @@ inline void tri_fragment(const Mesh& m, uint32_t t, const Ray& ray, float tt, fl
     f->dpdv = dpdv;
 }
 
+// quadratic, GoblinUtils.cpp:93-113
+inline bool quadratic(float A, float B, float C, float* t1, float* t2) {
+    float discriminant = B * B - 4.0f * A * C;
+    if (discriminant < 0.0f) return false;
+    float root = std::sqrt(discriminant);
+    float q;
+    if (B < 0) q = -0.5f * (B - root);
+    else q = -0.5f * (B + root);
+    *t1 = q / A;
+    *t2 = C / q;
+    if (*t1 > *t2) std::swap(*t1, *t2);
+    return true;
+}
+
+// Sphere::intersect / occluded up to the accepted distance (GoblinSphere.cpp:12-31, 88-107)
+inline bool sphere_test(float radius, const Ray& ray, float* t_out) {
+    float A = sqlen(ray.d);
+    float B = 2.0f * dot(ray.d, ray.o);
+    float C = sqlen(ray.o) - radius * radius;
+    float t_near, t_far;
+    if (!quadratic(A, B, C, &t_near, &t_far)) return false;
+    if (t_near > ray.maxt || t_far < ray.mint) return false;
+    float t_hit = t_near;
+    if (t_hit < ray.mint) {
+        t_hit = t_far;
+        if (t_hit > ray.maxt) return false;
+    }
+    *t_out = t_hit;
+    return true;
+}
+// the Fragment Sphere::intersect fills (:32-86)
+inline void sphere_fragment(float radius, const Ray& ray, float t_hit, Frag* f) {
+    V3 p = ray.o + t_hit * ray.d;
+    float phi = std::atan2(p.y, p.x);
+    if (phi < 0.0f) phi += TWO_PI;
+    float u = phi * INV_TWOPI;
+    float theta = std::acos(p.z / radius);
+    float v = theta * INV_PI;
+    float inv_r = 1.0f / std::sqrt(p.x * p.x + p.y * p.y);
+    float cos_phi = p.x * inv_r;
+    float sin_phi = p.y * inv_r;
+    f->p = p;
+    f->n = normalize(p);
+    f->u = u;
+    f->v = v;
+    f->dpdu = V3(-TWO_PI * p.y, TWO_PI * p.x, 0.0f);
+    f->dpdv = PI * V3(p.z * cos_phi, p.z * sin_phi, -radius * std::sin(theta));
+}
+// Disk::intersect / occluded (GoblinDisk.cpp:12-31, 63-74).  The two differ at the rim: intersect rejects
+// squareR > r^2, occluded accepts squareR <= r^2 -- the same set.
+inline bool disk_test(float radius, const Ray& ray, float* t_out) {
+    if (std::fabs(ray.d.z) < 1e-7f) return false;
+    float t = -ray.o.z / ray.d.z;
+    V3 p = ray.o + t * ray.d;
+    if (t < ray.mint || t > ray.maxt) return false;
+    float square_r = p.x * p.x + p.y * p.y;
+    if (square_r > radius * radius) return false;
+    *t_out = t;
+    return true;
+}
+inline void disk_fragment(float radius, const Ray& ray, float t, Frag* f) {   // :33-60
+    V3 p = ray.o + t * ray.d;
+    float square_r = p.x * p.x + p.y * p.y;
+    float r = std::sqrt(square_r);
+    float phi = std::atan2(p.y, p.x);
+    if (phi < 0.0f) phi += TWO_PI;
+    f->p = p;
+    f->n = V3(0.0f, 0.0f, 1.0f);
+    f->u = phi * INV_TWOPI;
+    f->v = r / radius;
+    f->dpdu = V3(-TWO_PI * p.y, TWO_PI * p.x, 0.0f);
+    f->dpdv = V3(radius * p.x / r, radius * p.y / r, 0.0f);
+}
+inline bool shape_test(const Mesh& m, const Ray& ray, float* t_out) {
+    return m.shape == GBL_SHAPE_SPHERE ? sphere_test(m.radius, ray, t_out) : disk_test(m.radius, ray, t_out);
+}
+inline void shape_fragment(const Mesh& m, const Ray& ray, float t, Frag* f) {
+    if (m.shape == GBL_SHAPE_SPHERE) sphere_fragment(m.radius, ray, t, f);
+    else disk_fragment(m.radius, ray, t, f);
+}
+
 struct Hit {
     Frag frag;
     int instance = -1;
@@ -851,6 +1024,17 @@ bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt) {
         r.mint = ray.mint;
         r.maxt = ray.maxt;
         bool h = false;
+        if (m.shape != GBL_SHAPE_MESH) {   // Model::intersect without a BVH (GoblinModel.cpp:46-54)
+            ++cnt->tris;
+            float tt;
+            if (shape_test(m, r, &tt)) {
+                r.maxt = tt;
+                hit->epsilon = 1e-3f * tt;
+                shape_fragment(m, r, tt, &hit->frag);
+                hit->instance = static_cast<int>(inst_id);
+                h = true;
+            }
+        } else
         traverse(m.bvh, r, cnt, [&](uint32_t tri) {
             ++cnt->tris;
             float tt, b1, b2;
@@ -889,6 +1073,12 @@ bool scene_occluded(const orc_scene* s, const Ray& ray, Counters* cnt) {   // Go
         r.d = in.xf.invert_vector(ray.d);
         r.mint = ray.mint;
         r.maxt = ray.maxt;
+        if (m.shape != GBL_SHAPE_MESH) {
+            ++cnt->tris;
+            float tt;
+            if (shape_test(m, r, &tt)) occ = true;
+            return occ;
+        }
         traverse(m.bvh, r, cnt, [&](uint32_t tri) {
             ++cnt->tris;
             float tt, b1, b2;
@@ -917,7 +1107,7 @@ void scene_filtered_traversal(const orc_scene* s, const Ray& ray, Counters* cnt)
         r.d = in.xf.invert_vector(ray.d);
         r.mint = ray.mint;
         r.maxt = ray.maxt;
-        traverse(m.bvh, r, cnt, [&](uint32_t) { return false; });
+        if (m.shape == GBL_SHAPE_MESH) traverse(m.bvh, r, cnt, [&](uint32_t) { return false; });
         return false;
     });
 }
@@ -1163,9 +1353,84 @@ float tri_pdf(const Mesh& m, uint32_t t, float area, V3 p, V3 wi) {
     if (std::isinf(pdf)) pdf = 0.0f;
     return pdf;
 }
+// Geometry::pdf for an analytic shape (GoblinGeometry.cpp:44-62)
+float shape_area_pdf(const Mesh& m, float area, V3 p, V3 wi) {
+    Ray ray;
+    ray.o = p;
+    ray.d = wi;
+    ray.mint = 1e-3f;
+    ray.maxt = INF;
+    float tt;
+    if (!shape_test(m, ray, &tt)) return 0.0f;
+    Frag f;
+    shape_fragment(m, ray, tt, &f);
+    float pdf = sqlen(p - f.p) / (area * absdot(-wi, f.n));
+    if (std::isinf(pdf)) pdf = 0.0f;
+    return pdf;
+}
+// Sphere::pdf, GoblinSphere.cpp:126-138
+float sphere_pdf(const Mesh& m, float area, V3 p, V3 wi) {
+    float d2 = sqlen(p);
+    float r2 = m.radius * m.radius;
+    if (d2 - r2 < 1e-4f) return shape_area_pdf(m, area, p, wi);
+    float sin_max2 = r2 / d2;
+    float cos_max = std::sqrt(std::max(0.0f, 1.0f - sin_max2));
+    return 1.0f / (TWO_PI * (1.0f - cos_max));   // uniformConePdf, GoblinSampler.h:168-170
+}
+// uniformSampleSphere, GoblinSampler.cpp:489-496
+inline V3 uniform_sample_sphere(float u1, float u2) {
+    float z = 1.0f - 2.0f * u1;
+    float sin_t = sqrtf(std::max(0.0f, 1.0f - z * z));
+    float phi = TWO_PI * u2;
+    return V3(sin_t * std::cos(phi), sin_t * std::sin(phi), z);
+}
+// Sphere::sample(p, u1, u2, &n) (:115-124 uniform, :117-... cone) / Disk::sample (GoblinDisk.cpp:76-80)
+V3 shape_sample(const Mesh& m, V3 p, float u1, float u2, V3* normal) {
+    if (m.shape == GBL_SHAPE_DISK) {
+        *normal = V3(0.0f, 0.0f, 1.0f);
+        float x, y;
+        uniform_sample_disk(u1, u2, &x, &y);
+        return V3(m.radius * x, m.radius * y, 0.0f);
+    }
+    float r2 = m.radius * m.radius;
+    float d2 = sqlen(p);
+    if (d2 - r2 < 1e-4f) {
+        *normal = uniform_sample_sphere(u1, u2);
+        return m.radius * (*normal);
+    }
+    V3 z_axis = normalize(-p);
+    V3 x_axis, y_axis;
+    coordinate_axes(z_axis, &x_axis, &y_axis);
+    float sin_max2 = r2 / d2;
+    float cos_max = std::sqrt(std::max(0.0f, 1.0f - sin_max2));
+    // uniformSampleCone(u1, u2, cosThetaMax, x, y, z), GoblinSampler.cpp:459-467
+    float cos_t = 1.0f - u1 + u1 * cos_max;
+    float sin_t = sqrtf(std::max(0.0f, 1.0f - cos_t * cos_t));
+    float phi = TWO_PI * u2;
+    Ray ray;
+    ray.o = p;
+    ray.d = x_axis * sin_t * std::cos(phi) + y_axis * sin_t * std::sin(phi) + z_axis * cos_t;
+    ray.mint = 1e-3f;
+    ray.maxt = INF;
+    V3 p_hit;
+    float tt;
+    if (sphere_test(m.radius, ray, &tt)) {
+        p_hit = ray.o + tt * ray.d;
+    } else {
+        p_hit = ray.o + (std::sqrt(d2) * cos_max) * ray.d;   // ray scratches over the sphere's surface
+    }
+    *normal = normalize(p_hit);
+    return p_hit;
+}
 float geoset_pdf(const orc_scene* s, const Light& l, V3 p, V3 wi) {   // GeometrySet::pdf, :336-343
     const Mesh& m = s->meshes[l.mesh];
     float pdf = 0.0f;
+    if (m.shape != GBL_SHAPE_MESH) {
+        float a = l.geo.area[0];
+        pdf += a * (m.shape == GBL_SHAPE_SPHERE ? sphere_pdf(m, a, p, wi) : shape_area_pdf(m, a, p, wi));
+        pdf /= l.geo.sum_area;
+        return pdf;
+    }
     for (uint32_t t = 0; t < m.ntris; ++t) pdf += l.geo.area[t] * tri_pdf(m, t, l.geo.area[t], p, wi);
     pdf /= l.geo.sum_area;
     return pdf;
@@ -1178,12 +1443,17 @@ Col light_sample(const orc_scene* s, int li, V3 p, float epsilon, float u_comp, 
         const Mesh& m = s->meshes[l.mesh];
         V3 p_local = l.xf.invert_point(p);
         int tri = s->light_geo_cdf[li].sample_discrete(u_comp, nullptr);   // GeometrySet::sample, :313-323
+        V3 ns_local, ps_local;
+        if (m.shape != GBL_SHAPE_MESH) {
+            ps_local = shape_sample(m, p_local, u1, u2, &ns_local);
+        } else {
         // Triangle::sample, GoblinTriangle.cpp:165-177 ; uniformSampleTriangle GoblinSampler.cpp:420-424
         float root = sqrtf(u1);
         float b0 = 1.0f - root, b1 = root * u2;
         V3 p0 = m.P(m.idx[3 * tri]), p1 = m.P(m.idx[3 * tri + 1]), p2 = m.P(m.idx[3 * tri + 2]);
-        V3 ns_local = normalize(cross(p1 - p0, p2 - p0));
-        V3 ps_local = b0 * p0 + b1 * p1 + (1.0f - b0 - b1) * p2;
+        ns_local = normalize(cross(p1 - p0, p2 - p0));
+        ps_local = b0 * p0 + b1 * p1 + (1.0f - b0 - b1) * p2;
+        }
         V3 wi_local = normalize(ps_local - p_local);
         *pdf = geoset_pdf(s, l, p_local, wi_local);
         V3 ps = l.xf.on_point(ps_local);
@@ -1194,6 +1464,15 @@ Col light_sample(const orc_scene* s, int li, V3 p, float epsilon, float u_comp, 
         shadow->mint = epsilon;
         shadow->maxt = length(ps - p) - epsilon;
         return dot(ns, -*wi) > 0.0f ? l.color : BLACK;   // AreaLight::L, :368-371
+    }
+    if (l.type == GBL_LIGHT_DIRECTIONAL) {   // DirectionalLight::sampleL, :145-154 (maxt stays the Ray default)
+        *wi = -l.spot_axis;
+        *pdf = 1.0f;
+        shadow->o = p;
+        shadow->d = *wi;
+        shadow->mint = epsilon;
+        shadow->maxt = INF;
+        return l.color;
     }
     // PointLight / SpotLight::sampleL, :87-99 / :225-237
     V3 dir = l.pos - p;
@@ -1599,7 +1878,7 @@ Col ao_li(LiCtx* c, const Ray& primary, const float* rec) {
 }
 
 inline Col eval_li(LiCtx* c, const float* rec) {
-    Ray ray = camera_ray(c->s, rec[0], rec[1]);
+    Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3]);
     c->dims_used += 2;
     return c->rs->integrator == GBL_INTEGRATOR_AO ? ao_li(c, ray, rec) : path_li(c, ray, rec);
 }

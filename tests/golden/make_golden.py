@@ -28,10 +28,12 @@ from goblin_amd import scene as gs  # noqa: E402
 HARNESS = os.path.join(REPO, "oracle", "_ref", "ref_harness")
 
 
-def ov(resolution, spp, depth=None, method=None, ao=None, filt=None, crop=None, geometries=None):
+def ov(resolution, spp, depth=None, method=None, ao=None, filt=None, crop=None, geometries=None, camera=None):
     o = gs.config_overrides(resolution=resolution, spp=spp, depth=depth, method=method, ao_samples=ao, filter=filt)
     if crop:
         o["camera"]["film"]["crop"] = crop
+    if camera:
+        o["camera"].update(camera)
     if geometries:
         o["geometries"] = geometries
     return o
@@ -51,6 +53,11 @@ CASES = {
     "cornell_mitchell": ("cornell", ov((40, 30), 5, 3, filt={"type": "mitchell", "width": [2.0, 2.0], "b": 0.33, "c": 0.33}), 0, False),
     "cornell_triangle_crop": ("cornell", ov((40, 30), 4, 3, filt={"type": "triangle", "width": [1.5, 1.5]},
                                             crop=[0.25, 0.75, 0.1, 0.9]), 0, False),
+    # sphere / disk geometry (also as area lights), directional light, thin-lens and orthographic cameras
+    "shapes_pt": ("shapes", ov((64, 64), 9, 5), 2048, False),
+    "shapes_thinlens": ("shapes", ov((48, 48), 9, 4, camera={"lens_radius": 0.12, "focal_distance": 4.6}), 1024, False),
+    "shapes_ortho": ("shapes", ov((48, 48), 4, 4, camera={"type": "orthographic", "film_width": 5.0}), 1024, False),
+    "shapes_ao": ("shapes", ov((40, 40), 4, method="ao", ao=4), 512, False),
 }
 
 
@@ -93,7 +100,13 @@ def main():
         sys.exit("oracle/_ref/ref_harness is missing: run `make -C oracle ref` (needs /root/reference)")
     manifest = {}
     with tempfile.TemporaryDirectory() as tmp:
+        only = set(sys.argv[1:])
+        if only and os.path.exists(os.path.join(HERE, "manifest.json")):
+            with open(os.path.join(HERE, "manifest.json")) as f:
+                manifest = json.load(f)
         for name, (scene, overrides, nrec, with_kat) in CASES.items():
+            if only and name not in only:
+                continue
             jp = os.path.join(tmp, name + ".json")
             absolute_scene(scene, overrides, jp)
             prefix = os.path.join(tmp, name)

@@ -73,19 +73,42 @@ def test_render_methods():
 def test_out_of_scope_features_fail_loudly():
     cases = [
         minimal(volume={"type": "homogeneous"}),
-        minimal(camera={"type": "orthographic"}),
-        minimal(camera={"lens_radius": 0.1}),
         minimal(lights=[{"type": "ibl", "name": "e", "file": "x.exr"}]),
-        minimal(lights=[{"type": "directional", "name": "d", "radiance": [1, 1, 1], "direction": [0, -1, 0]}]),
         minimal(materials=[{"name": "m", "type": "subsurface"}]),
         minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
         minimal(textures=[{"name": "w", "type": "checkerboard"}]),
-        minimal(geometries=[{"name": "q", "type": "sphere", "radius": 1.0}]),
     ]
     for doc in cases:
         with pytest.raises(_abi.GoblinError) as e:
             load(doc)
         assert e.value.status == _abi.GBL_ERR_UNSUPPORTED, doc
+
+
+def test_shapes_cameras_and_directional_light():
+    """SURVEY 8f rank 3 rows now on the device path: sphere / disk geometry (createGeometries,
+    GoblinContextLoader.cpp:226-234), orthographic and thin-lens cameras (:146-187), directional light."""
+    s = load(minimal(geometries=[{"name": "q", "type": "sphere", "radius": 2.5}]))
+    m = s.desc.meshes[s.desc.instances[0].mesh]
+    assert (m.shape, m.radius, m.tri_count) == (_abi.GBL_SHAPE_SPHERE, 2.5, 0)
+    s = load(minimal(geometries=[{"name": "q", "type": "disk"}]))
+    m = s.desc.meshes[s.desc.instances[0].mesh]
+    assert (m.shape, m.radius) == (_abi.GBL_SHAPE_DISK, 1.0)          # "radius" defaults to 1
+    s = load(minimal(geometries=[{"name": "q", "type": "torus"}]))
+    assert s.desc.meshes[s.desc.instances[0].mesh].shape == _abi.GBL_SHAPE_SPHERE   # unknown type -> sphere (:232-234)
+    s = load(minimal(camera={"type": "orthographic", "film_width": 12.0}))
+    assert (s.desc.camera.type, s.desc.camera.film_width) == (_abi.GBL_CAMERA_ORTHOGRAPHIC, 12.0)
+    s = load(minimal(camera={"type": "orthographic"}))
+    assert s.desc.camera.film_width == 35.0
+    # a lens adds a black-lambert Disk instance with the camera's transform BEFORE every other instance
+    s = load(minimal(camera={"lens_radius": 0.25, "focal_distance": 3.0, "position": [1, 2, 3]}))
+    d = s.desc
+    assert d.num_instances == 2 and (d.camera.lens_radius, d.camera.focal_distance) == (0.25, 3.0)
+    lens = d.instances[0]
+    assert (d.meshes[lens.mesh].shape, d.meshes[lens.mesh].radius) == (_abi.GBL_SHAPE_DISK, 0.25)
+    assert list(lens.to_world.position) == [1, 2, 3] and list(d.materials[lens.material].color) == [0, 0, 0]
+    s = load(minimal(lights=[{"type": "directional", "name": "d", "radiance": [1, 2, 3], "direction": [0, -2, 0]}]))
+    l = s.desc.lights[0]
+    assert l.type == _abi.GBL_LIGHT_DIRECTIONAL and list(l.color) == [1, 2, 3] and list(l.direction) == [0, -2, 0]
 
 
 def test_unused_out_of_scope_declarations_are_ignored():
@@ -94,7 +117,7 @@ def test_unused_out_of_scope_declarations_are_ignored():
     doc["geometries"].append({"name": "ball", "type": "sphere", "radius": 0.05})
     doc["materials"].append({"name": "sss", "type": "subsurface"})
     s = load(doc)
-    assert s.desc.num_instances == 1
+    assert s.desc.num_instances == 1 and s.desc.num_meshes == 1
 
 
 def test_missing_names_and_files():
