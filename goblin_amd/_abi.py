@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 2
+GBL_ABI_VERSION = 3
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM = range(6)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM"}
@@ -41,9 +41,20 @@ class gbl_mesh(C.Structure):
                 ("shape", C.c_uint32), ("radius", C.c_float)]
 
 
+class gbl_texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("is_float", C.c_uint32), ("value", C.c_float * 3), ("child", C.c_int32 * 2),
+                ("mapping", C.c_uint32), ("uv_scale", C.c_float * 2), ("uv_offset", C.c_float * 2), ("to_tex", gbl_trs),
+                ("filter", C.c_uint32)]
+
+
+GBL_TEX_CONSTANT, GBL_TEX_CHECKERBOARD, GBL_TEX_SCALE = 0, 1, 2
+GBL_MAP_UV, GBL_MAP_SPHERICAL = 0, 1
+
+
 class gbl_material(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", C.c_float * 3), ("color2", C.c_float * 3), ("index", C.c_float),
-                ("k", C.c_float), ("exponent", C.c_float)]
+                ("k", C.c_float), ("exponent", C.c_float), ("tex_color", C.c_int32), ("tex_color2", C.c_int32),
+                ("tex_exponent", C.c_int32)]
 
 
 class gbl_instance(C.Structure):
@@ -80,6 +91,7 @@ class gbl_scene_desc(C.Structure):
                 ("num_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
                 ("num_meshes", C.c_uint32), ("meshes", C.POINTER(gbl_mesh)),
                 ("num_materials", C.c_uint32), ("materials", C.POINTER(gbl_material)),
+                ("num_textures", C.c_uint32), ("textures", C.POINTER(gbl_texture)),
                 ("num_instances", C.c_uint32), ("instances", C.POINTER(gbl_instance)),
                 ("num_lights", C.c_uint32), ("lights", C.POINTER(gbl_light)),
                 ("camera", gbl_camera), ("film", gbl_film), ("setting", gbl_render_setting)]

@@ -74,7 +74,22 @@ struct DevMaterial {
     float color[3];
     float color2[3];
     float index, k, exponent;
+    int32_t tex_color, tex_color2, tex_exponent;   // -1: the constant above; else an index into DevScene::textures
+    uint32_t has_tex;                               // any of the three >= 0
     float pad[2];
+};
+
+// One node of a procedural texture graph (gbl_texture).  Graphs are at most GBL_TEX_MAX_DEPTH levels deep below a
+// material slot (checked when the scene is packed), so the device evaluates them by bounded template recursion.
+#define GBL_TEX_MAX_DEPTH 2
+struct DevTexture {
+    uint32_t type, is_float;
+    float value[3];
+    int32_t child[2];
+    uint32_t mapping, filter;
+    float uv_scale[2], uv_offset[2];
+    float to_tex[12];   // spherical mapping: toTex 3x4
+    float pad;
 };
 
 // one emitting triangle of an area light, light-local space (GeometrySet, GoblinLight.cpp:289-343)
@@ -128,6 +143,7 @@ struct DevScene {
     const float* uvs;        // 2 per vertex
     const DevInstance* instances;
     const DevMaterial* materials;
+    const DevTexture* textures;
     const DevLight* lights;
     const DevLightTri* light_tris;
     const float* light_cdf;       // num_lights + 1, normalised (CDF1D::mCDF)

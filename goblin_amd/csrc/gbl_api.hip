@@ -301,6 +301,7 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     if ((st = upload(ctx, packed.uvs, &sc.uvs)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.instances, &sc.instances)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.materials, &sc.materials)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.textures, &sc.textures)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.lights, &sc.lights)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.light_tris, &sc.light_tris)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.light_cdf, &sc.light_cdf)) != GBL_OK) return bail(st);

@@ -78,6 +78,10 @@ struct Params {
         auto it = ints.find(k);
         return it == ints.end() ? d : it->second;
     }
+    bool get_bool(const std::string& k, bool d = false) const {
+        auto it = bools.find(k);
+        return it == bools.end() ? d : it->second;
+    }
     float get_float(const std::string& k, float d = 0.0f) const {
         auto it = floats.find(k);
         return it == floats.end() ? d : it->second;
@@ -322,6 +326,7 @@ struct gbl_host_scene {
     std::vector<uint32_t> indices;
     std::vector<gbl_mesh> meshes;
     std::vector<gbl_material> materials;
+    std::vector<gbl_texture> textures;
     std::vector<gbl_instance> instances;
     std::vector<gbl_light> lights;
     gbl_scene_desc desc;
@@ -338,6 +343,13 @@ struct TextureDecl {
     std::string format, type;
     float color[3] = {0, 0, 0};
     float value = 0.5f;
+    // checkerboard / scale (createColor/FloatCheckerboardTexture, createColor/FloatScaleTexture)
+    std::string texture1, texture2, texture, scale_name, mapping;
+    bool filter = false;
+    float uv_scale[2] = {1.0f, 1.0f}, uv_offset[2] = {0.0f, 0.0f};
+    gbl_trs to_tex;
+    int order = 0;      // position in the "textures" list: a texture only sees the ones defined before it
+    int id = -2;        // -2 unresolved, -1 constant, >= 0 index into gbl_host_scene::textures
 };
 struct ModelDecl {
     bool is_instance = false;
@@ -463,6 +475,7 @@ private:
         gbl_material black;
         memset(&black, 0, sizeof(black));
         black.type = GBL_MAT_LAMBERT;
+        black.tex_color = black.tex_color2 = black.tex_exponent = -1;
         material_ids_[camera_type_ + "_lens_material"] = static_cast<int>(s_->materials.size());
         s_->materials.push_back(black);
         ModelDecl d;
@@ -498,6 +511,7 @@ private:
     void read_textures() {
         const gbl_json::Value* l = list("textures");
         if (!l) return;
+        int order = 0;
         for (const gbl_json::Value& t : l->arr) {
             Params p(&t);
             TextureDecl d;
@@ -506,28 +520,106 @@ private:
             Vec c = p.get_vec(p.vec3s, "color", vec(0, 0, 0));
             for (int i = 0; i < 3; ++i) d.color[i] = c.v[i];
             d.value = p.get_float("float", 0.5f);
+            d.texture1 = p.get_string("texture1");
+            d.texture2 = p.get_string("texture2");
+            d.texture = p.get_string("texture");
+            d.scale_name = p.get_string("scale");
+            d.mapping = p.get_string("mapping", "uv");
+            d.filter = p.get_bool("filter", false);
+            Vec sc = p.get_vec(p.vec2s, "scale", vec(1.0f, 1.0f));      // UVMapping (getTextureMapping, :599-615)
+            Vec of = p.get_vec(p.vec2s, "offset", vec(0.0f, 0.0f));
+            for (int i = 0; i < 2; ++i) {
+                d.uv_scale[i] = sc.v[i];
+                d.uv_offset[i] = of.v[i];
+            }
+            read_trs(p, &d.to_tex);                                     // SphericalMapping: getTransform(params)
+            d.order = order++;
             // color and float textures live in separate maps in the reference
             textures_.insert({d.format + ":" + p.get_string("name"), d});
         }
     }
 
-    gbl_status color_texture(const std::string& name, float out[3]) {
-        auto it = textures_.find("color:" + name);
-        if (it == textures_.end()) return fail(GBL_ERR_INVALID, "Texture " + name + " not defined!");
-        const std::string& t = it->second.type;
-        if (t == "checkerboard" || t == "scale" || t == "image")
-            return fail(GBL_ERR_UNSUPPORTED, "texture type \"" + t + "\" is outside the device path (constant only)");
-        for (int i = 0; i < 3; ++i) out[i] = it->second.color[i];
+    // Resolve a texture by name into either a constant (returns -1, value in `constant`) or an entry of
+    // gbl_host_scene::textures.  `before` is the list position of the texture asking (a checkerboard / scale
+    // texture is created while the list is being read, so it only finds the ones defined earlier,
+    // createTextures GoblinContextLoader.cpp:245-307); materials see the whole list.
+    gbl_status texture_ref(bool is_float, const std::string& name, int before, int* id, float constant[3]) {
+        auto it = textures_.find(std::string(is_float ? "float:" : "color:") + name);
+        if (it == textures_.end() || it->second.order >= before) return fail(GBL_ERR_INVALID, "Texture " + name + " not defined!");
+        TextureDecl& d = it->second;
+        const std::string& t = d.type;
+        if (t == "image") return fail(GBL_ERR_UNSUPPORTED, "texture type \"image\" is outside the device path");
+        if (t != "checkerboard" && t != "scale") {   // "constant" and the unknown-type fallback (:282-285, :300-303)
+            *id = -1;
+            if (is_float) constant[0] = constant[1] = constant[2] = d.value;
+            else for (int i = 0; i < 3; ++i) constant[i] = d.color[i];
+            return GBL_OK;
+        }
+        if (d.id == -2) {
+            gbl_texture g;
+            memset(&g, 0, sizeof(g));
+            g.is_float = is_float ? 1u : 0u;
+            gbl_status st;
+            float c0[3], c1[3];
+            int i0, i1;
+            if (t == "checkerboard") {
+                g.type = GBL_TEX_CHECKERBOARD;
+                if ((st = texture_ref(is_float, d.texture1, d.order, &i0, c0)) != GBL_OK) return st;
+                if ((st = texture_ref(is_float, d.texture2, d.order, &i1, c1)) != GBL_OK) return st;
+                if (d.mapping == "spherical") {
+                    g.mapping = GBL_MAP_SPHERICAL;
+                } else {   // "uv" and the unknown-mapping fallback: UVMapping((1,1), (0,0)) (:609-613)
+                    g.mapping = GBL_MAP_UV;
+                    const bool known = d.mapping == "uv";
+                    for (int i = 0; i < 2; ++i) {
+                        g.uv_scale[i] = known ? d.uv_scale[i] : 1.0f;
+                        g.uv_offset[i] = known ? d.uv_offset[i] : 0.0f;
+                    }
+                }
+                g.to_tex = d.to_tex;
+                g.filter = d.filter ? 1u : 0u;
+            } else {
+                g.type = GBL_TEX_SCALE;
+                if ((st = texture_ref(is_float, d.texture, d.order, &i0, c0)) != GBL_OK) return st;
+                if ((st = texture_ref(true, d.scale_name, d.order, &i1, c1)) != GBL_OK) return st;
+            }
+            // constant children become constant texture entries so every child is an index
+            g.child[0] = i0 >= 0 ? i0 : add_constant(is_float, c0);
+            g.child[1] = i1 >= 0 ? i1 : add_constant(t == "scale" ? true : is_float, c1);
+            d.id = static_cast<int>(s_->textures.size());
+            s_->textures.push_back(g);
+        }
+        *id = d.id;
         return GBL_OK;
     }
 
-    gbl_status float_texture(const std::string& name, float* out) {
-        auto it = textures_.find("float:" + name);
-        if (it == textures_.end()) return fail(GBL_ERR_INVALID, "Texture " + name + " not defined!");
-        const std::string& t = it->second.type;
-        if (t == "checkerboard" || t == "scale" || t == "image")
-            return fail(GBL_ERR_UNSUPPORTED, "texture type \"" + t + "\" is outside the device path (constant only)");
-        *out = it->second.value;
+    int add_constant(bool is_float, const float c[3]) {
+        gbl_texture g;
+        memset(&g, 0, sizeof(g));
+        g.type = GBL_TEX_CONSTANT;
+        g.is_float = is_float ? 1u : 0u;
+        for (int i = 0; i < 3; ++i) g.value[i] = c[i];
+        g.child[0] = g.child[1] = -1;
+        s_->textures.push_back(g);
+        return static_cast<int>(s_->textures.size()) - 1;
+    }
+
+    gbl_status color_texture(const std::string& name, float out[3], int32_t* tex) {
+        int id;
+        gbl_status st = texture_ref(false, name, 1 << 30, &id, out);
+        if (st != GBL_OK) return st;
+        *tex = id;
+        if (id >= 0) out[0] = out[1] = out[2] = 0.0f;
+        return GBL_OK;
+    }
+
+    gbl_status float_texture(const std::string& name, float* out, int32_t* tex) {
+        int id;
+        float c[3] = {0, 0, 0};
+        gbl_status st = texture_ref(true, name, 1 << 30, &id, c);
+        if (st != GBL_OK) return st;
+        *tex = id;
+        *out = id >= 0 ? 0.0f : c[0];
         return GBL_OK;
     }
 
@@ -557,28 +649,29 @@ private:
         std::string type = p.get_string("type");
         gbl_material m;
         memset(&m, 0, sizeof(m));
+        m.tex_color = m.tex_color2 = m.tex_exponent = -1;
         gbl_status st;
         if (type == "blinn") {
             m.type = GBL_MAT_BLINN;
-            if ((st = color_texture(p.get_string("Kg"), m.color)) != GBL_OK) return st;
-            if ((st = float_texture(p.get_string("exponent"), &m.exponent)) != GBL_OK) return st;
+            if ((st = color_texture(p.get_string("Kg"), m.color, &m.tex_color)) != GBL_OK) return st;
+            if ((st = float_texture(p.get_string("exponent"), &m.exponent, &m.tex_exponent)) != GBL_OK) return st;
             m.index = p.get_float("index", 1.5f);
             m.k = p.get_float("k", -1.0f);
         } else if (type == "transparent") {
             m.type = GBL_MAT_TRANSPARENT;
-            if ((st = color_texture(p.get_string("Kr"), m.color)) != GBL_OK) return st;
-            if ((st = color_texture(p.get_string("Kt"), m.color2)) != GBL_OK) return st;
+            if ((st = color_texture(p.get_string("Kr"), m.color, &m.tex_color)) != GBL_OK) return st;
+            if ((st = color_texture(p.get_string("Kt"), m.color2, &m.tex_color2)) != GBL_OK) return st;
             m.index = p.get_float("index", 1.5f);
         } else if (type == "mirror") {
             m.type = GBL_MAT_MIRROR;
-            if ((st = color_texture(p.get_string("Kr"), m.color)) != GBL_OK) return st;
+            if ((st = color_texture(p.get_string("Kr"), m.color, &m.tex_color)) != GBL_OK) return st;
             m.index = p.get_float("index", 0.8f);
             m.k = p.get_float("k", 6.0f);
         } else if (type == "subsurface" || type == "mask") {
             return fail(GBL_ERR_UNSUPPORTED, "material type \"" + type + "\" is outside the device path");
         } else {  // "lambert" and the unknown-type fallback
             m.type = GBL_MAT_LAMBERT;
-            if ((st = color_texture(p.get_string("Kd"), m.color)) != GBL_OK) return st;
+            if ((st = color_texture(p.get_string("Kd"), m.color, &m.tex_color)) != GBL_OK) return st;
         }
         *out = static_cast<int>(s_->materials.size());
         s_->materials.push_back(m);
@@ -751,6 +844,7 @@ private:
                 gbl_material black;
                 memset(&black, 0, sizeof(black));
                 black.type = GBL_MAT_LAMBERT;
+                black.tex_color = black.tex_color2 = black.tex_exponent = -1;
                 gbl_instance inst;
                 memset(&inst, 0, sizeof(inst));
                 inst.mesh = lt.mesh;
@@ -777,6 +871,8 @@ private:
         d.meshes = s_->meshes.data();
         d.num_materials = static_cast<uint32_t>(s_->materials.size());
         d.materials = s_->materials.data();
+        d.num_textures = static_cast<uint32_t>(s_->textures.size());
+        d.textures = s_->textures.data();
         d.num_instances = static_cast<uint32_t>(s_->instances.size());
         d.instances = s_->instances.data();
         d.num_lights = static_cast<uint32_t>(s_->lights.size());

@@ -84,6 +84,61 @@ __device__ __forceinline__ void camera_ray(const DevCamera& c, float image_x, fl
     *d = quat_rotate(c.q, normalize(view));
 }
 
+// The camera ray's auxiliary rays (RayDifferential::dx/dy, one pixel to the right / below), GoblinCamera.cpp:97-148,
+// 298-326.  Only texture filtering at the primary hit reads them.
+__device__ __forceinline__ void camera_differentials(const DevCamera& c, float image_x, float image_y, float lens_u1, float lens_u2,
+                                                     F3* dxo, F3* dxd, F3* dyo, F3* dyd) {
+    float xndc = +2.0f * image_x * c.inv_xres - 1.0f;
+    float yndc = -2.0f * image_y * c.inv_yres + 1.0f;
+    float dxndc = +2.0f * (image_x + 1.0f) * c.inv_xres - 1.0f;
+    float dyndc = -2.0f * (image_y + 1.0f) * c.inv_yres + 1.0f;
+    const F3 pos = f3(c.pos[0], c.pos[1], c.pos[2]);
+    if (c.type == 1u) {
+        float xv = 0.5f * c.film_w * xndc, yv = 0.5f * c.film_h * yndc;
+        float dxv = 0.5f * c.film_w * dxndc, dyv = 0.5f * c.film_h * dyndc;
+        *dxo = pos + quat_rotate(c.q, f3(dxv, yv, 0.0f));
+        *dyo = pos + quat_rotate(c.q, f3(xv, dyv, 0.0f));
+        *dxd = *dyd = quat_rotate(c.q, f3(0.0f, 0.0f, 1.0f));
+        return;
+    }
+    float xv = xndc / c.proj00, yv = yndc / c.proj11;
+    F3 dx_view = f3(dxndc / c.proj00, yv, 1.0f), dy_view = f3(xv, dyndc / c.proj11, 1.0f);
+    if (c.lens_radius != 0.0f) {
+        float ft = c.focal_distance / 1.0f;
+        float lx, ly;
+        uniform_sample_disk(lens_u1, lens_u2, &lx, &ly);
+        F3 vo = f3(c.lens_radius * lx, c.lens_radius * ly, 0.0f);
+        *dxo = *dyo = quat_rotate(c.q, vo) + pos;
+        *dxd = quat_rotate(c.q, normalize(dx_view * ft - vo));
+        *dyd = quat_rotate(c.q, normalize(dy_view * ft - vo));
+        return;
+    }
+    *dxo = *dyo = pos;
+    *dxd = quat_rotate(c.q, normalize(dx_view));
+    *dyd = quat_rotate(c.q, normalize(dy_view));
+}
+
+// TexFrag differentials of a hit: the camera ray's for the primary hit, none afterwards (RayDifferential(p, wi, eps)
+// carries no auxiliary rays, GoblinRay.h:48-51).
+template <bool REPLAY>
+__device__ __forceinline__ void hit_differentials(const DevScene& sc, const SampleSource& src, bool primary, float image_x, float image_y,
+                                                  const Frag& fr, TexFrag& tf) {
+    F3 dxo = f3(0, 0, 0), dxd = dxo, dyo = dxo, dyd = dxo;
+    if (primary) {
+        float lens_u1 = 0.0f, lens_u2 = 0.0f;
+        if (sc.camera.lens_radius != 0.0f) {
+            if (REPLAY) {
+                lens_u1 = src.rec[2];
+                lens_u2 = src.rec[3];
+            } else {
+                src.native_2d(1u, 1u, 0u, true, &lens_u1, &lens_u2);
+            }
+        }
+        camera_differentials(sc.camera, image_x, image_y, lens_u1, lens_u2, &dxo, &dxd, &dyo, &dyd);
+    }
+    uv_differential(fr, tf, primary, dxo, dxd, dyo, dyd);
+}
+
 // ImageTile::addSample into the LDS tile.  tile origin (tx0, ty0), row pitch tp pixels.
 template <bool STATS>
 __device__ __forceinline__ void splat(const DevFilm& film, const float* ftab, float* tile, int tx0, int ty0, int tp, float image_x,
@@ -273,8 +328,13 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 }
             }
             Frag fr;
+            TexFrag tf;
             if (active && !finished) {
-                if (got) make_fragment<EXT>(sc, hit, ps.o, ps.d, fr);
+                if (got) {
+                    make_fragment<EXT>(sc, hit, ps.o, ps.d, fr, &tf);
+                    if (EXT && sc.materials[sc.instances[hit.inst].material].has_tex != 0u)
+                        hit_differentials<REPLAY>(sc, src, ps.bounce < 0, image_x, image_y, fr, tf);
+                }
                 if (ps.bounce < 0) {
                     if (!got) {
                         finished = true;   // no image based light on this path: evalEnvironmentLight == 0
@@ -309,6 +369,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             float shadow_maxt = 0.0f;
             F3 wo = -ps.d;
             const DevMaterial* mat = nullptr;
+            DevMaterial resolved;   // EXT: the hit material with its textures evaluated
             float u_bsdf_c = 0.0f, u_bsdf_1 = 0.0f, u_bsdf_2 = 0.0f;
             if (active && !finished) {
                 const int b = ps.bounce;
@@ -335,6 +396,10 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 ps.pick_pdf = sc.light_pick_pdf[li];
                 ps.Ld = f3(0, 0, 0);
                 mat = sc.materials + sc.instances[hit.inst].material;
+                if (EXT && mat->has_tex != 0u) {
+                    resolve_material(sc, *mat, fr, tf, resolved);
+                    mat = &resolved;
+                }
                 const DevLight& light = sc.lights[li];
                 LightSampleOut ls;
                 light_sample<EXT>(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);

@@ -27,18 +27,46 @@ struct Frag {
     float eps;    // 1e-3 * t
 };
 
+// What texture lookups read from the Fragment (EXT builds, filled only when the hit material has textures)
+struct TexFrag {
+    float u, v;
+    F3 dpdu, dpdv;                    // world space (Fragment::transform)
+    F3 dpdx, dpdy;                    // Intersection::computeUVDifferential; zero without ray differentials
+    float dudx, dvdx, dudy, dvdy;
+};
+
 // Rebuild the reference's Fragment for the closest hit and move it to world space.
 template <bool EXT>
-__device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, F3 wo_origin, F3 w_dir, Frag& fr) {
+__device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, F3 wo_origin, F3 w_dir, Frag& fr, TexFrag* tf = nullptr) {
     const DevInstance* ip = sc.instances + h.inst;
     // the object-space ray the triangle test saw (Transform::invertRay)
     F3 ro = xf_point(ip->inv, wo_origin), rd = xf_vector(ip->inv, w_dir);
+    const bool want_tex = EXT && tf != nullptr && sc.materials[ip->material].has_tex != 0u;
     if (EXT && ip->shape != 0u) {
         // Sphere::intersect (GoblinSphere.cpp:32-86) / Disk::intersect (GoblinDisk.cpp:33-60): position, normal and
         // dpdu are algebraic in the hit point; uv and dpdv (atan2 / acos) only feed textures and bump maps
         F3 pos = ro + h.t * rd;
         F3 nrm = ip->shape == 1u ? normalize(pos) : f3(0.0f, 0.0f, 1.0f);
         F3 dpdu = f3(-GBL_TWO_PI * pos.y, GBL_TWO_PI * pos.x, 0.0f);
+        if (want_tex) {
+            float phi = atan2f(pos.y, pos.x);
+            if (phi < 0.0f) phi += GBL_TWO_PI;
+            tf->u = phi * GBL_INV_TWOPI;
+            F3 dpdv;
+            if (ip->shape == 1u) {
+                float theta = acosf(pos.z / ip->radius);
+                tf->v = theta * GBL_INV_PI;
+                float inv_r = 1.0f / sqrtf(pos.x * pos.x + pos.y * pos.y);
+                float cos_phi = pos.x * inv_r, sin_phi = pos.y * inv_r;
+                dpdv = GBL_PI * f3(pos.z * cos_phi, pos.z * sin_phi, -ip->radius * sinf(theta));
+            } else {
+                float r = sqrtf(pos.x * pos.x + pos.y * pos.y);
+                tf->v = r / ip->radius;
+                dpdv = f3(ip->radius * pos.x / r, ip->radius * pos.y / r, 0.0f);
+            }
+            tf->dpdu = xf_vector(ip->m, dpdu);
+            tf->dpdv = xf_vector(ip->m, dpdv);
+        }
         fr.p = xf_point(ip->m, pos);
         fr.n = normalize(xf_normal(ip->inv, nrm));
         F3 dpdu_w = xf_vector(ip->m, dpdu);
@@ -73,17 +101,143 @@ __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, 
         float det = du1 * dv2 - dv1 * du2;   // never 0: the packer rejects degenerate-uv meshes
         float inv_det = 1.0f / det;
         dpdu = inv_det * (dv2 * e1 - dv1 * e2);
+        if (want_tex) {
+            tf->u = b0 * u0 + b1 * u1 + b2 * u2;
+            tf->v = b0 * v0 + b1 * v1 + b2 * v2;
+            tf->dpdv = xf_vector(ip->m, inv_det * (-du2 * e1 + du1 * e2));
+        }
     } else {
         dpdu = e1;   // default uvs (0,0),(1,0),(0,1): invDet * (1*e1 - 0*e2)
+        if (want_tex) {
+            tf->u = b0 * 0.0f + b1 * 1.0f + b2 * 0.0f;
+            tf->v = b0 * 0.0f + b1 * 0.0f + b2 * 1.0f;
+            tf->dpdv = xf_vector(ip->m, e2);
+        }
     }
     // Fragment::transform
     fr.p = xf_point(ip->m, pos);
     fr.n = normalize(xf_normal(ip->inv, nrm));
     F3 dpdu_w = xf_vector(ip->m, dpdu);
+    if (want_tex) tf->dpdu = dpdu_w;
     // Fragment::getWorldToShade
     fr.t = normalize(dpdu_w - fr.n * dot(dpdu_w, fr.n));
     fr.b = cross(fr.n, fr.t);
     fr.eps = 1e-3f * h.t;
+}
+
+// ------------------------------------------------------------------- textures
+// Intersection::computeUVDifferential (GoblinPrimitive.cpp:32-97) for the camera ray's auxiliary rays.
+__device__ __forceinline__ void uv_differential(const Frag& fr, TexFrag& tf, bool has, F3 dxo, F3 dxd, F3 dyo, F3 dyd) {
+    tf.dudx = tf.dvdx = tf.dudy = tf.dvdy = 0.0f;
+    tf.dpdx = tf.dpdy = f3(0, 0, 0);
+    if (!has) return;
+    const F3 p = fr.p, n = fr.n;
+    float minus_d = dot(p, n);
+    float tdx = (minus_d - dot(dxo, n)) / dot(dxd, n);
+    float tdy = (minus_d - dot(dyo, n)) / dot(dyd, n);
+    if (isnan(tdx) || isnan(tdy)) return;
+    F3 pdx = dxo + tdx * dxd, pdy = dyo + tdy * dyd;
+    tf.dpdx = pdx - p;
+    tf.dpdy = pdy - p;
+    float a00, a01, a10, a11, bx0, bx1, by0, by1;
+    if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) {
+        a00 = tf.dpdu.y; a01 = tf.dpdv.y; a10 = tf.dpdu.z; a11 = tf.dpdv.z;
+        bx0 = tf.dpdx.y; bx1 = tf.dpdx.z; by0 = tf.dpdy.y; by1 = tf.dpdy.z;
+    } else if (fabsf(n.y) > fabsf(n.z)) {
+        a00 = tf.dpdu.x; a01 = tf.dpdv.x; a10 = tf.dpdu.z; a11 = tf.dpdv.z;
+        bx0 = tf.dpdx.x; bx1 = tf.dpdx.z; by0 = tf.dpdy.x; by1 = tf.dpdy.z;
+    } else {
+        a00 = tf.dpdu.x; a01 = tf.dpdv.x; a10 = tf.dpdu.y; a11 = tf.dpdv.y;
+        bx0 = tf.dpdx.x; bx1 = tf.dpdx.y; by0 = tf.dpdy.x; by1 = tf.dpdy.y;
+    }
+    float det = a00 * a11 - a01 * a10;   // solve2x2LinearSystem, GoblinUtils.h:151-163
+    if (fabsf(det) < 1e-10f) return;
+    float x = (+a11 * bx0 - a01 * bx1) / det, y = (-a10 * bx0 + a00 * bx1) / det;
+    if (!(isnan(x) || isnan(y))) {
+        tf.dudx = x;
+        tf.dvdx = y;
+    }
+    x = (+a11 * by0 - a01 * by1) / det;
+    y = (-a10 * by0 + a00 * by1) / det;
+    if (!(isnan(x) || isnan(y))) {
+        tf.dudy = x;
+        tf.dvdy = y;
+    }
+}
+
+// SphericalMapping::pointToST, GoblinTexture.cpp:339-347
+__device__ __forceinline__ void point_to_st(const float* to_tex, F3 p, float* s, float* t) {
+    F3 v = normalize(xf_point(to_tex, p) - f3(0.0f, 0.0f, 0.0f));
+    float theta = acosf(fminf(fmaxf(v.z, -1.0f), 1.0f));
+    float phi = atan2f(v.y, v.x);
+    phi = phi < 0.0f ? phi + GBL_TWO_PI : phi;
+    *s = phi * GBL_INV_TWOPI;
+    *t = theta * GBL_INV_PI;
+}
+__device__ __forceinline__ float integrate_checker(float x) {
+    float xh = 0.5f * x;
+    return floorf(xh) + 2.0f * fmaxf(xh - floorf(xh) - 0.5f, 0.0f);
+}
+// Texture<T>::lookup (float textures carry their value in every channel)
+template <int DEPTH>
+__device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& fr, const TexFrag& tf) {
+    const DevTexture& g = sc.textures[id];
+    const F3 value = f3(g.value[0], g.value[1], g.value[2]);
+    if constexpr (DEPTH == 0) {
+        return value;   // the packer rejects graphs deeper than GBL_TEX_MAX_DEPTH
+    } else {
+        if (g.type == 0u) return value;
+        const F3 a = tex_eval<DEPTH - 1>(sc, g.child[0], fr, tf);
+        const F3 b = tex_eval<DEPTH - 1>(sc, g.child[1], fr, tf);
+        if (g.type == 2u) return a * b.x;   // ScaleTexture: mScale->lookup * mTexture->lookup
+        float s, t, dsdx, dtdx, dsdy, dtdy;
+        if (g.mapping == 1u) {
+            point_to_st(g.to_tex, fr.p, &s, &t);
+            float sdx, tdx, sdy, tdy;
+            point_to_st(g.to_tex, fr.p + tf.dpdx, &sdx, &tdx);
+            point_to_st(g.to_tex, fr.p + tf.dpdy, &sdy, &tdy);
+            dsdx = sdx - s;
+            if (dsdx > 0.5f) dsdx -= 1.0f;
+            else if (dsdx < -0.5f) dsdx += 1.0f;
+            dsdy = sdy - s;
+            if (dsdy > 0.5f) dsdy -= 1.0f;
+            else if (dsdy < -0.5f) dsdy += 1.0f;
+            dtdx = tdx - t;
+            dtdy = tdy - t;
+        } else {
+            s = g.uv_scale[0] * tf.u + g.uv_offset[0];
+            t = g.uv_scale[1] * tf.v + g.uv_offset[1];
+            dsdx = g.uv_scale[0] * tf.dudx;
+            dtdx = g.uv_scale[1] * tf.dvdx;
+            dsdy = g.uv_scale[0] * tf.dudy;
+            dtdy = g.uv_scale[1] * tf.dvdy;
+        }
+        const bool first = (static_cast<int>(floorf(s)) + static_cast<int>(floorf(t))) % 2 == 0;
+        if (!g.filter) return first ? a : b;
+        float ds = fmaxf(fabsf(dsdx), fabsf(dsdy)), dt = fmaxf(fabsf(dtdx), fabsf(dtdy));
+        float s0 = s - ds, s1 = s + ds, t0 = t - dt, t1 = t + dt;
+        if (static_cast<int>(floorf(s0)) == static_cast<int>(floorf(s1)) && static_cast<int>(floorf(t0)) == static_cast<int>(floorf(t1)))
+            return first ? a : b;
+        float sr = (integrate_checker(s1) - integrate_checker(s0)) / (2.0f * ds);
+        float tr = (integrate_checker(t1) - integrate_checker(t0)) / (2.0f * dt);
+        float area2 = sr + tr - 2.0f * sr * tr;
+        if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
+        return (1.0f - area2) * a + area2 * b;
+    }
+}
+// The hit's material with its texture slots evaluated at this fragment (every lookup of a bounce sees the same
+// Fragment, so resolving once is what the reference's repeated lookups return).
+__device__ __forceinline__ void resolve_material(const DevScene& sc, const DevMaterial& m, const Frag& fr, const TexFrag& tf, DevMaterial& out) {
+    out = m;
+    if (m.tex_color >= 0) {
+        F3 c = tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_color, fr, tf);
+        out.color[0] = c.x; out.color[1] = c.y; out.color[2] = c.z;
+    }
+    if (m.tex_color2 >= 0) {
+        F3 c = tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_color2, fr, tf);
+        out.color2[0] = c.x; out.color2[1] = c.y; out.color2[2] = c.z;
+    }
+    if (m.tex_exponent >= 0) out.exponent = tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_exponent, fr, tf).x;
 }
 
 // shadeToWorld * v, shadeToWorld = transpose(rows t, b, n)

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     hit.inst = -1;
     bool got = false;
     Frag fr;
+    TexFrag tf;
     if (alive) {
         float4 o = wa.ray_o[slot], d = wa.ray_d[slot];
         float4 h = wa.hit[slot];
@@ -261,7 +262,26 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         if (sc.num_lights == 0) {
             finished = true;
         } else {
-            if (got) make_fragment<EXT>(sc, hit, ps.o, ps.d, fr);
+            if (got) {
+                make_fragment<EXT>(sc, hit, ps.o, ps.d, fr, &tf);
+                if (EXT && sc.materials[sc.instances[hit.inst].material].has_tex != 0u) {
+                    float image_x = 0.0f, image_y = 0.0f;
+                    if (ps.bounce < 0) {   // the camera sample this path started from (wf regeneration below)
+                        if (REPLAY) {
+                            image_x = src.rec[0];
+                            image_y = src.rec[1];
+                        } else {
+                            const int sub_w = ra.window[1] - ra.window[0];
+                            const uint32_t pix = out_index / static_cast<uint32_t>(wa.pass_spp);
+                            float u, v;
+                            src.native_2d(0u, 1u, 0u, false, &u, &v);
+                            image_x = (ra.window[0] + static_cast<int>(pix % sub_w)) + u;
+                            image_y = (ra.window[2] + static_cast<int>(pix / sub_w)) + v;
+                        }
+                    }
+                    hit_differentials<REPLAY>(sc, src, ps.bounce < 0, image_x, image_y, fr, tf);
+                }
+            }
             if (ps.bounce < 0) {
                 if (!got) {
                     finished = true;
@@ -318,6 +338,11 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         ps.pick_pdf = sc.light_pick_pdf[li];
         ps.Ld = f3(0, 0, 0);
         const DevMaterial* mat = sc.materials + sc.instances[hit.inst].material;
+        DevMaterial resolved;   // EXT: the hit material with its textures evaluated
+        if (EXT && mat->has_tex != 0u) {
+            resolve_material(sc, *mat, fr, tf, resolved);
+            mat = &resolved;
+        }
         const DevLight& light = sc.lights[li];
         LightSampleOut ls;
         light_sample<EXT>(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);

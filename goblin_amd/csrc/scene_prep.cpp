@@ -386,6 +386,16 @@ struct Filter {
     }
 };
 
+// Levels below a material slot: a constant is 0, a checkerboard / scale of constants is 1, ...  -1: bad index or cycle.
+int texture_depth(const gbl_scene_desc* d, int32_t id, int guard) {
+    if (id < 0 || static_cast<uint32_t>(id) >= d->num_textures || guard > 64) return -1;
+    const gbl_texture& g = d->textures[id];
+    if (g.type == GBL_TEX_CONSTANT) return 0;
+    int a = texture_depth(d, g.child[0], guard + 1), b = texture_depth(d, g.child[1], guard + 1);
+    if (a < 0 || b < 0) return -1;
+    return 1 + std::max(a, b);
+}
+
 int ceil_i(float f) { return static_cast<int>(std::ceil(f)); }
 int floor_i(float f) { return static_cast<int>(std::floor(f)); }
 
@@ -579,6 +589,51 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         dm.index = m.index;
         dm.k = m.k;
         dm.exponent = m.exponent;
+        dm.tex_color = m.tex_color;
+        dm.tex_color2 = m.tex_color2;
+        dm.tex_exponent = m.tex_exponent;
+        dm.has_tex = (m.tex_color >= 0 || m.tex_color2 >= 0 || m.tex_exponent >= 0) ? 1u : 0u;
+        for (int32_t t : {m.tex_color, m.tex_color2, m.tex_exponent}) {
+            if (t < 0) continue;
+            out->extended = 1;
+            int depth = texture_depth(d, t, 0);
+            if (depth < 0) {
+                *err = "material " + std::to_string(i) + " references a texture out of range (or a cyclic texture graph)";
+                return GBL_ERR_INVALID;
+            }
+            if (depth > GBL_TEX_MAX_DEPTH) {
+                *err = "material " + std::to_string(i) + ": texture graph deeper than " + std::to_string(GBL_TEX_MAX_DEPTH) +
+                       " levels below the material slot is outside the device path";
+                return GBL_ERR_UNSUPPORTED;
+            }
+        }
+    }
+
+    // ---- textures
+    out->textures.resize(d->num_textures);
+    for (uint32_t i = 0; i < d->num_textures; ++i) {
+        const gbl_texture& g = d->textures[i];
+        if (g.type > GBL_TEX_SCALE || g.mapping > GBL_MAP_SPHERICAL) {
+            *err = "unknown texture or mapping type";
+            return GBL_ERR_INVALID;
+        }
+        DevTexture& t = out->textures[i];
+        memset(&t, 0, sizeof(t));
+        t.type = g.type;
+        t.is_float = g.is_float;
+        for (int k = 0; k < 3; ++k) t.value[k] = g.is_float ? g.value[0] : g.value[k];
+        t.child[0] = g.child[0];
+        t.child[1] = g.child[1];
+        t.mapping = g.mapping;
+        t.filter = g.filter;
+        for (int k = 0; k < 2; ++k) {
+            t.uv_scale[k] = g.uv_scale[k];
+            t.uv_offset[k] = g.uv_offset[k];
+        }
+        if (g.type == GBL_TEX_CHECKERBOARD && g.mapping == GBL_MAP_SPHERICAL) {
+            Trs tt = compose(g.to_tex.position, g.to_tex.orientation, g.to_tex.scale);   // SphericalMapping::mToTex
+            store3x4(tt.m, t.to_tex);
+        }
     }
 
     // ---- lights, power distribution (Scene ctor, CDF1D::init)

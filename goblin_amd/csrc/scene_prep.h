@@ -13,6 +13,7 @@ struct PackedScene {
     std::vector<float> normals, uvs;
     std::vector<DevInstance> instances;
     std::vector<DevMaterial> materials;
+    std::vector<DevTexture> textures;
     std::vector<DevLight> lights;
     std::vector<DevLightTri> light_tris;
     std::vector<float> light_cdf, light_pick_pdf;

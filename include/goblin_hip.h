@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 2
+#define GBL_ABI_VERSION 3
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -81,15 +81,44 @@ typedef enum gbl_material_type {
     GBL_MAT_MIRROR = 3       /* GoblinMaterial.cpp:709-726 */
 } gbl_material_type;
 
-/* Constant-texture materials only (createColorConstantTexture,
- * GoblinTexture.cpp:622-625).  Colours are rgb; alpha is 1 as in Color(r,g,b). */
+typedef enum gbl_texture_type {
+    GBL_TEX_CONSTANT = 0,     /* ConstantTexture,   GoblinTexture.cpp:349-354, 617-625 */
+    GBL_TEX_CHECKERBOARD = 1, /* CheckboardTexture, GoblinTexture.cpp:356-416, 627-647 */
+    GBL_TEX_SCALE = 2         /* ScaleTexture,      GoblinTexture.cpp:418-425, 649-665 */
+} gbl_texture_type;
+
+typedef enum gbl_mapping_type {
+    GBL_MAP_UV = 0,       /* UVMapping,        GoblinTexture.cpp:293-304 */
+    GBL_MAP_SPHERICAL = 1 /* SphericalMapping, GoblinTexture.cpp:306-347 */
+} gbl_mapping_type;
+
+/* One texture of the scene's "textures" list ("format": color | float).  Image
+ * textures are not on the device path. */
+typedef struct gbl_texture {
+    uint32_t type;       /* gbl_texture_type                                            */
+    uint32_t is_float;   /* "format" == "float"                                         */
+    float value[3];      /* constant: "color", or "float" in value[0]                   */
+    int32_t child[2];    /* checkerboard: texture1, texture2 (same format);
+                          * scale: "texture" (same format), "scale" (float format)      */
+    uint32_t mapping;    /* checkerboard: gbl_mapping_type ("mapping", default uv)      */
+    float uv_scale[2];   /* uv mapping "scale" (default 1, 1)                           */
+    float uv_offset[2];  /* uv mapping "offset" (default 0, 0)                          */
+    gbl_trs to_tex;      /* spherical mapping: getTransform(params)                     */
+    uint32_t filter;     /* checkerboard "filter" (bool, default false)                 */
+} gbl_texture;
+
+/* Materials.  Each texture slot is either a constant (tex_* == -1: the value is
+ * in color / color2 / exponent, createColorConstantTexture GoblinTexture.cpp:
+ * 622-625) or an index into gbl_scene_desc.textures.  Colours are rgb; alpha is
+ * 1 as in Color(r,g,b). */
 typedef struct gbl_material {
     uint32_t type;     /* gbl_material_type                                    */
     float color[3];    /* Lambert Kd | Blinn Kg | Transparent Kr | Mirror Kr   */
     float color2[3];   /* Transparent Kt                                       */
     float index;       /* eta: blinn/transparent default 1.5, mirror 0.8       */
     float k;           /* absorption: blinn conductor iff > 0; mirror 6.0      */
-    float exponent;    /* blinn exponent (float constant texture)              */
+    float exponent;    /* blinn exponent (float texture)                       */
+    int32_t tex_color, tex_color2, tex_exponent; /* -1: constant above          */
 } gbl_material;
 
 /* InstancedPrimitive over a Model(geometry, material[, areaLight])
@@ -185,6 +214,8 @@ typedef struct gbl_scene_desc {
     const gbl_mesh* meshes;
     uint32_t num_materials;
     const gbl_material* materials;
+    uint32_t num_textures;
+    const gbl_texture* textures; /* only the non-constant ones materials reach */
     uint32_t num_instances;
     const gbl_instance* instances; /* in SceneCache::getInstances() order */
     uint32_t num_lights;

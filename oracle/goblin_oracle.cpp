@@ -83,6 +83,7 @@ inline Col operator/(Col c, float s) {
     float inv = 1.0f / s;
     return Col(c.r * inv, c.g * inv, c.b * inv, c.a);
 }
+inline Col operator+(Col a, Col b) { return Col(a.r + b.r, a.g + b.g, a.b + b.b, a.a); }   // GoblinColor.h:32-34
 inline Col& operator+=(Col& a, Col b) {
     a.r += b.r; a.g += b.g; a.b += b.b;
     return a;
@@ -393,6 +394,14 @@ inline void traverse(const Bvh& bvh, const Ray& ray, Counters* cnt, Leaf&& leaf)
 struct Frag {   // Fragment, GoblinGeometry.h:14-127
     V3 p, n, dpdu, dpdv;
     float u, v;
+    // set by Intersection::computeUVDifferential (GoblinPrimitive.cpp:32-97); zero without ray differentials
+    V3 dpdx = V3(0, 0, 0), dpdy = V3(0, 0, 0);
+    float dudx = 0.0f, dvdx = 0.0f, dudy = 0.0f, dvdy = 0.0f;
+};
+
+struct RayDiff {   // RayDifferential's auxiliary rays (GoblinRay.h:33-46)
+    bool has = false;
+    V3 dxo, dxd, dyo, dyd;
 };
 
 struct Mesh {
@@ -458,6 +467,8 @@ struct orc_scene {
     std::vector<Mesh> meshes;
     std::vector<Instance> instances;
     std::vector<gbl_material> materials;
+    std::vector<gbl_texture> textures;
+    std::vector<Xform> tex_xf;   // SphericalMapping::mToTex per texture
     std::vector<Light> lights;
     std::vector<Cdf> light_geo_cdf;   // per light (area only)
     Cdf light_power;
@@ -673,6 +684,10 @@ void prepare(orc_scene* s) {
         m.bvh.build(boxes);
     }
     s->materials.assign(d.materials, d.materials + d.num_materials);
+    s->textures.assign(d.textures, d.textures + d.num_textures);
+    s->tex_xf.resize(d.num_textures);
+    for (uint32_t i = 0; i < d.num_textures; ++i)
+        s->tex_xf[i].set(d.textures[i].to_tex.position, d.textures[i].to_tex.orientation, d.textures[i].to_tex.scale);
     // instances + TLAS over instances only (GoblinScene.cpp:15, GoblinPrimitive.cpp:119-121)
     s->instances.resize(d.num_instances);
     std::vector<Box> iboxes(d.num_instances);
@@ -821,9 +836,13 @@ inline void uniform_sample_disk(float u1, float u2, float* ox, float* oy) {
     *oy = r * std::sin(theta);
 }
 
-inline Ray camera_ray(const orc_scene* s, float image_x, float image_y, float lens_u1 = 0.0f, float lens_u2 = 0.0f) {
+inline Ray camera_ray(const orc_scene* s, float image_x, float image_y, float lens_u1 = 0.0f, float lens_u2 = 0.0f,
+                      RayDiff* rd = nullptr) {
     float xndc = +2.0f * image_x * s->inv_xres - 1.0f;
     float yndc = -2.0f * image_y * s->inv_yres + 1.0f;
+    float dxndc = +2.0f * (image_x + 1.0f) * s->inv_xres - 1.0f;
+    float dyndc = -2.0f * (image_y + 1.0f) * s->inv_yres + 1.0f;
+    if (rd) rd->has = true;
     Ray r;
     if (s->cam_type == GBL_CAMERA_ORTHOGRAPHIC) {   // OrthographicCamera::generateRay, GoblinCamera.cpp:298-326
         float xv = 0.5f * s->film_w * xndc;
@@ -832,15 +851,37 @@ inline Ray camera_ray(const orc_scene* s, float image_x, float image_y, float le
         r.d = quat_rotate(s->cam_q, V3(0.0f, 0.0f, 1.0f));
         r.mint = 0.0f;
         r.maxt = INF;
+        if (rd) {
+            float dxv = 0.5f * s->film_w * dxndc;
+            float dyv = 0.5f * s->film_h * dyndc;
+            rd->dxo = s->cam_pos + quat_rotate(s->cam_q, V3(dxv, yv, 0.0f));
+            rd->dyo = s->cam_pos + quat_rotate(s->cam_q, V3(xv, dyv, 0.0f));
+            rd->dxd = rd->dyd = r.d;
+        }
         return r;
     }
     float xv = xndc / s->proj00;
     float yv = yndc / s->proj11;
     V3 view(xv, yv, 1.0f);
+    V3 dx_view(dxndc / s->proj00, yv, 1.0f), dy_view(xv, dyndc / s->proj11, 1.0f);
     if (s->lens_radius == 0.0f) {
         r.o = s->cam_pos;
         r.d = quat_rotate(s->cam_q, normalize(view));
+        if (rd) {
+            rd->dxo = rd->dyo = s->cam_pos;
+            rd->dxd = quat_rotate(s->cam_q, normalize(dx_view));
+            rd->dyd = quat_rotate(s->cam_q, normalize(dy_view));
+        }
     } else {   // thin lens, :127-141
+        if (rd) {
+            float ft0 = s->focal_distance / view.z;
+            float lx0, ly0;
+            uniform_sample_disk(lens_u1, lens_u2, &lx0, &ly0);
+            V3 vo(s->lens_radius * lx0, s->lens_radius * ly0, 0.0f);
+            rd->dxo = rd->dyo = quat_rotate(s->cam_q, vo) + s->cam_pos;
+            rd->dxd = quat_rotate(s->cam_q, normalize(dx_view * ft0 - vo));
+            rd->dyd = quat_rotate(s->cam_q, normalize(dy_view * ft0 - vo));
+        }
         float ft = s->focal_distance / view.z;
         V3 p_focus = view * ft;
         float lx, ly;
@@ -1110,6 +1151,142 @@ void scene_filtered_traversal(const orc_scene* s, const Ray& ray, Counters* cnt)
         if (m.shape == GBL_SHAPE_MESH) traverse(m.bvh, r, cnt, [&](uint32_t) { return false; });
         return false;
     });
+}
+
+// Intersection::computeUVDifferential, GoblinPrimitive.cpp:32-97
+inline void compute_uv_differential(Frag* f, const RayDiff* rd) {
+    float dudx = 0.0f, dvdx = 0.0f, dudy = 0.0f, dvdy = 0.0f;
+    f->dpdx = f->dpdy = V3(0, 0, 0);   // every intersection builds a fresh Fragment (GoblinGeometry.cpp:7-13)
+    if (rd && rd->has) {
+        V3 p = f->p, n = f->n;
+        float minus_d = dot(p, n);
+        float tdx = (minus_d - dot(rd->dxo, n)) / dot(rd->dxd, n);
+        float tdy = (minus_d - dot(rd->dyo, n)) / dot(rd->dyd, n);
+        if (!std::isnan(tdx) && !std::isnan(tdy)) {
+            V3 pdx = rd->dxo + tdx * rd->dxd;
+            V3 pdy = rd->dyo + tdy * rd->dyd;
+            V3 dpdx = pdx - p, dpdy = pdy - p;
+            f->dpdx = dpdx;
+            f->dpdy = dpdy;
+            int axis[2];
+            if (std::fabs(n.x) > std::fabs(n.y) && std::fabs(n.x) > std::fabs(n.z)) {
+                axis[0] = 1; axis[1] = 2;
+            } else if (std::fabs(n.y) > std::fabs(n.z)) {
+                axis[0] = 0; axis[1] = 2;
+            } else {
+                axis[0] = 0; axis[1] = 1;
+            }
+            float A[2][2] = {{f->dpdu[axis[0]], f->dpdv[axis[0]]}, {f->dpdu[axis[1]], f->dpdv[axis[1]]}};
+            auto solve = [&](const float B[2], float* x, float* y) {   // solve2x2LinearSystem, GoblinUtils.h:151-163
+                float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+                if (std::fabs(det) < 1e-10f) return false;
+                *x = (+A[1][1] * B[0] - A[0][1] * B[1]) / det;
+                *y = (-A[1][0] * B[0] + A[0][0] * B[1]) / det;
+                if (std::isnan(*x) || std::isnan(*y)) return false;
+                return true;
+            };
+            float Bx[2] = {dpdx[axis[0]], dpdx[axis[1]]};
+            if (!solve(Bx, &dudx, &dvdx)) dudx = dvdx = 0.0f;
+            float By[2] = {dpdy[axis[0]], dpdy[axis[1]]};
+            if (!solve(By, &dudy, &dvdy)) dudy = dvdy = 0.0f;
+        }
+    }
+    f->dudx = dudx; f->dvdx = dvdx; f->dudy = dudy; f->dvdy = dvdy;
+}
+
+// TextureMapping::map (UVMapping / SphericalMapping, GoblinTexture.cpp:296-347)
+struct TexCoord {
+    float s, t, dsdx, dtdx, dsdy, dtdy;
+};
+inline void point_to_st(const Xform& to_tex, V3 p, float* s, float* t) {
+    V3 v = normalize(to_tex.on_point(p) - V3(0.0f, 0.0f, 0.0f));
+    float theta = std::acos(std::min(std::max(v.z, -1.0f), 1.0f));   // sphericalTheta / clamp, GoblinUtils.h:142-149
+    float phi = std::atan2(v.y, v.x);
+    phi = phi < 0.0f ? phi + TWO_PI : phi;
+    *s = phi * INV_TWOPI;
+    *t = theta * INV_PI;
+}
+inline TexCoord tex_map(const orc_scene* sc, uint32_t id, const Frag& f) {
+    const gbl_texture& g = sc->textures[id];
+    TexCoord tc;
+    if (g.mapping == GBL_MAP_SPHERICAL) {
+        const Xform& xf = sc->tex_xf[id];
+        point_to_st(xf, f.p, &tc.s, &tc.t);
+        float sdx, tdx, sdy, tdy;
+        point_to_st(xf, f.p + f.dpdx, &sdx, &tdx);
+        point_to_st(xf, f.p + f.dpdy, &sdy, &tdy);
+        float dsdx = sdx - tc.s;
+        if (dsdx > 0.5f) dsdx -= 1.0f;
+        else if (dsdx < -0.5f) dsdx += 1.0f;
+        float dsdy = sdy - tc.s;
+        if (dsdy > 0.5f) dsdy -= 1.0f;
+        else if (dsdy < -0.5f) dsdy += 1.0f;
+        tc.dsdx = dsdx;
+        tc.dtdx = tdx - tc.t;
+        tc.dsdy = dsdy;
+        tc.dtdy = tdy - tc.t;
+    } else {
+        tc.s = g.uv_scale[0] * f.u + g.uv_offset[0];
+        tc.t = g.uv_scale[1] * f.v + g.uv_offset[1];
+        tc.dsdx = g.uv_scale[0] * f.dudx;
+        tc.dtdx = g.uv_scale[1] * f.dvdx;
+        tc.dsdy = g.uv_scale[0] * f.dudy;
+        tc.dtdy = g.uv_scale[1] * f.dvdy;
+    }
+    return tc;
+}
+inline float integrate_checker(float x) {   // GoblinTexture.cpp:371-375
+    float x_half = 0.5f * x;
+    return std::floor(x_half) + 2.0f * std::max(x_half - std::floor(x_half) - 0.5f, 0.0f);
+}
+// Texture<T>::lookup for T = Color (is_float == 0) and T = float (value in .r)
+Col tex_lookup(const orc_scene* sc, int id, const Frag& f) {
+    const gbl_texture& g = sc->textures[id];
+    if (g.type == GBL_TEX_CONSTANT) return g.is_float ? Col(g.value[0], g.value[0], g.value[0]) : Col(g.value[0], g.value[1], g.value[2]);
+    if (g.type == GBL_TEX_SCALE) {   // mScale->lookup(f) * mTexture->lookup(f), :421-425
+        float sc_v = tex_lookup(sc, g.child[1], f).r;
+        Col t = tex_lookup(sc, g.child[0], f);
+        if (g.is_float) {
+            float v = sc_v * t.r;
+            return Col(v, v, v);
+        }
+        return sc_v * t;
+    }
+    // CheckboardTexture<T>::lookup, :377-416
+    TexCoord tc = tex_map(sc, id, f);
+    float s = tc.s, t = tc.t;
+    auto pick = [&]() { return (floor_int(s) + floor_int(t)) % 2 == 0 ? tex_lookup(sc, g.child[0], f) : tex_lookup(sc, g.child[1], f); };
+    if (!g.filter) return pick();
+    float ds = std::max(std::fabs(tc.dsdx), std::fabs(tc.dsdy));
+    float dt = std::max(std::fabs(tc.dtdx), std::fabs(tc.dtdy));
+    float s0 = s - ds, s1 = s + ds, t0 = t - dt, t1 = t + dt;
+    if (floor_int(s0) == floor_int(s1) && floor_int(t0) == floor_int(t1)) return pick();
+    float s_ratio = (integrate_checker(s1) - integrate_checker(s0)) / (2.0f * ds);
+    float t_ratio = (integrate_checker(t1) - integrate_checker(t0)) / (2.0f * dt);
+    float area2 = s_ratio + t_ratio - 2.0f * s_ratio * t_ratio;
+    if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
+    Col a = tex_lookup(sc, g.child[0], f), b = tex_lookup(sc, g.child[1], f);
+    if (g.is_float) {
+        float v = (1.0f - area2) * a.r + area2 * b.r;
+        return Col(v, v, v);
+    }
+    return (1.0f - area2) * a + area2 * b;
+}
+// The material with every texture slot evaluated at this fragment: all lookups a bounce makes see the same
+// Fragment, so they all return these values.
+inline gbl_material resolve_material(const orc_scene* sc, const gbl_material& m, const Frag& f) {
+    if (m.tex_color < 0 && m.tex_color2 < 0 && m.tex_exponent < 0) return m;
+    gbl_material r = m;
+    if (m.tex_color >= 0) {
+        Col c = tex_lookup(sc, m.tex_color, f);
+        r.color[0] = c.r; r.color[1] = c.g; r.color[2] = c.b;
+    }
+    if (m.tex_color2 >= 0) {
+        Col c = tex_lookup(sc, m.tex_color2, f);
+        r.color2[0] = c.r; r.color2[1] = c.g; r.color2[2] = c.b;
+    }
+    if (m.tex_exponent >= 0) r.exponent = tex_lookup(sc, m.tex_exponent, f).r;
+    return r;
 }
 
 // Fragment::getWorldToShade rows t, b, n (GoblinGeometry.cpp:17-29)
@@ -1751,7 +1928,7 @@ inline Col eval_attenuation(LiCtx* c, const Ray& ray) {
 }
 
 // PathTracer::Li, GoblinPathtracer.cpp:50-179
-Col path_li(LiCtx* c, const Ray& primary, const float* rec) {
+Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* primary_diff) {
     const orc_scene* s = c->s;
     if (s->lights.empty()) return Col(0.0f);
     Col Li(0.0f);
@@ -1775,7 +1952,8 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec) {
         float pick_pdf;
         int light = s->light_power.sample_discrete(pick, &pick_pdf);   // Scene::sampleLight, GoblinScene.cpp:97-104
         Col Ld(0.0f);
-        const gbl_material& mat = s->materials[s->instances[hit.instance].material];
+        compute_uv_differential(&hit.frag, bounce == 0 ? primary_diff : nullptr);   // :77; only the camera ray has differentials
+        const gbl_material mat = resolve_material(s, s->materials[s->instances[hit.instance].material], hit.frag);
         const Frag& frag = hit.frag;
         V3 wo = -cur.d;
         V3 wi;
@@ -1878,9 +2056,10 @@ Col ao_li(LiCtx* c, const Ray& primary, const float* rec) {
 }
 
 inline Col eval_li(LiCtx* c, const float* rec) {
-    Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3]);
+    RayDiff rd;
+    Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3], &rd);
     c->dims_used += 2;
-    return c->rs->integrator == GBL_INTEGRATOR_AO ? ao_li(c, ray, rec) : path_li(c, ray, rec);
+    return c->rs->integrator == GBL_INTEGRATOR_AO ? ao_li(c, ray, rec) : path_li(c, ray, rec, &rd);
 }
 
 // ---------------------------------------------------------------------------

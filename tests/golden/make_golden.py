@@ -58,6 +58,9 @@ CASES = {
     "shapes_thinlens": ("shapes", ov((48, 48), 9, 4, camera={"lens_radius": 0.12, "focal_distance": 4.6}), 1024, False),
     "shapes_ortho": ("shapes", ov((48, 48), 4, 4, camera={"type": "orthographic", "film_width": 5.0}), 1024, False),
     "shapes_ao": ("shapes", ov((40, 40), 4, method="ao", ao=4), 512, False),
+    # checkerboard (uv + spherical mapping, filtered through the camera ray's differentials), scale and float textures
+    "textured_pt": ("textured", ov((64, 64), 9, 5), 2048, False),
+    "textured_ortho": ("textured", ov((48, 48), 4, 4, camera={"type": "orthographic", "film_width": 6.0}), 1024, False),
 }
 
 

@@ -72,7 +72,7 @@ def fake_window(full, n_pixels):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box",
-                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao"])
+                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -100,7 +100,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
-                                  "shapes_pt", "shapes_thinlens", "shapes_ortho"])
+                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -130,6 +130,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     ("cornell", gs.config_overrides(resolution=(32, 32), spp=9, depth=6)),
     ("bunny", gs.config_overrides(resolution=(32, 32), spp=4, method="ao", ao_samples=16)),
     ("shapes", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
+    ("textured", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("shapes", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
                     camera={"film": {"resolution": [32, 32]}, "lens_radius": 0.1, "focal_distance": 4.6})),
 ])

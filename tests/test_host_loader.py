@@ -76,7 +76,7 @@ def test_out_of_scope_features_fail_loudly():
         minimal(lights=[{"type": "ibl", "name": "e", "file": "x.exr"}]),
         minimal(materials=[{"name": "m", "type": "subsurface"}]),
         minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
-        minimal(textures=[{"name": "w", "type": "checkerboard"}]),
+        minimal(textures=[{"name": "w", "type": "image", "file": "x.png"}]),
     ]
     for doc in cases:
         with pytest.raises(_abi.GoblinError) as e:
@@ -109,6 +109,43 @@ def test_shapes_cameras_and_directional_light():
     s = load(minimal(lights=[{"type": "directional", "name": "d", "radiance": [1, 2, 3], "direction": [0, -2, 0]}]))
     l = s.desc.lights[0]
     assert l.type == _abi.GBL_LIGHT_DIRECTIONAL and list(l.color) == [1, 2, 3] and list(l.direction) == [0, -2, 0]
+
+
+def test_texture_graphs():
+    """createTextures (GoblinContextLoader.cpp:245-307): checkerboard / scale textures reference earlier textures
+    by name, per format; constants stay inline in the material, graphs become gbl_texture entries."""
+    tex = [
+        {"format": "color", "name": "a", "type": "constant", "color": [1, 0, 0]},
+        {"format": "color", "name": "b", "type": "constant", "color": [0, 1, 0]},
+        {"format": "float", "name": "s", "type": "constant", "float": 0.25},
+        {"format": "color", "name": "w", "type": "checkerboard", "texture1": "a", "texture2": "b",
+         "scale": [4.0, 2.0], "offset": [0.5, 0.0], "filter": True},
+        {"format": "color", "name": "dim", "type": "scale", "texture": "w", "scale": "s"},
+    ]
+    s = load(minimal(textures=tex))
+    d = s.desc
+    m = d.materials[d.instances[0].material]
+    assert m.tex_color >= 0 and (m.tex_color2, m.tex_exponent) == (-1, -1)
+    w = d.textures[m.tex_color]
+    assert (w.type, w.is_float, w.mapping, w.filter) == (_abi.GBL_TEX_CHECKERBOARD, 0, _abi.GBL_MAP_UV, 1)
+    assert list(w.uv_scale) == [4.0, 2.0] and list(w.uv_offset) == [0.5, 0.0]
+    c1, c2 = d.textures[w.child[0]], d.textures[w.child[1]]
+    assert (c1.type, list(c1.value)) == (_abi.GBL_TEX_CONSTANT, [1, 0, 0]) and list(c2.value) == [0, 1, 0]
+    doc = minimal(textures=tex)
+    doc["materials"][0]["Kd"] = "dim"
+    s = load(doc)
+    d = s.desc
+    t = d.textures[d.materials[d.instances[0].material].tex_color]
+    assert t.type == _abi.GBL_TEX_SCALE and d.textures[t.child[0]].type == _abi.GBL_TEX_CHECKERBOARD
+    assert d.textures[t.child[1]].is_float == 1 and d.textures[t.child[1]].value[0] == 0.25
+    # a texture only sees the ones defined before it; color and float names live in separate maps
+    bad = [dict(tex[3]), tex[0], tex[1]]
+    with pytest.raises(_abi.GoblinError) as e:
+        load(minimal(textures=bad))
+    assert e.value.status == _abi.GBL_ERR_INVALID
+    # constant materials stay inline
+    s = load(minimal())
+    assert s.desc.num_textures == 0 and s.desc.materials[0].tex_color == -1
 
 
 def test_unused_out_of_scope_declarations_are_ignored():
