@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 3
+GBL_ABI_VERSION = 4
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM = range(6)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM"}
@@ -76,7 +76,8 @@ class gbl_camera(C.Structure):
 class gbl_film(C.Structure):
     _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4), ("filter_type", C.c_uint32),
                 ("filter_width", C.c_float * 2), ("gaussian_falloff", C.c_float), ("mitchell_b", C.c_float),
-                ("mitchell_c", C.c_float)]
+                ("mitchell_c", C.c_float), ("tone_mapping", C.c_uint32), ("bloom_radius", C.c_float),
+                ("bloom_weight", C.c_float)]
 
 
 class gbl_render_setting(C.Structure):
@@ -127,7 +128,8 @@ class gbl_info(C.Structure):
 
 HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "gbl_host_free",
                 "gbl_host_last_error", "gbl_host_sample_window", "gbl_host_round_to_square",
-                "gbl_host_sample_dimension", "gbl_host_film_normalize", "gbl_host_write_pfm"]
+                "gbl_host_sample_dimension", "gbl_host_film_normalize", "gbl_host_write_pfm", "gbl_host_output_path",
+                "gbl_host_bloom", "gbl_host_tone_map", "gbl_host_write_ppm", "gbl_host_write_exr", "gbl_host_write_image"]
 HIP_SYMBOLS = ["gbl_create", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
                "gbl_last_error", "gbl_abi_version", "gbl_get_timings"]
 
@@ -158,6 +160,15 @@ def host_lib():
         lib.gbl_host_film_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         lib.gbl_host_film_normalize.restype = None
         lib.gbl_host_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        lib.gbl_host_output_path.argtypes = [C.c_void_p]
+        lib.gbl_host_output_path.restype = C.c_char_p
+        lib.gbl_host_bloom.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
+        lib.gbl_host_bloom.restype = None
+        lib.gbl_host_tone_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.gbl_host_tone_map.restype = None
+        lib.gbl_host_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        lib.gbl_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        lib.gbl_host_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         _host = lib
     return _host
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HOST_SOURCES = [os.path.join(CSRC, "host", "scene_loader.cpp")]
+HOST_SOURCES = [os.path.join(CSRC, "host", "scene_loader.cpp"), os.path.join(CSRC, "host", "image_io.cpp")]
 HOST_DEPS = HOST_SOURCES + [os.path.join(CSRC, "host", "json_lite.h"), os.path.join(REPO, "include", "goblin_hip.h")]
 HIP_SOURCES = [os.path.join(CSRC, "gbl_api.hip"), os.path.join(CSRC, "scene_prep.cpp")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, f) for f in

@@ -1,10 +1,10 @@
-// g_ray_hip <scene.json> [--device N] [--seed S] [--out file.pfm]
+// g_ray_hip <scene.json> [--device N] [--seed S] [--out file.{exr,ppm,pfm}]
 //
 // Stand-alone host with the call shape of the reference's g_ray
-// (/root/reference/src/g_ray.cpp:7-27): load the scene, render it, write the image
-// next to the scene file.  Everything goes through the C ABI of include/goblin_hip.h.
-// The image is written as a float PFM (the reference writes HALF EXR through
-// tinyexr, which is outside the hot path).
+// (/root/reference/src/g_ray.cpp:7-27): load the scene, render it, and run
+// Film::writeImage's tail (GoblinFilm.cpp:164-198): normalise, bloom, write the
+// film's "file" (default <scene>.exr, HALF B/G/R).  Everything goes through the C
+// ABI of include/goblin_hip.h.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -18,7 +18,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: g_ray_hip scene_file.json [--device N] [--seed S] [--out image.pfm]\n");
+        fprintf(stderr, "Usage: g_ray_hip scene_file.json [--device N] [--seed S] [--out image.{exr,ppm,pfm}]\n");
         return 0;
     }
     std::string scene_path = argv[1], out_path;
@@ -29,16 +29,13 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], nullptr, 10);
         else if (!strcmp(argv[i], "--out")) out_path = argv[i + 1];
     }
-    if (out_path.empty()) {
-        size_t dot = scene_path.find_last_of('.');
-        out_path = (dot == std::string::npos ? scene_path : scene_path.substr(0, dot)) + ".pfm";
-    }
     gbl_host_scene* hs = nullptr;
     if (gbl_host_load_file(scene_path.c_str(), &hs) != GBL_OK) {
         fprintf(stderr, "load failed: %s\n", gbl_host_last_error());
         return 1;
     }
     const gbl_scene_desc* desc = gbl_host_desc(hs);
+    if (out_path.empty()) out_path = gbl_host_output_path(hs);
     gbl_ctx* ctx = nullptr;
     if (gbl_create(desc, device, &ctx) != GBL_OK) {
         fprintf(stderr, "gbl_create failed: %s\n", gbl_last_error(nullptr));
@@ -74,7 +71,9 @@ int main(int argc, char** argv) {
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::vector<float> host(npix * 3);
     (void)hipMemcpy(host.data(), rgb, host.size() * sizeof(float), hipMemcpyDeviceToHost);
-    if (gbl_host_write_pfm(out_path.c_str(), host.data(), info.xres, info.yres) != GBL_OK) {
+    if (desc->film.bloom_radius > 0.0f && desc->film.bloom_weight > 0.0f)
+        gbl_host_bloom(host.data(), info.xres, info.yres, desc->film.bloom_radius, desc->film.bloom_weight);
+    if (gbl_host_write_image(out_path.c_str(), host.data(), info.xres, info.yres, static_cast<int32_t>(desc->film.tone_mapping)) != GBL_OK) {
         fprintf(stderr, "write failed: %s\n", gbl_host_last_error());
         return 1;
     }

@@ -21,13 +21,18 @@
 #include "json_lite.h"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
-gbl_status fail(gbl_status code, const std::string& msg) {
+namespace gbl_host_detail {
+gbl_status fail(gbl_status code, const std::string& msg) {   // shared with image_io.cpp
     g_last_error = msg;
     return code;
 }
+}  // namespace gbl_host_detail
+
+namespace {
+using gbl_host_detail::fail;
 
 // ---------------------------------------------------------------------------
 // ParamSet: a strictly typed bag (GoblinParamSet.cpp:100-161,
@@ -329,6 +334,7 @@ struct gbl_host_scene {
     std::vector<gbl_texture> textures;
     std::vector<gbl_instance> instances;
     std::vector<gbl_light> lights;
+    std::string output_path, default_output_path = "goblin.exr";
     gbl_scene_desc desc;
 };
 
@@ -443,6 +449,12 @@ private:
         Vec crop = fp.get_vec(fp.vec4s, "crop", vec(0, 1, 0, 1));
         for (int i = 0; i < 4; ++i) f.crop[i] = crop.v[i];
         if (f.xres <= 0 || f.yres <= 0) return fail(GBL_ERR_INVALID, "film resolution must be positive");
+        // createImageFilm (GoblinFilm.cpp:202-218); the default path comes from createFilm / ContextLoader::load
+        // (GoblinContextLoader.cpp:127-129, 474-484): <scene file without extension>.exr
+        f.tone_mapping = fp.get_bool("tone_mapping", false) ? 1u : 0u;
+        f.bloom_radius = fp.get_float("bloom_radius", 0.0f);
+        f.bloom_weight = fp.get_float("bloom_weight", 0.0f);
+        s_->output_path = fp.get_string("file", s_->default_output_path);
 
         Params flt(cam ? cam->find("filter") : nullptr);
         std::string ft = flt.get_string("type");
@@ -889,7 +901,13 @@ int round_to_square(int n) {
 
 extern "C" {
 
+static gbl_status load_text(const char* json_text, const char* scene_dir, const std::string& default_output, gbl_host_scene** out);
+
 gbl_status gbl_host_load_string(const char* json_text, const char* scene_dir, gbl_host_scene** out) {
+    return load_text(json_text, scene_dir, "goblin.exr", out);   // createImageFilm's own default (GoblinFilm.cpp:212)
+}
+
+static gbl_status load_text(const char* json_text, const char* scene_dir, const std::string& default_output, gbl_host_scene** out) {
     if (!json_text || !out) return fail(GBL_ERR_INVALID, "null argument");
     *out = nullptr;
     gbl_json::Value root;
@@ -898,6 +916,7 @@ gbl_status gbl_host_load_string(const char* json_text, const char* scene_dir, gb
     if (!parser.parse(&root, &err)) return fail(GBL_ERR_IO, "json parse error: " + err);
     if (root.kind != gbl_json::Value::Object) return fail(GBL_ERR_IO, "scene json must be an object");
     gbl_host_scene* s = new gbl_host_scene();
+    s->default_output_path = default_output;
     memset(&s->desc, 0, sizeof(s->desc));
     Loader loader(root, scene_dir ? scene_dir : ".", s);
     gbl_status st = loader.run();
@@ -919,8 +938,15 @@ gbl_status gbl_host_load_file(const char* json_path, gbl_host_scene** out) {
     size_t cut = path.find_last_of('/');
     if (cut == std::string::npos) cut = path.find_last_of('\\');
     if (cut != std::string::npos) dir = path.substr(0, cut);
-    return gbl_host_load_string(text.c_str(), dir.c_str(), out);
+    // default output path (GoblinContextLoader.cpp:474-484)
+    std::string def;
+    size_t ext = path.find_last_of('.');
+    if (ext != std::string::npos && ext < path.length() - 1 && path[ext + 1] != '/' && path[ext + 1] != '\\') def = path.substr(0, ext) + ".exr";
+    else def = path + ".exr";
+    return load_text(text.c_str(), dir.c_str(), def, out);
 }
+
+const char* gbl_host_output_path(const gbl_host_scene* scene) { return scene ? scene->output_path.c_str() : ""; }
 
 const gbl_scene_desc* gbl_host_desc(const gbl_host_scene* scene) { return scene ? &scene->desc : nullptr; }
 

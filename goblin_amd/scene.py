@@ -87,10 +87,16 @@ def load_scene(name_or_path, overrides=None):
     """Load a scene file; ``overrides`` is a dict deep-merged over the JSON
     (e.g. ``{"render_setting": {"sample_per_pixel": 16}, "camera": {"film": {"resolution": [256, 256]}}}``)."""
     path = scene_path(name_or_path)
+    if not overrides:   # ContextLoader::load on the file itself (also yields the reference's default output path)
+        lib = _abi.host_lib()
+        handle = C.c_void_p()
+        st = lib.gbl_host_load_file(os.fsencode(path), C.byref(handle))
+        if st != _abi.GBL_OK:
+            raise _abi.GoblinError(st, lib.gbl_host_last_error().decode())
+        return Scene(handle, path)
     with open(path) as f:
         doc = json.load(f)
-    if overrides:
-        _merge(doc, overrides)
+    _merge(doc, overrides)
     return load_scene_text(json.dumps(doc), os.path.dirname(os.path.abspath(path)))
 
 

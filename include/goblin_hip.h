@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 3
+#define GBL_ABI_VERSION 4
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -183,6 +183,9 @@ typedef struct gbl_film {
     float filter_width[2];
     float gaussian_falloff;
     float mitchell_b, mitchell_c;
+    /* Film::writeImage post-processing (GoblinFilm.cpp:164-198, 212-215); host side only */
+    uint32_t tone_mapping;
+    float bloom_radius, bloom_weight;
 } gbl_film;
 
 typedef enum gbl_integrator {
@@ -256,9 +259,25 @@ int32_t gbl_host_sample_dimension(const gbl_render_setting* setting);
 /* Film::writeImage's normalise step (GoblinFilm.cpp:164-172): rgb/weight.
  * accum = W*H float4 {sum w*L rgb, sum w}; rgb_out = W*H*3 floats. */
 void gbl_host_film_normalize(const float* accum, int32_t xres, int32_t yres, float* rgb_out);
-/* Portable float map writer (the reference writes HALF EXR through tinyexr,
- * GoblinImageIO.cpp:84 -- out of scope; parity is checked on the float film). */
+/* Portable float map writer (build-side extra: lossless, for parity checks). */
 gbl_status gbl_host_write_pfm(const char* path, const float* rgb, int32_t xres, int32_t yres);
+/* Film "file" of the loaded scene, or the reference's default <scene>.exr
+ * (GoblinContextLoader.cpp:127-129, 474-484).  Valid until gbl_host_free. */
+const char* gbl_host_output_path(const gbl_host_scene* scene);
+/* Goblin::bloom (GoblinImageIO.cpp:169-218), in place on W*H*3 floats. */
+void gbl_host_bloom(float* rgb, int32_t xres, int32_t yres, float bloom_radius, float bloom_weight);
+/* Goblin::toneMapping (GoblinImageIO.cpp:220-236), in place. */
+void gbl_host_tone_map(float* rgb, int32_t xres, int32_t yres);
+/* writeImagePPM (GoblinImageIO.cpp:101-127): ASCII P3, gamma 2.2. */
+gbl_status gbl_host_write_ppm(const char* path, const float* rgb, int32_t xres, int32_t yres);
+/* writeImageEXR (GoblinImageIO.cpp:35-98): HALF channels B, G, R with tinyexr's
+ * float->half rounding; scanlines are stored uncompressed (tinyexr defaults to
+ * ZIP), so the pixels are the reference's, the bytes are not. */
+gbl_status gbl_host_write_exr(const char* path, const float* rgb, int32_t xres, int32_t yres);
+/* Goblin::writeImage (GoblinImageIO.cpp:146-167): picks the format from the
+ * extension (.exr, .ppm with optional tone mapping, none/unknown -> <path>.ppm);
+ * .pfm is a build-side extra.  May tone-map rgb in place. */
+gbl_status gbl_host_write_image(const char* path, float* rgb, int32_t xres, int32_t yres, int32_t tone_mapping);
 
 /* ------------------------------------------------------------------------- */
 /* libgoblin_hip.so : the device integrator.                                  */
