@@ -66,8 +66,13 @@ struct DevInstance {
     int32_t mesh;
     uint32_t shape;     // gbl_shape: 0 triangles below `root`; sphere / disk are tested analytically (root = GBL_REF_SPHERE/DISK)
     float radius;
-    int32_t pad[2];
+    uint32_t is_mask;   // the material is a MaskMaterial (its type carries BSDFnullptr): what isOpaque / notOpaque filter on
+    int32_t pad;
 };
+// IntersectFilter of a scene query (GoblinPathtracer.cpp:5-11): none, isOpaque (skip masks), notOpaque (masks only)
+#define GBL_FILTER_NONE 0
+#define GBL_FILTER_OPAQUE 1
+#define GBL_FILTER_MASK 2
 
 struct DevMaterial {
     uint32_t type;
@@ -75,8 +80,9 @@ struct DevMaterial {
     float color2[3];
     float index, k, exponent;
     int32_t tex_color, tex_color2, tex_exponent;   // -1: the constant above; else an index into DevScene::textures
-    uint32_t has_tex;                               // any of the three >= 0
-    float pad[2];
+    uint32_t has_tex;                               // any of the three >= 0 (for a mask: also the wrapped material's)
+    int32_t masked;                                 // type 4 (mask): the wrapped material; alpha = exponent, transparent colour = color
+    float pad;
 };
 
 // One node of a procedural texture graph (gbl_texture).  Graphs are at most GBL_TEX_MAX_DEPTH levels deep below a
@@ -154,6 +160,7 @@ struct DevScene {
     int32_t num_lights;
     int32_t stack_entries;        // traversal stack depth this scene needs
     int32_t extended;             // scene uses analytic shapes, a directional light or a non-pinhole camera: EXT kernels
+    int32_t has_masks;            // some instance carries a mask material: filtered queries + attenuation walks (megakernel only)
     DevCamera camera;
     DevFilm film;
 };

@@ -312,6 +312,7 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     sc.num_lights = static_cast<int32_t>(packed.lights.size());
     sc.stack_entries = packed.stack_entries;
     sc.extended = packed.extended;
+    sc.has_masks = packed.has_masks;
     sc.camera = packed.camera;
     sc.film = packed.film;
     void* p = nullptr;
@@ -469,11 +470,11 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     // short (depth <= 8: configs 1, 2, 4), the wavefront formulation once they are long enough for its
     // compaction to pay for the path pool traffic (Cornell box at depth 16: 4.6 s against 6.5 s).  AO and the
     // Russian-roulette extension always run the megakernel.
-    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette;
+    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette && !sc.has_masks;
     bool wavefront = wf_capable && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
-        ctx->error = "the wavefront schedule covers the path tracer without Russian roulette";
+        ctx->error = "the wavefront schedule covers the path tracer without Russian roulette and without mask materials";
         return GBL_ERR_UNSUPPORTED;
     }
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));

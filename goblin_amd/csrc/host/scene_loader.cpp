@@ -487,7 +487,7 @@ private:
         gbl_material black;
         memset(&black, 0, sizeof(black));
         black.type = GBL_MAT_LAMBERT;
-        black.tex_color = black.tex_color2 = black.tex_exponent = -1;
+        black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = -1;
         material_ids_[camera_type_ + "_lens_material"] = static_cast<int>(s_->materials.size());
         s_->materials.push_back(black);
         ModelDecl d;
@@ -661,7 +661,7 @@ private:
         std::string type = p.get_string("type");
         gbl_material m;
         memset(&m, 0, sizeof(m));
-        m.tex_color = m.tex_color2 = m.tex_exponent = -1;
+        m.tex_color = m.tex_color2 = m.tex_exponent = m.masked_material = -1;
         gbl_status st;
         if (type == "blinn") {
             m.type = GBL_MAT_BLINN;
@@ -679,7 +679,28 @@ private:
             if ((st = color_texture(p.get_string("Kr"), m.color, &m.tex_color)) != GBL_OK) return st;
             m.index = p.get_float("index", 0.8f);
             m.k = p.get_float("k", 6.0f);
-        } else if (type == "subsurface" || type == "mask") {
+        } else if (type == "mask") {
+            // createMaskMaterial (GoblinMaterial.cpp:929-950).  The wrapped material is looked up while the list is
+            // being read, so it has to be defined earlier in "materials".
+            m.type = GBL_MAT_MASK;
+            m.exponent = 1.0f;
+            m.color[0] = m.color[1] = m.color[2] = 1.0f;
+            if (p.has_string("alpha") && (st = float_texture(p.get_string("alpha"), &m.exponent, &m.tex_exponent)) != GBL_OK) return st;
+            if (p.has_string("transparent_color") &&
+                (st = color_texture(p.get_string("transparent_color"), m.color, &m.tex_color)) != GBL_OK) return st;
+            const std::string inner = p.get_string("material");
+            bool earlier = false;
+            for (const gbl_json::Value& mv : l->arr) {
+                if (&mv == decl) break;
+                if (Params(&mv).get_string("name") == inner) earlier = true;
+            }
+            if (!earlier) return fail(GBL_ERR_INVALID, "Material " + inner + " not defined!");
+            int inner_id;
+            if ((st = material_id(inner, &inner_id)) != GBL_OK) return st;
+            if (s_->materials[inner_id].type == GBL_MAT_MASK)
+                return fail(GBL_ERR_UNSUPPORTED, "a mask material wrapping another mask is outside the device path");
+            m.masked_material = inner_id;
+        } else if (type == "subsurface") {
             return fail(GBL_ERR_UNSUPPORTED, "material type \"" + type + "\" is outside the device path");
         } else {  // "lambert" and the unknown-type fallback
             m.type = GBL_MAT_LAMBERT;
@@ -856,7 +877,7 @@ private:
                 gbl_material black;
                 memset(&black, 0, sizeof(black));
                 black.type = GBL_MAT_LAMBERT;
-                black.tex_color = black.tex_color2 = black.tex_exponent = -1;
+                black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = -1;
                 gbl_instance inst;
                 memset(&inst, 0, sizeof(inst));
                 inst.mesh = lt.mesh;

@@ -210,6 +210,28 @@ __device__ __forceinline__ void accumulate_stats(const RenderArgs& ra, const Lan
     }
 }
 
+// PathTracer::evalAttenuation (GoblinPathtracer.cpp:21-48): the product of (1 - alpha) * transparentColor over the
+// mask surfaces the segment [mint, maxt] of the ray crosses, found one notOpaque closest-hit query at a time.
+template <bool STATS, class STK>
+__device__ __forceinline__ F3 eval_attenuation(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, LaneCounters& cnt) {
+    F3 thr = f3(1.0f, 1.0f, 1.0f);
+    for (int guard = 0; guard < 1024; ++guard) {   // every step moves mint past a hit; the cap only bounds a degenerate scene
+        Hit h;
+        if (!trace<false, STATS, true>(sc, o, d, mint, maxt, stk, h, cnt, GBL_FILTER_MASK)) break;
+        Frag fr;
+        TexFrag tf;
+        make_fragment<true>(sc, h, o, d, fr, &tf);
+        uv_differential(fr, tf, false, o, o, o, o);
+        const DevMaterial& m = sc.materials[sc.instances[h.inst].material];
+        float alpha = m.tex_exponent >= 0 ? tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_exponent, fr, tf).x : m.exponent;
+        F3 tcolor = m.tex_color >= 0 ? tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_color, fr, tf) : f3(m.color[0], m.color[1], m.color[2]);
+        thr = thr * ((1.0f - alpha) * tcolor);
+        if (is_black(thr)) break;
+        mint = h.t + fr.eps;   // currentRay.mint = currentRay.maxt + epsilon
+    }
+    return thr;
+}
+
 // ---------------------------------------------------------------------------
 // Path state carried by a lane between iterations of the persistent loop.
 // ---------------------------------------------------------------------------
@@ -223,6 +245,7 @@ struct PathState {
     int light;          // light picked at the previous vertex
     int bounce;         // -1: the ray in flight is the camera ray
     uint32_t path;      // index of this path inside the work item
+    bool punch;         // EXT: the ray in flight left a mask surface through its alpha (sampledType == BSDFnullptr)
 };
 
 template <bool REPLAY, bool STATS, bool EXT>
@@ -307,6 +330,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     ps.throughput = f3(1.0f, 1.0f, 1.0f);
                     ps.Li = f3(0.0f, 0.0f, 0.0f);
                     ps.bounce = -1;
+                    ps.punch = false;
                     ps.path = fetched;
                     active = true;
                     if (STATS) cnt.dims += 2;
@@ -335,6 +359,22 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     if (EXT && sc.materials[sc.instances[hit.inst].material].has_tex != 0u)
                         hit_differentials<REPLAY>(sc, src, ps.bounce < 0, image_x, image_y, fr, tf);
                 }
+                // The MIS query sees opaque surfaces only (isOpaque, GoblinPathtracer.cpp:148) and is attenuated by the
+                // masks in front of them; the extension query above sees everything.  They only differ when the
+                // closest surface is a mask.
+                int mis_inst = got ? hit.inst : -1;
+                F3 mis_n = fr.n, mis_tr = f3(1.0f, 1.0f, 1.0f);
+                if (EXT && sc.has_masks != 0 && got && ps.bounce >= 0 && !ps.punch && sc.instances[hit.inst].is_mask != 0u) {
+                    Hit ho;
+                    const bool go = trace<false, STATS, EXT>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, ho, cnt, GBL_FILTER_OPAQUE);
+                    mis_tr = eval_attenuation<STATS>(sc, ps.o, ps.d, ps.mint, go ? ho.t : INFINITY, stk, cnt);
+                    mis_inst = go ? ho.inst : -1;
+                    if (go) {
+                        Frag fo;
+                        make_fragment<EXT>(sc, ho, ps.o, ps.d, fo);
+                        mis_n = fo.n;
+                    }
+                }
                 if (ps.bounce < 0) {
                     if (!got) {
                         finished = true;   // no image based light on this path: evalEnvironmentLight == 0
@@ -343,13 +383,18 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                         ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
                         ps.bounce = 0;
                     }
+                } else if (EXT && ps.punch) {
+                    // the bounce that punched through a mask contributes no direct light (`continue`, :122-136)
+                    ps.punch = false;
+                    ps.bounce += 1;
+                    if (!got) finished = true;
                 } else {
                     // close the previous bounce: MIS term for the sampled direction, then Li and throughput
-                    if (got && sc.instances[hit.inst].area_light == ps.light) {
-                        F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                    if (mis_inst >= 0 && sc.instances[mis_inst].area_light == ps.light) {
+                        F3 le = hit_Le(sc, mis_inst, mis_n, -ps.d);
                         if (!is_black(le)) {
-                            // Ld += f * tr * Li * absdot(wi, n) * fWeight / bsdfPdf   (tr == 1)
-                            F3 term = div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
+                            // Ld += f * tr * Li * absdot(wi, n) * fWeight / bsdfPdf   (tr == 1 without masks)
+                            F3 term = EXT ? div(ps.f * mis_tr * le * ps.cosw * ps.fw, ps.bsdf_pdf) : div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
                             ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
                         }
                     }
@@ -369,7 +414,10 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             float shadow_maxt = 0.0f;
             F3 wo = -ps.d;
             const DevMaterial* mat = nullptr;
-            DevMaterial resolved;   // EXT: the hit material with its textures evaluated
+            ResolvedMat rmat;       // EXT: the hit material with its textures evaluated / its mask unwrapped
+            F3 l_f = f3(0, 0, 0), l_L = f3(0, 0, 0);
+            float l_cos = 0.0f, l_w = 1.0f, l_pdf = 1.0f;
+            bool l_area = false;
             float u_bsdf_c = 0.0f, u_bsdf_1 = 0.0f, u_bsdf_2 = 0.0f;
             if (active && !finished) {
                 const int b = ps.bounce;
@@ -396,25 +444,31 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 ps.pick_pdf = sc.light_pick_pdf[li];
                 ps.Ld = f3(0, 0, 0);
                 mat = sc.materials + sc.instances[hit.inst].material;
-                if (EXT && mat->has_tex != 0u) {
-                    resolve_material(sc, *mat, fr, tf, resolved);
-                    mat = &resolved;
-                }
+                if (EXT) resolve_hit_material(sc, sc.instances[hit.inst].material, fr, tf, rmat);
                 const DevLight& light = sc.lights[li];
                 LightSampleOut ls;
                 light_sample<EXT>(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
                 if (!is_black(ls.L) && ls.pdf > 0.0f) {
-                    F3 f = mat_bsdf(*mat, fr.n, wo, ls.wi);
+                    F3 f = EXT ? rmat_bsdf(rmat, fr.n, wo, ls.wi) : mat_bsdf(*mat, fr.n, wo, ls.wi);
                     if (!is_black(f)) {
                         need_shadow = true;
                         shadow_d = ls.wi;
                         shadow_maxt = ls.maxt;
+                        float lw = 1.0f;
                         if (light.type != GBL_LIGHT_AREA) {
                             contrib = div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);
                         } else {
-                            float bp = mat_pdf(*mat, fr.n, wo, ls.wi);
-                            float lw = power_heuristic(ls.pdf, bp);
+                            float bp = EXT ? rmat_pdf(rmat, fr.n, wo, ls.wi) : mat_pdf(*mat, fr.n, wo, ls.wi);
+                            lw = power_heuristic(ls.pdf, bp);
                             contrib = div(f * ls.L * absdot(fr.n, ls.wi) * lw, ls.pdf);
+                        }
+                        if (EXT) {   // kept for the attenuated form f * tr * L * |n.wi| (* lWeight) / lightPdf below
+                            l_f = f;
+                            l_L = ls.L;
+                            l_cos = absdot(fr.n, ls.wi);
+                            l_w = lw;
+                            l_pdf = ls.pdf;
+                            l_area = light.type == GBL_LIGHT_AREA;
                         }
                     }
                 }
@@ -422,8 +476,14 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             // ---- shadow query (any-hit)
             if (need_shadow) {
                 Hit dummy;
-                bool occluded = trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt);
+                const bool masks = EXT && sc.has_masks != 0;
+                bool occluded = trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
+                                                        masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 if (STATS) cnt.shadow += 1;
+                if (!occluded && masks) {
+                    F3 tr = eval_attenuation<STATS>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, cnt);
+                    contrib = l_area ? div(l_f * tr * l_L * l_cos * l_w, l_pdf) : div(l_f * tr * l_L * l_cos, l_pdf);
+                }
                 if (!occluded) ps.Ld = f3(ps.Ld.x + contrib.x, ps.Ld.y + contrib.y, ps.Ld.z + contrib.z);
             }
             // ---- BSDF sample: the next ray
@@ -431,8 +491,17 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 F3 wi;
                 float pdf;
                 bool specular;
-                F3 f = mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
-                if (!is_black(f) && pdf > 0.0f) {
+                bool null_sampled = false;
+                F3 f = EXT ? rmat_sample(rmat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular, &null_sampled)
+                           : mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
+                if (EXT && null_sampled && !is_black(f) && pdf > 0.0f) {
+                    // punch through the mask: throughput *= f / pdf, no cosine, and this bounce's Ld is dropped (:122-136)
+                    ps.throughput = ps.throughput * div(f, pdf);
+                    ps.o = fr.p;
+                    ps.d = wi;
+                    ps.mint = fr.eps;
+                    ps.punch = true;
+                } else if (!is_black(f) && pdf > 0.0f) {
                     float fw = 1.0f;
                     if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
                     ps.f = f;

@@ -16,6 +16,7 @@
 #define GBL_MAT_BLINN 1u
 #define GBL_MAT_TRANSPARENT 2u
 #define GBL_MAT_MIRROR 3u
+#define GBL_MAT_MASK 4u
 #define GBL_LIGHT_POINT 0u
 #define GBL_LIGHT_DIRECTIONAL 1u
 #define GBL_LIGHT_SPOT 2u
@@ -393,6 +394,58 @@ __device__ __forceinline__ F3 mat_sample(const DevMaterial& m, const Frag& fr, F
     float f = fresnel_conductor(cosi, m.index, m.k);
     *wi = 2 * cosi * n - wo;
     return f3(m.color[0], m.color[1], m.color[2]) * (f / cosi);
+}
+
+// MaskMaterial (GoblinMaterial.cpp:747-811): `m` is the wrapped material with its textures resolved, alpha and
+// tcolor the mask's own two lookups; for any other material is_mask is false and `m` the material itself.
+struct ResolvedMat {
+    DevMaterial m;
+    float alpha;
+    F3 tcolor;
+    bool is_mask;
+};
+__device__ __forceinline__ void resolve_hit_material(const DevScene& sc, int material, const Frag& fr, const TexFrag& tf, ResolvedMat& r) {
+    const DevMaterial& outer = sc.materials[material];
+    r.is_mask = false;
+    r.alpha = 1.0f;
+    r.tcolor = f3(1.0f, 1.0f, 1.0f);
+    if (outer.type != GBL_MAT_MASK) {
+        if (outer.has_tex != 0u) resolve_material(sc, outer, fr, tf, r.m);
+        else r.m = outer;
+        return;
+    }
+    r.is_mask = true;
+    r.alpha = outer.tex_exponent >= 0 ? tex_eval<GBL_TEX_MAX_DEPTH>(sc, outer.tex_exponent, fr, tf).x : outer.exponent;
+    r.tcolor = outer.tex_color >= 0 ? tex_eval<GBL_TEX_MAX_DEPTH>(sc, outer.tex_color, fr, tf) : f3(outer.color[0], outer.color[1], outer.color[2]);
+    const DevMaterial& inner = sc.materials[outer.masked];
+    if (inner.has_tex != 0u) resolve_material(sc, inner, fr, tf, r.m);
+    else r.m = inner;
+}
+// bsdf / pdf / sampleBSDF with type == BSDFAll; *null_sampled: the alpha branch was taken (sampledType == BSDFnullptr)
+__device__ __forceinline__ F3 rmat_bsdf(const ResolvedMat& r, F3 n, F3 wo, F3 wi) {
+    F3 f = mat_bsdf(r.m, n, wo, wi);
+    return r.is_mask ? r.alpha * f : f;
+}
+__device__ __forceinline__ float rmat_pdf(const ResolvedMat& r, F3 n, F3 wo, F3 wi) {
+    float p = mat_pdf(r.m, n, wo, wi);
+    return r.is_mask ? r.alpha * p : p;
+}
+__device__ __forceinline__ F3 rmat_sample(const ResolvedMat& r, const Frag& fr, F3 wo, float u_comp, float u1, float u2, F3* wi, float* pdf,
+                                          bool* specular, bool* null_sampled) {
+    *null_sampled = false;
+    if (r.is_mask && !(u_comp < r.alpha)) {
+        *wi = -normalize(wo);
+        *pdf = 1.0f - r.alpha;
+        *specular = false;
+        *null_sampled = true;
+        return (1.0f - r.alpha) * r.tcolor;
+    }
+    F3 f = mat_sample(r.m, fr, wo, u_comp, u1, u2, wi, pdf, specular);
+    if (r.is_mask) {
+        f = r.alpha * f;
+        *pdf *= r.alpha;
+    }
+    return f;
 }
 
 // --------------------------------------------------------------------- lights

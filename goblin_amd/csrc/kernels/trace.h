@@ -249,8 +249,11 @@ __device__ __forceinline__ bool disk_test(float radius, F3 o, F3 d, float mint, 
 }
 
 // EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
+// `filter` (EXT builds): GBL_FILTER_* -- instances whose material is / is not a mask are skipped whole, which is
+// what Model::intersect does with the isOpaque / notOpaque IntersectFilter (GoblinModel.cpp:30-32, 44-46).
 template <bool ANY, bool STATS, bool EXT, class STK>
-__device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded) {
+__device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
+                                           int filter = GBL_FILTER_NONE) {
     const int cur = st.cur;
     if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
     if (cur == GBL_STACK_EXIT) return true;
@@ -262,8 +265,12 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, co
     }
     const uint32_t ref = ~static_cast<uint32_t>(cur);
     if (st.inst < 0) {
+        const DevInstance* ip = sc.instances + (ref >> 2);
+        if (EXT && filter != GBL_FILTER_NONE && (ip->is_mask != 0u ? GBL_FILTER_MASK : GBL_FILTER_OPAQUE) != filter) {
+            st.cur = static_cast<int>(stk.load(--st.sp));
+            return false;
+        }
         st.inst = static_cast<int>(ref >> 2);
-        const DevInstance* ip = sc.instances + st.inst;
         ray_space(st.r, xf_point(ip->inv, st.world.o), xf_vector(ip->inv, st.world.d));
         stk.store(st.sp++, GBL_STACK_SENTINEL);
         st.cur = ip->root;
@@ -326,7 +333,7 @@ __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
 // ANY = false: Scene::intersect (closest hit; hit.t shrinks like ray.maxt)
 template <bool ANY, bool STATS, bool EXT, class STK>
 __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
-                                      LaneCounters& cnt) {
+                                      LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
     TravState st;
     trav_begin(sc, st, o, d, mint, maxt, stk);
     bool occluded = false;
@@ -337,7 +344,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
     for (;;) {
         if (trav_at_interior(st)) {
             trav_interior<STATS>(sc, st, stk, cnt);
-        } else if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded)) {
+        } else if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded, filter)) {
             break;
         }
     }

@@ -540,6 +540,8 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         di.mesh = static_cast<int32_t>(gi.mesh);
         di.shape = d->meshes[gi.mesh].shape;
         di.radius = d->meshes[gi.mesh].radius;
+        di.is_mask = d->materials[gi.material].type == GBL_MAT_MASK ? 1u : 0u;
+        if (di.is_mask) out->has_masks = out->extended = 1;
         // Transform::onBBox: the 8 corners of the mesh bound
         const Aabb& mb = mesh_bounds[gi.mesh];
         Prim& p = iprims[i];
@@ -575,8 +577,13 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->materials.resize(d->num_materials);
     for (uint32_t i = 0; i < d->num_materials; ++i) {
         const gbl_material& m = d->materials[i];
-        if (m.type > GBL_MAT_MIRROR) {
+        if (m.type > GBL_MAT_MASK) {
             *err = "unknown material type";
+            return GBL_ERR_INVALID;
+        }
+        if (m.type == GBL_MAT_MASK && (m.masked_material < 0 || static_cast<uint32_t>(m.masked_material) >= d->num_materials ||
+                                       d->materials[m.masked_material].type == GBL_MAT_MASK)) {
+            *err = "mask material " + std::to_string(i) + " must wrap a non-mask material of the scene";
             return GBL_ERR_INVALID;
         }
         DevMaterial& dm = out->materials[i];
@@ -593,6 +600,11 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         dm.tex_color2 = m.tex_color2;
         dm.tex_exponent = m.tex_exponent;
         dm.has_tex = (m.tex_color >= 0 || m.tex_color2 >= 0 || m.tex_exponent >= 0) ? 1u : 0u;
+        dm.masked = m.type == GBL_MAT_MASK ? m.masked_material : -1;
+        if (m.type == GBL_MAT_MASK) {
+            const gbl_material& in = d->materials[m.masked_material];
+            if (in.tex_color >= 0 || in.tex_color2 >= 0 || in.tex_exponent >= 0) dm.has_tex = 1u;
+        }
         for (int32_t t : {m.tex_color, m.tex_color2, m.tex_exponent}) {
             if (t < 0) continue;
             out->extended = 1;

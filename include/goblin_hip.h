@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 4
+#define GBL_ABI_VERSION 5
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -78,7 +78,8 @@ typedef enum gbl_material_type {
     GBL_MAT_LAMBERT = 0,     /* GoblinMaterial.cpp:437-480 */
     GBL_MAT_BLINN = 1,       /* GoblinMaterial.cpp:540-644 */
     GBL_MAT_TRANSPARENT = 2, /* GoblinMaterial.cpp:647-706 */
-    GBL_MAT_MIRROR = 3       /* GoblinMaterial.cpp:709-726 */
+    GBL_MAT_MIRROR = 3,      /* GoblinMaterial.cpp:709-726 */
+    GBL_MAT_MASK = 4         /* GoblinMaterial.cpp:747-811: alpha-masked wrapper, BSDFnullptr punch-through */
 } gbl_material_type;
 
 typedef enum gbl_texture_type {
@@ -117,8 +118,12 @@ typedef struct gbl_material {
     float color2[3];   /* Transparent Kt                                       */
     float index;       /* eta: blinn/transparent default 1.5, mirror 0.8       */
     float k;           /* absorption: blinn conductor iff > 0; mirror 6.0      */
-    float exponent;    /* blinn exponent (float texture)                       */
+    float exponent;    /* blinn exponent (float texture) | Mask alpha          */
     int32_t tex_color, tex_color2, tex_exponent; /* -1: constant above          */
+    /* Mask: color = "transparent_color" (default white), exponent = "alpha"
+     * (default 1), masked_material = index of the wrapped material (which must
+     * not be a mask itself); -1 for every other type. */
+    int32_t masked_material;
 } gbl_material;
 
 /* InstancedPrimitive over a Model(geometry, material[, areaLight])

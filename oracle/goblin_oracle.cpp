@@ -420,8 +420,12 @@ struct Mesh {
 struct Instance {
     uint32_t mesh, material;
     int area_light;
+    bool is_mask = false;   // its material's type carries BSDFnullptr: what isOpaque / notOpaque test (GoblinPathtracer.cpp:5-11)
     Xform xf;
 };
+
+// IntersectFilter of the scene queries: none, isOpaque (skip masks), notOpaque (masks only)
+enum { FILTER_NONE = 0, FILTER_OPAQUE = 1, FILTER_MASK = 2 };
 
 struct AreaGeo {   // GeometrySet, GoblinLight.cpp:289-343
     std::vector<float> area, cdf;
@@ -469,6 +473,7 @@ struct orc_scene {
     std::vector<gbl_material> materials;
     std::vector<gbl_texture> textures;
     std::vector<Xform> tex_xf;   // SphericalMapping::mToTex per texture
+    bool has_masks = false;
     std::vector<Light> lights;
     std::vector<Cdf> light_geo_cdf;   // per light (area only)
     Cdf light_power;
@@ -697,6 +702,8 @@ void prepare(orc_scene* s) {
         in.mesh = gi.mesh;
         in.material = gi.material;
         in.area_light = gi.area_light;
+        in.is_mask = d.materials[gi.material].type == GBL_MAT_MASK;
+        s->has_masks = s->has_masks || in.is_mask;
         in.xf.set(gi.to_world.position, gi.to_world.orientation, gi.to_world.scale);
         iboxes[i] = transform_box(in.xf, s->meshes[in.mesh].bounds);   // Model::getAABB = mesh bound
     }
@@ -1053,11 +1060,13 @@ struct Hit {
 // Triangle::intersect (GoblinScene.cpp:75-83, GoblinPrimitive.cpp:103-112,
 // GoblinModel.cpp:39-55).  ray.maxt shrinks in place.  Frag state persists
 // across candidate hits exactly as the reference's single Intersection does.
-bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt) {
+bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt, int filter = FILTER_NONE) {
     ++cnt->closest;
     bool any = false;
     traverse(s->tlas, ray, cnt, [&](uint32_t inst_id) {
         const Instance& in = s->instances[inst_id];
+        // Model::intersect: `if (f != nullptr && !f(this, ray)) return false` (GoblinModel.cpp:44-46, 30-32)
+        if (filter != FILTER_NONE && (in.is_mask ? FILTER_MASK : FILTER_OPAQUE) != filter) return false;
         const Mesh& m = s->meshes[in.mesh];
         Ray r;   // Transform::invertRay: d is NOT renormalised, so t is shared
         r.o = in.xf.invert_point(ray.o);
@@ -1103,11 +1112,12 @@ bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt) {
     return any;
 }
 
-bool scene_occluded(const orc_scene* s, const Ray& ray, Counters* cnt) {   // GoblinScene.cpp:85-87, GoblinBVH.cpp:189-232
+bool scene_occluded(const orc_scene* s, const Ray& ray, Counters* cnt, int filter = FILTER_NONE) {   // GoblinScene.cpp:85-87, GoblinBVH.cpp:189-232
     ++cnt->anyhit;
     bool occ = false;
     traverse(s->tlas, ray, cnt, [&](uint32_t inst_id) {
         const Instance& in = s->instances[inst_id];
+        if (filter != FILTER_NONE && (in.is_mask ? FILTER_MASK : FILTER_OPAQUE) != filter) return false;
         const Mesh& m = s->meshes[in.mesh];
         Ray r;
         r.o = in.xf.invert_point(ray.o);
@@ -1286,6 +1296,28 @@ inline gbl_material resolve_material(const orc_scene* sc, const gbl_material& m,
         r.color2[0] = c.r; r.color2[1] = c.g; r.color2[2] = c.b;
     }
     if (m.tex_exponent >= 0) r.exponent = tex_lookup(sc, m.tex_exponent, f).r;
+    return r;
+}
+
+// A hit's material ready to evaluate.  For MaskMaterial (GoblinMaterial.cpp:747-811) `m` is the wrapped material,
+// `alpha` / `tcolor` the mask's own two lookups.
+struct ResolvedMat {
+    gbl_material m;
+    bool is_mask = false;
+    float alpha = 1.0f;
+    Col tcolor = Col(1.0f);
+};
+inline ResolvedMat resolve_hit_material(const orc_scene* sc, uint32_t material, const Frag& f) {
+    ResolvedMat r;
+    gbl_material outer = resolve_material(sc, sc->materials[material], f);
+    if (outer.type != GBL_MAT_MASK) {
+        r.m = outer;
+        return r;
+    }
+    r.is_mask = true;
+    r.alpha = outer.exponent;
+    r.tcolor = Col(outer.color[0], outer.color[1], outer.color[2]);
+    r.m = resolve_material(sc, sc->materials[outer.masked_material], f);
     return r;
 }
 
@@ -1505,6 +1537,30 @@ Col mat_sample(const gbl_material& m, const Frag& frag, V3 wo, float u_comp, flo
 // ---------------------------------------------------------------------------
 // Lights (GoblinLight.cpp)
 // ---------------------------------------------------------------------------
+// MaskMaterial::bsdf / pdf / sampleBSDF with type == BSDFAll (GoblinMaterial.cpp:747-811)
+Col rmat_bsdf(const ResolvedMat& r, V3 n, V3 wo, V3 wi) {
+    if (!r.is_mask) return mat_bsdf(r.m, n, wo, wi);
+    return r.alpha * mat_bsdf(r.m, n, wo, wi);
+}
+float rmat_pdf(const ResolvedMat& r, V3 n, V3 wo, V3 wi) {
+    if (!r.is_mask) return mat_pdf(r.m, n, wo, wi);
+    return r.alpha * mat_pdf(r.m, n, wo, wi);
+}
+Col rmat_sample(const ResolvedMat& r, const Frag& frag, V3 wo, float u_comp, float u1, float u2, V3* wi, float* pdf, int* sampled) {
+    if (!r.is_mask) return mat_sample(r.m, frag, wo, u_comp, u1, u2, wi, pdf, sampled);
+    float masked_prob = r.alpha;
+    if (u_comp < masked_prob) {
+        Col result = r.alpha * mat_sample(r.m, frag, wo, u_comp, u1, u2, wi, pdf, sampled);
+        *pdf *= masked_prob;
+        return result;
+    }
+    Col result = (1.0f - r.alpha) * r.tcolor;
+    *wi = -normalize(wo);
+    *pdf = 1.0f - masked_prob;
+    *sampled = BSDF_NULL;
+    return result;
+}
+
 float spot_falloff(const Light& l, V3 w) {   // :277-287
     float cos_t = dot(w, l.spot_axis);
     if (cos_t < l.cos_max) return 0.0f;
@@ -1921,10 +1977,31 @@ inline void draw_bsdf_sample(LiCtx* c) {
     }
 }
 
-// PathTracer::evalAttenuation, GoblinPathtracer.cpp:21-48: identity without BSDFnullptr materials.
+// PathTracer::evalAttenuation, GoblinPathtracer.cpp:21-48: walks the BSDFnullptr (mask) surfaces along the ray;
+// identity without them (then only ref_faithful pays for the empty filtered traversal).
 inline Col eval_attenuation(LiCtx* c, const Ray& ray) {
-    if (c->ref_faithful) scene_filtered_traversal(c->s, ray, &c->cnt);
-    return Col(1.0f);
+    const orc_scene* s = c->s;
+    if (!s->has_masks) {
+        if (c->ref_faithful) scene_filtered_traversal(s, ray, &c->cnt);
+        return Col(1.0f);
+    }
+    Col throughput(1.0f);
+    float maxt = ray.maxt;
+    Ray cur = ray;
+    Hit hit;
+    hit.frag.n = V3(0, 0, 0);
+    hit.frag.dpdv = V3(0, 0, 0);
+    while (true) {
+        if (!scene_intersect(s, cur, &hit, &c->cnt, FILTER_MASK)) break;
+        compute_uv_differential(&hit.frag, nullptr);
+        ResolvedMat rm = resolve_hit_material(s, s->instances[hit.instance].material, hit.frag);
+        // sampleBSDF(..., BSDFnullptr): sampleAlpha only -> (1 - alpha) * transparentColor (:784-791)
+        throughput *= (1.0f - rm.alpha) * rm.tcolor;
+        if (throughput == BLACK) break;
+        cur.mint = cur.maxt + hit.epsilon;
+        cur.maxt = maxt;
+    }
+    return throughput;
 }
 
 // PathTracer::Li, GoblinPathtracer.cpp:50-179
@@ -1953,7 +2030,7 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
         int light = s->light_power.sample_discrete(pick, &pick_pdf);   // Scene::sampleLight, GoblinScene.cpp:97-104
         Col Ld(0.0f);
         compute_uv_differential(&hit.frag, bounce == 0 ? primary_diff : nullptr);   // :77; only the camera ray has differentials
-        const gbl_material mat = resolve_material(s, s->materials[s->instances[hit.instance].material], hit.frag);
+        const ResolvedMat mat = resolve_hit_material(s, s->instances[hit.instance].material, hit.frag);
         const Frag& frag = hit.frag;
         V3 wo = -cur.d;
         V3 wi;
@@ -1962,23 +2039,33 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
         Ray shadow;
         Col L = light_sample(s, light, p, epsilon, ls_comp, ls_geo[0], ls_geo[1], &wi, &light_pdf_v, &shadow);
         if (L != BLACK && light_pdf_v > 0.0f) {
-            Col f = mat_bsdf(mat, n, wo, wi);
-            if (f != BLACK && !scene_occluded(s, shadow, &c->cnt)) {
+            Col f = rmat_bsdf(mat, n, wo, wi);
+            if (f != BLACK && !scene_occluded(s, shadow, &c->cnt, FILTER_OPAQUE)) {
                 draw_bsdf_sample(c);
                 Col tr = eval_attenuation(c, shadow);
                 if (light_is_delta(s->lights[light])) {
                     Ld += f * tr * L * absdot(n, wi) / light_pdf_v;
                 } else {
-                    bsdf_pdf = mat_pdf(mat, n, wo, wi);
+                    bsdf_pdf = rmat_pdf(mat, n, wo, wi);
                     float lw = power_heuristic(1, light_pdf_v, 1, bsdf_pdf);
                     Ld += f * tr * L * absdot(n, wi) * lw / light_pdf_v;
                 }
             }
         }
         int sampled = 0;
-        Col f = mat_sample(mat, frag, wo, bs_comp, bs_dir[0], bs_dir[1], &wi, &bsdf_pdf, &sampled);
+        Col f = rmat_sample(mat, frag, wo, bs_comp, bs_dir[0], bs_dir[1], &wi, &bsdf_pdf, &sampled);
         if (f != BLACK && bsdf_pdf > 0.0f) {
-            // (sampledType == BSDFnullptr cannot happen without mask materials)
+            if (sampled == BSDF_NULL) {
+                // stepped on an index-matched (mask) BSDF: punch through, no direct light for this bounce (:122-136)
+                throughput *= (f / bsdf_pdf);
+                cur.o = p; cur.d = wi; cur.mint = epsilon; cur.maxt = INF;
+                Hit nh;
+                nh.frag = hit.frag;
+                if (!scene_intersect(s, cur, &nh, &c->cnt)) break;   // evalEnvironmentLight = 0 on this path
+                hit = nh;
+                epsilon = nh.epsilon;
+                continue;
+            }
             float fw = 1.0f;
             if (!(sampled & BSDF_SPECULAR)) {
                 light_pdf_v = light_pdf(s, light, p, wi);
@@ -1989,6 +2076,28 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
             // The reference traces this "MIS ray" and then the identical
             // extension ray below.  Unless asked to be faithful to that cost we
             // trace it once and reuse the hit.
+            if (s->has_masks) {
+                // With masks the MIS query (isOpaque filter, :148) and the extension query (:170) differ.
+                Hit lh;
+                lh.frag = hit.frag;
+                Ray rr = r;
+                bool lhit = scene_intersect(s, rr, &lh, &c->cnt, FILTER_OPAQUE);
+                draw_bsdf_sample(c);
+                Col tr = eval_attenuation(c, rr);
+                if (lhit && s->instances[lh.instance].area_light == light) {
+                    Col Le = hit_Le(s, lh, -wi);
+                    if (Le != BLACK) Ld += f * tr * Le * absdot(wi, n) * fw / bsdf_pdf;
+                }
+                Li += throughput * Ld / pick_pdf;
+                throughput *= f * absdot(wi, n) / bsdf_pdf;
+                cur = r;
+                Hit nh;
+                nh.frag = hit.frag;
+                if (!scene_intersect(s, cur, &nh, &c->cnt)) break;
+                hit = nh;
+                epsilon = nh.epsilon;
+                continue;
+            }
             Hit lh;
             lh.frag = hit.frag;
             Ray rr = r;

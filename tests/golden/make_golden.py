@@ -61,6 +61,8 @@ CASES = {
     # checkerboard (uv + spherical mapping, filtered through the camera ray's differentials), scale and float textures
     "textured_pt": ("textured", ov((64, 64), 9, 5), 2048, False),
     "textured_ortho": ("textured", ov((48, 48), 4, 4, camera={"type": "orthographic", "film_width": 6.0}), 1024, False),
+    # mask materials: BSDFnullptr punch-through, isOpaque-filtered shadow / MIS queries, evalAttenuation walks
+    "masked_pt": ("masked", ov((64, 64), 9, 6), 2048, False),
 }
 
 

@@ -52,7 +52,9 @@ class _Scheduled:
 
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
-        kw.setdefault("schedule", "auto" if (s.integrator == _abi.GBL_INTEGRATOR_AO or kw.get("rr")) else self._schedule)
+        d = self._t.scene.desc
+        masks = any(d.materials[i].type == _abi.GBL_MAT_MASK for i in range(d.num_materials))   # megakernel only
+        kw.setdefault("schedule", "auto" if (s.integrator == _abi.GBL_INTEGRATOR_AO or kw.get("rr") or masks) else self._schedule)
         return self._t.render(**kw)
 
 
@@ -72,7 +74,7 @@ def fake_window(full, n_pixels):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box",
-                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho"])
+                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -100,7 +102,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
-                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho"])
+                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -131,6 +133,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     ("bunny", gs.config_overrides(resolution=(32, 32), spp=4, method="ao", ao_samples=16)),
     ("shapes", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("textured", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
+    ("masked", gs.config_overrides(resolution=(40, 40), spp=9, depth=6)),
     ("shapes", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
                     camera={"film": {"resolution": [32, 32]}, "lens_radius": 0.1, "focal_distance": 4.6})),
 ])
@@ -211,6 +214,17 @@ def test_linearity_two_passes(torch, schedule):
     r.render(film=film, seed=1)
     r.render(film=film, seed=2)
     np.testing.assert_allclose(film.numpy(), f1 + f2, rtol=2e-5, atol=1e-6)
+
+
+def test_masks_run_on_the_megakernel_only(torch):
+    scene = gs.load_scene("masked", gs.config_overrides(resolution=(16, 16), spp=1, depth=3))
+    from goblin_amd.renderer import HipPathTracer
+    r = HipPathTracer(scene, 0)
+    r.render(schedule="auto")
+    r.render(schedule="megakernel")
+    with pytest.raises(_abi.GoblinError) as e:
+        r.render(schedule="wavefront")
+    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
 
 
 def test_error_behaviour(torch, schedule):

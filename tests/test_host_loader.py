@@ -148,6 +148,31 @@ def test_texture_graphs():
     assert s.desc.num_textures == 0 and s.desc.materials[0].tex_color == -1
 
 
+def test_mask_material():
+    """createMaskMaterial (GoblinMaterial.cpp:929-950): alpha defaults to 1, transparent_color to white, the wrapped
+    material must already exist when the mask is created."""
+    mats = [{"name": "inner", "type": "lambert", "Kd": "w"},
+            {"name": "m", "type": "mask", "material": "inner", "alpha": "a"}]
+    tex = [{"name": "w", "type": "constant", "color": [0.5, 0.6, 0.7]},
+           {"format": "float", "name": "a", "type": "constant", "float": 0.25}]
+    s = load(minimal(materials=mats, textures=tex))
+    d = s.desc
+    m = d.materials[d.instances[0].material]
+    assert m.type == _abi.GBL_MAT_MASK and m.exponent == 0.25 and list(m.color) == [1, 1, 1]
+    inner = d.materials[m.masked_material]
+    assert inner.type == _abi.GBL_MAT_LAMBERT and inner.masked_material == -1
+    s = load(minimal(materials=[mats[0], {"name": "m", "type": "mask", "material": "inner"}], textures=tex))
+    m = s.desc.materials[s.desc.instances[0].material]
+    assert m.exponent == 1.0                                            # "no feed in alpha"
+    with pytest.raises(_abi.GoblinError) as e:                          # wrapped material defined later
+        load(minimal(materials=[mats[1], mats[0]], textures=tex))
+    assert e.value.status == _abi.GBL_ERR_INVALID
+    with pytest.raises(_abi.GoblinError) as e:                          # mask of a mask
+        load(minimal(materials=[mats[0], {"name": "m1", "type": "mask", "material": "inner"},
+                                {"name": "m", "type": "mask", "material": "m1"}], textures=tex))
+    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+
+
 def test_unused_out_of_scope_declarations_are_ignored():
     """bunny.json declares a sphere geometry nothing uses (examples/bunny.json:36-40)."""
     doc = minimal()
