@@ -143,10 +143,6 @@ __device__ __forceinline__ void trav_begin(const DevScene& sc, TravState& st, F3
 // Entry distance of one child, INFINITY if the ray misses it.  `n*` / `f*` hold the grid
 // coordinates of the child's planes the ray crosses first / last on each axis (chosen per ray
 // direction once per node), so no per-child min/max is needed, and an unused slot
-// (qlo = 255 > qhi = 0) is an empty interval for every direction.
-// Entry distance of one child, INFINITY if the ray misses it.  `n*` / `f*` hold the grid
-// coordinates of the child's planes the ray crosses first / last on each axis (chosen per ray
-// direction once per node), so no per-child min/max is needed, and an unused slot
 // (qlo = 255 > qhi = 0) is an empty interval for every direction.  (Pairing the near and far plane of an
 // axis in one v_pk_fma_f32 was measured: 52.7 ms against 51.5 ms for the scalar FMAs on config 2.)
 __device__ __forceinline__ float child_entry(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, F3 A, F3 B,
