@@ -124,7 +124,7 @@ class gbl_timing(C.Structure):
 class gbl_info(C.Structure):
     _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("window", C.c_int32 * 4), ("blas_nodes", C.c_uint64),
                 ("tlas_nodes", C.c_uint64), ("triangles", C.c_uint64), ("instances", C.c_uint64),
-                ("scene_bytes", C.c_uint64)]
+                ("scene_bytes", C.c_uint64), ("instanced_triangles", C.c_uint64)]
 
 
 HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "gbl_host_free",

