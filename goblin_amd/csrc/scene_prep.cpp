@@ -175,6 +175,15 @@ int balanced_height(size_t n, int leaf) {
     return h;
 }
 
+// SAH cost of visiting a node relative to one triangle test (tuning knob: GBL_SAH_CT)
+inline float sah_traversal_cost() {
+    static const float ct = [] {
+        const char* e = getenv("GBL_SAH_CT");
+        return e ? static_cast<float>(atof(e)) : 1.0f;
+    }();
+    return ct;
+}
+
 struct Builder {
     std::vector<Prim>& prims;
     std::vector<TmpNode> nodes;
@@ -228,7 +237,7 @@ struct Builder {
                     size_t rn = right_n[b + 1];
                     if (ln == 0 || rn == 0) continue;
                     if (balanced_height(std::max(ln, rn), max_leaf) > room) continue;   // would break the depth cap
-                    float cost = 1.0f + (left.half_area() * ln + right_acc[b + 1].half_area() * rn) / parent_area;
+                    float cost = sah_traversal_cost() + (left.half_area() * ln + right_acc[b + 1].half_area() * rn) / parent_area;
                     if (cost < best_cost) {
                         best_cost = cost;
                         best_axis = axis;
