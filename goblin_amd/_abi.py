@@ -124,14 +124,16 @@ class gbl_timing(C.Structure):
 class gbl_info(C.Structure):
     _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("window", C.c_int32 * 4), ("blas_nodes", C.c_uint64),
                 ("tlas_nodes", C.c_uint64), ("triangles", C.c_uint64), ("instances", C.c_uint64),
-                ("scene_bytes", C.c_uint64), ("instanced_triangles", C.c_uint64)]
+                ("scene_bytes", C.c_uint64), ("instanced_triangles", C.c_uint64), ("build_ms", C.c_double),
+                ("blas_depth", C.c_int32), ("tlas_depth", C.c_int32)]
 
 
 HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "gbl_host_free",
                 "gbl_host_last_error", "gbl_host_sample_window", "gbl_host_round_to_square",
                 "gbl_host_sample_dimension", "gbl_host_film_normalize", "gbl_host_write_pfm", "gbl_host_output_path",
                 "gbl_host_bloom", "gbl_host_tone_map", "gbl_host_write_ppm", "gbl_host_write_exr", "gbl_host_write_image"]
-HIP_SYMBOLS = ["gbl_create", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
+GBL_CREATE_DEVICE_BVH = 1
+HIP_SYMBOLS = ["gbl_create", "gbl_create_ex", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
                "gbl_last_error", "gbl_abi_version", "gbl_get_timings"]
 
 _host = None
@@ -189,6 +191,7 @@ def hip_lib():
         import torch  # noqa: F401
         lib = C.CDLL(path)
         lib.gbl_create.argtypes = [C.POINTER(gbl_scene_desc), C.c_int, C.POINTER(C.c_void_p)]
+        lib.gbl_create_ex.argtypes = [C.POINTER(gbl_scene_desc), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
         lib.gbl_render.argtypes = [C.c_void_p, C.POINTER(gbl_render_params), C.c_void_p, C.POINTER(gbl_stats)]
         lib.gbl_film_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gbl_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +20,8 @@
 #include "device_scene.h"
 #include "kernels/render_kernels.h"
 #include "kernels/wavefront.h"
+#include "kernels/lbvh.h"
+#include <hipcub/hipcub.hpp>
 #include "scene_prep.h"
 
 namespace {
@@ -42,6 +46,7 @@ struct gbl_ctx {
     float4* wf_li = nullptr;
     size_t wf_li_entries = 0;
     uint64_t li_budget = 0;   // li_budget_bytes()
+    double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     uint32_t* wf_host_flags = nullptr;   // pinned
     // ring of event triples for gbl_get_timings
     static const int kTimingRing = 64;
@@ -263,6 +268,100 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Device BLAS build (kernels/lbvh.h).  One mesh at a time: nodes are written at node_base (absolute child
+// references), DevTri records at tri_base in Morton order.  Returns the mesh's root reference.
+// ---------------------------------------------------------------------------
+namespace {
+struct LbvhScratch {
+    std::vector<void*> ptrs;
+    ~LbvhScratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    bool alloc(T** out, size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return false;
+        ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return true;
+    }
+};
+
+gbl_status build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,
+                             DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base,
+                             int32_t* root_out, uint32_t* nodes_out, int* depth_out) {
+    LbvhScratch sc;
+    unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+    LbvhBox* tri_box = nullptr;
+    LbvhTree t;
+    memset(&t, 0, sizeof(t));
+    LbvhFrontier *fa = nullptr, *fb = nullptr;
+    uint32_t* counters = nullptr;   // [0] next frontier size, [1] nodes emitted
+    const size_t ni = n > 1 ? n - 1 : 1;
+    if (!sc.alloc(&keys, n) || !sc.alloc(&keys_sorted, n) || !sc.alloc(&tri_box, n) || !sc.alloc(&t.left, ni) || !sc.alloc(&t.right, ni) ||
+        !sc.alloc(&t.parent, 2 * static_cast<size_t>(n)) || !sc.alloc(&t.first, ni) || !sc.alloc(&t.last, ni) || !sc.alloc(&t.box, ni) ||
+        !sc.alloc(&t.leaf_box, n) || !sc.alloc(&t.visits, ni) || !sc.alloc(&fa, ni) || !sc.alloc(&fb, ni) || !sc.alloc(&counters, 2)) {
+        ctx->error = "hipMalloc(device BVH build scratch) failed";
+        return GBL_ERR_OOM;
+    }
+    LbvhBox mesh;
+    for (int a = 0; a < 3; ++a) {
+        mesh.lo[a] = lo[a];
+        mesh.hi[a] = hi[a];
+    }
+    const dim3 block(256), grid((n + 255) / 256);
+    hipLaunchKernelGGL(lbvh_keys, grid, block, 0, 0, d_pos, d_idx, n, mesh, keys, tri_box);
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
+    unsigned char* temp = nullptr;
+    if (!sc.alloc(&temp, temp_bytes)) {
+        ctx->error = "hipMalloc(radix sort scratch) failed";
+        return GBL_ERR_OOM;
+    }
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
+    hipLaunchKernelGGL(lbvh_tris, grid, block, 0, 0, d_pos, d_idx, keys_sorted, n, shade_base, d_tris + tri_base);
+    *nodes_out = 0;
+    *depth_out = 0;
+    if (n <= GBL_MAX_LEAF_TRIS) {   // the whole mesh is one leaf
+        *root_out = ~static_cast<int32_t>((tri_base << 2) | (n - 1u));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        return GBL_OK;
+    }
+    hipLaunchKernelGGL(lbvh_gather_boxes, grid, block, 0, 0, keys_sorted, tri_box, n, t.leaf_box);
+    hipLaunchKernelGGL(lbvh_hierarchy, grid, block, 0, 0, keys_sorted, static_cast<int>(n), t);
+    HIP_TRY(ctx, hipMemsetAsync(t.visits, 0, ni * sizeof(uint32_t), 0));
+    hipLaunchKernelGGL(lbvh_fit, grid, block, 0, 0, static_cast<int>(n), t);
+    // collapse, one 4-wide level per launch
+    LbvhFrontier rootf = {0, 0};
+    uint32_t init[2] = {0u, 1u};
+    HIP_TRY(ctx, hipMemcpy(fa, &rootf, sizeof(rootf), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(counters, init, sizeof(init), hipMemcpyHostToDevice));
+    uint32_t n_in = 1;
+    int depth = 0;
+    while (n_in > 0) {
+        ++depth;
+        hipLaunchKernelGGL(lbvh_collapse, dim3((n_in + 255) / 256), block, 0, 0, t, fa, n_in, fb, counters, counters + 1, d_nodes + node_base,
+                           node_base, tri_base);
+        uint32_t h[2];
+        HIP_TRY(ctx, hipMemcpy(h, counters, sizeof(h), hipMemcpyDeviceToHost));
+        n_in = h[0];
+        *nodes_out = h[1];
+        HIP_TRY(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t), 0));
+        std::swap(fa, fb);
+        if (depth > 128) {
+            ctx->error = "device BVH build did not terminate";
+            return GBL_ERR_DEVICE;
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    *root_out = node_base;
+    *depth_out = depth;
+    return GBL_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int gbl_abi_version(void) { return GBL_ABI_VERSION; }
@@ -270,6 +369,12 @@ int gbl_abi_version(void) { return GBL_ABI_VERSION; }
 const char* gbl_last_error(const gbl_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
+    const char* e = getenv("GBL_BVH_BUILD");
+    return gbl_create_ex(desc, device, (e && !strcmp(e, "device")) ? GBL_CREATE_DEVICE_BVH : 0u, out);
+}
+
+gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags, gbl_ctx** out) {
+    const bool device_bvh = (flags & GBL_CREATE_DEVICE_BVH) != 0;
     if (!desc || !out) {
         g_create_error = "null argument";
         return GBL_ERR_INVALID;
@@ -277,7 +382,8 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     *out = nullptr;
     PackedScene packed;
     std::string err;
-    gbl_status st = pack_scene(desc, &packed, &err);
+    auto t_pack0 = std::chrono::steady_clock::now();
+    gbl_status st = pack_scene(desc, &packed, &err, device_bvh);
     if (st != GBL_OK) {
         g_create_error = err;
         return st;
@@ -307,8 +413,53 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
     DevScene& sc = ctx->scene;
     std::vector<float> ftab(packed.filter_table, packed.filter_table + 256);
-    if ((st = upload(ctx, packed.nodes, &sc.nodes)) != GBL_OK) return bail(st);
-    if ((st = upload(ctx, packed.tris, &sc.tris)) != GBL_OK) return bail(st);
+    if (!device_bvh) {
+        if ((st = upload(ctx, packed.nodes, &sc.nodes)) != GBL_OK) return bail(st);
+        if ((st = upload(ctx, packed.tris, &sc.tris)) != GBL_OK) return bail(st);
+    } else {
+        // nodes = [TLAS (from the host) | mesh 0 | mesh 1 | ...], tris = every mesh's triangles in Morton order
+        size_t node_cap = packed.nodes.size(), tri_cap = 0;
+        for (uint32_t m = 0; m < desc->num_meshes; ++m)
+            if (desc->meshes[m].shape == GBL_SHAPE_MESH) {
+                node_cap += desc->meshes[m].tri_count;
+                tri_cap += desc->meshes[m].tri_count;
+            }
+        std::vector<DevNode> nodes_h(node_cap);
+        std::copy(packed.nodes.begin(), packed.nodes.end(), nodes_h.begin());
+        std::vector<DevTri> tris_h(tri_cap);
+        if ((st = upload(ctx, nodes_h, &sc.nodes)) != GBL_OK) return bail(st);
+        if ((st = upload(ctx, tris_h, &sc.tris)) != GBL_OK) return bail(st);
+        std::vector<float> pos_h(desc->positions, desc->positions + 3 * static_cast<size_t>(desc->num_vertices));
+        std::vector<uint32_t> idx_h(desc->indices, desc->indices + 3 * static_cast<size_t>(desc->num_triangles));
+        const float* d_pos = nullptr;
+        const uint32_t* d_idx = nullptr;
+        if ((st = upload(ctx, pos_h, &d_pos)) != GBL_OK) return bail(st);
+        if ((st = upload(ctx, idx_h, &d_idx)) != GBL_OK) return bail(st);
+        std::vector<int32_t> mesh_root(desc->num_meshes, 0);
+        int32_t node_base = static_cast<int32_t>(packed.nodes.size());
+        uint32_t tri_base = 0;
+        int max_depth = 0;
+        for (uint32_t m = 0; m < desc->num_meshes; ++m) {
+            const gbl_mesh& gm = desc->meshes[m];
+            if (gm.shape != GBL_SHAPE_MESH) continue;
+            uint32_t used = 0;
+            int depth = 0;
+            st = build_blas_device(ctx, d_pos + 3 * static_cast<size_t>(gm.vertex_offset), d_idx + 3 * static_cast<size_t>(gm.tri_offset), gm.tri_count,
+                                   &packed.mesh_lo[3 * m], &packed.mesh_hi[3 * m], const_cast<DevNode*>(sc.nodes), node_base,
+                                   const_cast<DevTri*>(sc.tris), tri_base, gm.tri_offset, &mesh_root[m], &used, &depth);
+            if (st != GBL_OK) return bail(st);
+            node_base += static_cast<int32_t>(used);
+            tri_base += gm.tri_count;
+            max_depth = std::max(max_depth, depth);
+        }
+        for (size_t i = 0; i < packed.instances.size(); ++i)
+            if (packed.instances[i].shape == 0u) packed.instances[i].root = mesh_root[packed.instances[i].mesh];
+        packed.blas_max_depth = max_depth;
+        packed.blas_nodes = static_cast<uint64_t>(node_base) - packed.nodes.size();
+        packed.stack_entries = 3 * (packed.tlas_depth + max_depth) + 2;
+        packed.tris.resize(tri_cap);   // for gbl_info only
+    }
+    ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if ((st = upload(ctx, packed.tri_shade, &sc.tri_shade)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.normals, &sc.normals)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.uvs, &sc.uvs)) != GBL_OK) return bail(st);
@@ -352,6 +503,9 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     ctx->info.tlas_nodes = packed.tlas_nodes;
     ctx->info.triangles = packed.tris.size();
     ctx->info.instances = packed.instances.size();
+    ctx->info.build_ms = ctx->build_ms;
+    ctx->info.blas_depth = packed.blas_max_depth;
+    ctx->info.tlas_depth = packed.tlas_depth;
     ctx->info.instanced_triangles = 0;
     for (uint32_t i = 0; i < desc->num_instances; ++i) ctx->info.instanced_triangles += desc->meshes[desc->instances[i].mesh].tri_count;
     *out = ctx;

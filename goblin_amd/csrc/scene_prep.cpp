@@ -410,7 +410,7 @@ int floor_i(float f) { return static_cast<int>(std::floor(f)); }
 
 }  // namespace
 
-gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* err) {
+gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* err, bool device_blas) {
     if (!d || d->abi_version != GBL_ABI_VERSION) {
         *err = "scene description has the wrong abi_version";
         return GBL_ERR_INVALID;
@@ -492,6 +492,15 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         const float* P = d->positions + 3 * static_cast<size_t>(gm.vertex_offset);
         const uint32_t* I = d->indices + 3 * static_cast<size_t>(gm.tri_offset);
         for (uint32_t v = 0; v < gm.vertex_count; ++v) mesh_bounds[mi].grow(P + 3 * v);
+        if (device_blas) {   // shading records only; the tree and the DevTri order come from kernels/lbvh.h
+            for (uint32_t t = 0; t < gm.tri_count; ++t) {
+                DevTriShade& s = out->tri_shade[gm.tri_offset + t];
+                for (int k = 0; k < 3; ++k) s.v[k] = gm.vertex_offset + I[3 * t + k];
+                s.flags = (gm.has_normal ? 1u : 0u) | (gm.has_uv ? 2u : 0u);
+            }
+            mesh_root[mi] = 0;
+            continue;
+        }
         std::vector<Prim> prims(gm.tri_count);
         for (uint32_t t = 0; t < gm.tri_count; ++t) {
             Prim& p = prims[t];
@@ -527,6 +536,13 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         out->blas_max_depth = std::max(out->blas_max_depth, f4.depth);
     }
     out->blas_nodes = out->nodes.size();
+    out->mesh_lo.resize(3 * d->num_meshes);
+    out->mesh_hi.resize(3 * d->num_meshes);
+    for (uint32_t mi = 0; mi < d->num_meshes; ++mi)
+        for (int k = 0; k < 3; ++k) {
+            out->mesh_lo[3 * mi + k] = mesh_bounds[mi].lo[k];
+            out->mesh_hi[3 * mi + k] = mesh_bounds[mi].hi[k];
+        }
 
     // ---- instances + TLAS
     out->instances.resize(d->num_instances);

@@ -24,9 +24,13 @@ struct PackedScene {
     int32_t has_masks = 0;  // DevScene::has_masks
     uint64_t blas_nodes = 0, tlas_nodes = 0;
     int blas_max_depth = 0, tlas_depth = 0;
+    std::vector<float> mesh_lo, mesh_hi;   // 3 per mesh: object bounds
     DevCamera camera;
     DevFilm film;
 };
 
 // Returns GBL_OK or an error with *err set.
-gbl_status pack_scene(const gbl_scene_desc* desc, PackedScene* out, std::string* err);
+// device_blas: leave the triangle BLASes to the device builder (kernels/lbvh.h): `nodes` then holds the TLAS only
+// (at indices 0..), `tris` stays empty, mesh instances get root = 0 (patched after the device build) and
+// `mesh_lo/hi` carry the object bounds the Morton codes are scaled by.
+gbl_status pack_scene(const gbl_scene_desc* desc, PackedScene* out, std::string* err, bool device_blas = false);

@@ -44,7 +44,8 @@ class Film:
 class HipPathTracer:
     """Device path tracer / AO renderer bound to one scene on one GPU."""
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, bvh="host"):
+        """bvh: "host" (binned SAH, the default) or "device" (Morton-sorted linear BVH built on the GPU)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("HipPathTracer needs a HIP device: torch.cuda.is_available() is False and there is no "
@@ -54,7 +55,12 @@ class HipPathTracer:
         self.device_index = device if isinstance(device, int) else torch.device(device).index or 0
         self.device = torch.device("cuda", self.device_index)
         handle = C.c_void_p()
-        st = self.lib.gbl_create(scene.desc_ptr, self.device_index, C.byref(handle))
+        if bvh not in ("host", "device"):
+            raise ValueError("bvh must be 'host' or 'device'")
+        if bvh == "device":
+            st = self.lib.gbl_create_ex(scene.desc_ptr, self.device_index, _abi.GBL_CREATE_DEVICE_BVH, C.byref(handle))
+        else:
+            st = self.lib.gbl_create(scene.desc_ptr, self.device_index, C.byref(handle))
         if st != _abi.GBL_OK:
             raise _abi.GoblinError(st, self.lib.gbl_last_error(None).decode())
         self.handle = handle

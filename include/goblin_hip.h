@@ -359,6 +359,9 @@ typedef struct gbl_stats {
  * (replaces Scene/BVH/Model construction: GoblinScene.cpp:11-27,
  * GoblinBVH.cpp:34-151, GoblinModel.cpp:10-26).  `device` is a HIP ordinal. */
 gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out);
+/* Same with flags (GBL_CREATE_*, declared below).  gbl_create is gbl_create_ex
+ * with flags 0, or GBL_CREATE_DEVICE_BVH when GBL_BVH_BUILD=device is set. */
+gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags, gbl_ctx** out);
 
 /* Run the integrator over params->window and ACCUMULATE into film_accum, a
  * device buffer of xres*yres float4 {sum w*L.rgb, sum w} (the per-thread
@@ -388,12 +391,18 @@ typedef struct gbl_timing {
 int gbl_get_timings(gbl_ctx* ctx, int n, gbl_timing* out);
 
 /* Scene facts the caller needs for buffer sizing and reporting. */
+/* gbl_create_ex flags */
+#define GBL_CREATE_DEVICE_BVH 1u /* build the triangle BLASes on the GPU (Morton-sorted linear BVH) instead of the
+                                  * host's binned-SAH build: faster to construct, slower to trace */
+
 typedef struct gbl_info {
     int32_t xres, yres;
     int32_t window[4];      /* full sample window x0,x1,y0,y1 */
     uint64_t blas_nodes, tlas_nodes, triangles, instances;
     uint64_t scene_bytes;   /* device bytes held by the scene */
     uint64_t instanced_triangles; /* sum over instances of their mesh's triangle count */
+    double build_ms;        /* host wall time of scene packing + BVH build + geometry upload in gbl_create */
+    int32_t blas_depth, tlas_depth; /* 4-wide levels */
 } gbl_info;
 gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out);
 
