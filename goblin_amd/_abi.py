@@ -133,7 +133,7 @@ HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "
                 "gbl_host_sample_dimension", "gbl_host_film_normalize", "gbl_host_write_pfm", "gbl_host_output_path",
                 "gbl_host_bloom", "gbl_host_tone_map", "gbl_host_write_ppm", "gbl_host_write_exr", "gbl_host_write_image"]
 GBL_CREATE_DEVICE_BVH = 1
-HIP_SYMBOLS = ["gbl_create", "gbl_create_ex", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
+HIP_SYMBOLS = ["gbl_create", "gbl_create_ex", "gbl_update_instances", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
                "gbl_last_error", "gbl_abi_version", "gbl_get_timings"]
 
 _host = None
@@ -192,6 +192,7 @@ def hip_lib():
         lib = C.CDLL(path)
         lib.gbl_create.argtypes = [C.POINTER(gbl_scene_desc), C.c_int, C.POINTER(C.c_void_p)]
         lib.gbl_create_ex.argtypes = [C.POINTER(gbl_scene_desc), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.gbl_update_instances.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(gbl_trs)]
         lib.gbl_render.argtypes = [C.c_void_p, C.POINTER(gbl_render_params), C.c_void_p, C.POINTER(gbl_stats)]
         lib.gbl_film_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gbl_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

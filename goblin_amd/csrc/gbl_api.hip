@@ -42,11 +42,23 @@ struct gbl_ctx {
     void* rccl_allreduce = nullptr;
     // wavefront pool (allocated on first use)
     uint32_t wf_pool = 0;
+    uint32_t* wf_spill = nullptr;   // wf_ensure_spill()
+    int wf_spill_levels = 0;
     WfArgs wf;
     float4* wf_li = nullptr;
     size_t wf_li_entries = 0;
     uint64_t li_budget = 0;   // li_budget_bytes()
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
+    // what gbl_update_instances needs to rebuild the TLAS
+    std::vector<gbl_instance> h_instances;
+    std::vector<gbl_mesh> h_meshes;
+    std::vector<gbl_material> h_materials;
+    std::vector<float> mesh_lo, mesh_hi;
+    std::vector<int32_t> mesh_root;
+    int32_t tlas_base = 0;
+    uint32_t tlas_capacity = 0;
+    int blas_depth = 0;
+    bool has_directional = false;
     uint32_t* wf_host_flags = nullptr;   // pinned
     // ring of event triples for gbl_get_timings
     static const int kTimingRing = 64;
@@ -128,10 +140,6 @@ gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     WF_A(sh_o, pool); WF_A(sh_d, pool); WF_A(sh_c, pool); WF_A(sh_count, pool / 64);
     WF_A(live_flags, 8);
     WF_A(wave_next, pool / 64);
-    {   // stack levels beyond the LDS part, one column per thread of the largest persistent trace grid (8 WGs per CU)
-        const size_t deep = ctx->scene.stack_entries > GBL_WF_STACK_LDS ? ctx->scene.stack_entries - GBL_WF_STACK_LDS : 1;
-        WF_A(stack_spill, deep * static_cast<size_t>(ctx->num_cus) * 8 * GBL_BLOCK);
-    }
 #undef WF_A
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_flags), 8 * sizeof(uint32_t)) != hipSuccess) {
         ctx->error = "hipHostMalloc(wavefront flags) failed";
@@ -151,6 +159,22 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
         if (const char* e = getenv("GBL_LI_BUDGET_MB")) ctx->li_budget = std::max<uint64_t>(1ull << 20, strtoull(e, nullptr, 10) << 20);
     }
     return ctx->li_budget;
+}
+
+// Stack levels of the wavefront trace kernels beyond the LDS part: one column per thread of the largest persistent
+// trace grid (8 workgroups per CU).  Re-made when an instance edit deepens the TLAS.
+gbl_status wf_ensure_spill(gbl_ctx* ctx) {
+    const int deep = ctx->scene.stack_entries > GBL_WF_STACK_LDS ? ctx->scene.stack_entries - GBL_WF_STACK_LDS : 1;
+    if (ctx->wf_spill && deep <= ctx->wf_spill_levels) return GBL_OK;
+    if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
+    ctx->wf_spill = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->wf_spill), static_cast<size_t>(deep) * ctx->num_cus * 8 * GBL_BLOCK * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        ctx->error = std::string("hipMalloc(trace stack backing): ") + hipGetErrorString(e);
+        return GBL_ERR_OOM;
+    }
+    ctx->wf_spill_levels = deep;
+    return GBL_OK;
 }
 
 // per-sample radiance scratch (16 B per sample), grown on demand
@@ -174,6 +198,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     const DevScene& sc = ctx->scene;
     gbl_status st = wf_ensure_pool(ctx);
     if (st != GBL_OK) return st;
+    if ((st = wf_ensure_spill(ctx)) != GBL_OK) return st;
     const uint64_t window_pixels = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * (ra.window[3] - ra.window[2]);
     // samples per pass: bound the per-sample radiance buffer (16 B per sample) to ~2 GiB
     int pass_spp = ra.spp;
@@ -186,6 +211,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
         return GBL_ERR_INVALID;
     }
     WfArgs wa = ctx->wf;
+    wa.stack_spill = ctx->wf_spill;
     if (ra.li_out) {
         wa.li_buf = reinterpret_cast<float4*>(ra.li_out);   // single pass: li_buf is the caller's buffer, in its order
     } else {
@@ -454,6 +480,8 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
         }
         for (size_t i = 0; i < packed.instances.size(); ++i)
             if (packed.instances[i].shape == 0u) packed.instances[i].root = mesh_root[packed.instances[i].mesh];
+        for (uint32_t m = 0; m < desc->num_meshes; ++m)
+            if (desc->meshes[m].shape == GBL_SHAPE_MESH) packed.mesh_root[m] = mesh_root[m];
         packed.blas_max_depth = max_depth;
         packed.blas_nodes = static_cast<uint64_t>(node_base) - packed.nodes.size();
         packed.stack_entries = 3 * (packed.tlas_depth + max_depth) + 2;
@@ -503,6 +531,17 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     ctx->info.tlas_nodes = packed.tlas_nodes;
     ctx->info.triangles = packed.tris.size();
     ctx->info.instances = packed.instances.size();
+    ctx->h_instances.assign(desc->instances, desc->instances + desc->num_instances);
+    ctx->h_meshes.assign(desc->meshes, desc->meshes + desc->num_meshes);
+    ctx->h_materials.assign(desc->materials, desc->materials + desc->num_materials);
+    ctx->mesh_lo = packed.mesh_lo;
+    ctx->mesh_hi = packed.mesh_hi;
+    ctx->mesh_root = packed.mesh_root;
+    ctx->tlas_base = packed.tlas_base;
+    ctx->tlas_capacity = packed.tlas_capacity;
+    ctx->blas_depth = packed.blas_max_depth;
+    for (uint32_t i = 0; i < desc->num_lights; ++i)
+        if (desc->lights[i].type == GBL_LIGHT_DIRECTIONAL) ctx->has_directional = true;
     ctx->info.build_ms = ctx->build_ms;
     ctx->info.blas_depth = packed.blas_max_depth;
     ctx->info.tlas_depth = packed.tlas_depth;
@@ -512,11 +551,62 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     return GBL_OK;
 }
 
+gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world) {
+    if (!ctx) return GBL_ERR_INVALID;
+    if (!to_world || static_cast<uint64_t>(first) + count > ctx->h_instances.size()) {
+        ctx->error = "gbl_update_instances: instance range out of bounds";
+        return GBL_ERR_INVALID;
+    }
+    if (ctx->has_directional) {
+        ctx->error = "gbl_update_instances: a directional light's power depends on the scene bound (GoblinLight.cpp:203-210); "
+                     "re-create the context instead";
+        return GBL_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < count; ++i)
+        if (ctx->h_instances[first + i].area_light >= 0) {
+            ctx->error = "gbl_update_instances: instance " + std::to_string(first + i) + " carries an area light, whose own transform would "
+                         "have to move with it; re-create the context instead";
+            return GBL_ERR_UNSUPPORTED;
+        }
+    std::vector<gbl_instance> edited = ctx->h_instances;
+    for (uint32_t i = 0; i < count; ++i) edited[first + i].to_world = to_world[i];
+    std::vector<DevInstance> inst;
+    std::vector<DevNode> tlas;
+    int32_t root = 0;
+    int depth = 0;
+    float lo[3], hi[3];
+    std::string err;
+    gbl_status st = build_tlas(edited.data(), static_cast<uint32_t>(edited.size()), ctx->h_meshes.data(), ctx->h_materials.data(), ctx->mesh_lo.data(),
+                               ctx->mesh_hi.data(), ctx->mesh_root.data(), ctx->tlas_base, &inst, &tlas, &root, &depth, lo, hi, &err);
+    if (st != GBL_OK) {
+        ctx->error = err;
+        return st;
+    }
+    if (tlas.size() > ctx->tlas_capacity) {
+        ctx->error = "gbl_update_instances: rebuilt TLAS does not fit its reserved nodes";
+        return GBL_ERR_DEVICE;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());   // no render may be reading the old TLAS
+    DevScene& sc = ctx->scene;
+    if (!inst.empty())
+        HIP_TRY(ctx, hipMemcpy(const_cast<DevInstance*>(sc.instances), inst.data(), inst.size() * sizeof(DevInstance), hipMemcpyHostToDevice));
+    if (!tlas.empty())
+        HIP_TRY(ctx, hipMemcpy(const_cast<DevNode*>(sc.nodes) + ctx->tlas_base, tlas.data(), tlas.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+    sc.tlas_root = root;
+    sc.stack_entries = 3 * (depth + ctx->blas_depth) + 2;   // (the wavefront stack backing is re-checked at render time)
+    ctx->info.tlas_depth = depth;
+    ctx->info.tlas_nodes = tlas.size();
+    ctx->h_instances.swap(edited);
+    return GBL_OK;
+}
+
 void gbl_destroy(gbl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
+    if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
     if (ctx->wf_host_flags) (void)hipHostFree(ctx->wf_host_flags);
     for (int i = 0; i < gbl_ctx::kTimingRing; ++i)
         for (int k = 0; k < 3; ++k)

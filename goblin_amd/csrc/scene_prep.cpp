@@ -289,8 +289,9 @@ inline float nudge_up(float v) { return v + std::fabs(v) * 4e-7f + 1e-30f; }
 struct Flat4 {
     const Builder& b;
     std::vector<DevNode>& out;
+    int32_t base;         // index out[0] has in the device node array
     int depth = 0;        // deepest 4-wide level reached (root = 1)
-    Flat4(const Builder& bb, std::vector<DevNode>& o) : b(bb), out(o) {}
+    Flat4(const Builder& bb, std::vector<DevNode>& o, int32_t base_index = 0) : b(bb), out(o), base(base_index) {}
 
     template <class LeafRef>
     int32_t emit(int node, int level, LeafRef& leaf_ref) {
@@ -315,7 +316,7 @@ struct Flat4 {
             kids[best] = c.left;
             kids[n++] = c.right;
         }
-        int32_t me = static_cast<int32_t>(out.size());
+        int32_t me = base + static_cast<int32_t>(out.size());
         out.push_back(DevNode());
         int32_t refs[4];
         for (int i = 0; i < 4; ++i) refs[i] = i < n ? emit(kids[i], level + 1, leaf_ref) : static_cast<int32_t>(GBL_REF_NONE);
@@ -360,7 +361,7 @@ struct Flat4 {
             nd.qhi[a] = qh;
         }
         for (int i = 0; i < 4; ++i) nd.child[i] = refs[i];
-        out[me] = nd;
+        out[me - base] = nd;
         return me;
     }
 };
@@ -406,6 +407,73 @@ int texture_depth(const gbl_scene_desc* d, int32_t id, int guard) {
 }
 
 int ceil_i(float f) { return static_cast<int>(std::ceil(f)); }
+
+}  // namespace
+
+// Instances (transforms in the reference's float order, world boxes by Transform::onBBox) and the TLAS over them.
+// TLAS node k gets device index tlas_base + k; sb_lo/hi return the union of the instance boxes.
+gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* meshes, const gbl_material* materials, const float* mesh_lo,
+                      const float* mesh_hi, const int32_t* mesh_root, int32_t tlas_base, std::vector<DevInstance>* out_inst,
+                      std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err) {
+    const int kTlasCap = 22;
+    out_inst->resize(n);
+    out_nodes->clear();
+    std::vector<Prim> iprims(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const gbl_instance& gi = inst[i];
+        Trs t = compose(gi.to_world.position, gi.to_world.orientation, gi.to_world.scale);
+        if (!t.invertible) {
+            *err = "instance " + std::to_string(i) + ": |det(toWorld)| < 1e-5, the reference cannot invert this transform "
+                   "(GoblinMatrix.cpp:451); use a uniform scale >= 0.0216";
+            return GBL_ERR_INVALID;
+        }
+        DevInstance& di = (*out_inst)[i];
+        memset(&di, 0, sizeof(di));
+        store3x4(t.m, di.m);
+        store3x4(t.inv, di.inv);
+        di.root = mesh_root[gi.mesh];
+        di.material = static_cast<int32_t>(gi.material);
+        di.area_light = gi.area_light;
+        di.mesh = static_cast<int32_t>(gi.mesh);
+        di.shape = meshes[gi.mesh].shape;
+        di.radius = meshes[gi.mesh].radius;
+        di.is_mask = materials[gi.material].type == GBL_MAT_MASK ? 1u : 0u;
+        // Transform::onBBox: the 8 corners of the mesh bound
+        const float* lo = mesh_lo + 3 * gi.mesh;
+        const float* hi = mesh_hi + 3 * gi.mesh;
+        Prim& p = iprims[i];
+        for (int c = 0; c < 8; ++c) {
+            float corner[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+            float w[3];
+            point_by(t.m, corner, w);
+            p.box.grow(w);
+        }
+        for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+        p.id = i;
+    }
+    Aabb scene_bound;
+    for (const Prim& p : iprims) {
+        scene_bound.grow(p.box.lo);
+        scene_bound.grow(p.box.hi);
+    }
+    for (int k = 0; k < 3; ++k) {
+        sb_lo[k] = scene_bound.lo[k];
+        sb_hi[k] = scene_bound.hi[k];
+    }
+    *tlas_depth = 0;
+    *tlas_root = 0;
+    if (n > 0) {
+        Builder tb(iprims, 1, kTlasCap);
+        int root = tb.build(0, iprims.size(), 1);
+        Flat4 t4(tb, *out_nodes, tlas_base);
+        auto inst_ref = [&](uint32_t first, uint32_t) { return ~static_cast<int32_t>(iprims[first].id << 2); };
+        *tlas_root = t4.emit(root, 1, inst_ref);
+        *tlas_depth = t4.depth;
+    }
+    return GBL_OK;
+}
+
+namespace {
 int floor_i(float f) { return static_cast<int>(std::floor(f)); }
 
 }  // namespace
@@ -471,7 +539,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->uvs.assign(d->uvs, d->uvs + 2 * static_cast<size_t>(d->num_vertices));
 
     // ---- one BLAS per mesh
-    const int kBlasCap = 40, kTlasCap = 22;
+    const int kBlasCap = 40;
     std::vector<int32_t> mesh_root(d->num_meshes);
     std::vector<Aabb> mesh_bounds(d->num_meshes);
     out->tris.clear();
@@ -545,56 +613,25 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         }
 
     // ---- instances + TLAS
-    out->instances.resize(d->num_instances);
-    std::vector<Prim> iprims(d->num_instances);
-    for (uint32_t i = 0; i < d->num_instances; ++i) {
-        const gbl_instance& gi = d->instances[i];
-        Trs t = compose(gi.to_world.position, gi.to_world.orientation, gi.to_world.scale);
-        if (!t.invertible) {
-            *err = "instance " + std::to_string(i) + ": |det(toWorld)| < 1e-5, the reference cannot invert this transform "
-                   "(GoblinMatrix.cpp:451); use a uniform scale >= 0.0216";
-            return GBL_ERR_INVALID;
-        }
-        DevInstance& di = out->instances[i];
-        memset(&di, 0, sizeof(di));
-        store3x4(t.m, di.m);
-        store3x4(t.inv, di.inv);
-        di.root = mesh_root[gi.mesh];
-        di.material = static_cast<int32_t>(gi.material);
-        di.area_light = gi.area_light;
-        di.mesh = static_cast<int32_t>(gi.mesh);
-        di.shape = d->meshes[gi.mesh].shape;
-        di.radius = d->meshes[gi.mesh].radius;
-        di.is_mask = d->materials[gi.material].type == GBL_MAT_MASK ? 1u : 0u;
+    out->mesh_root = mesh_root;
+    out->tlas_base = static_cast<int32_t>(out->nodes.size());
+    out->tlas_capacity = std::max<uint32_t>(1u, d->num_instances);
+    std::vector<DevNode> tlas;
+    float sb_lo[3], sb_hi[3];
+    {
+        gbl_status ts = build_tlas(d->instances, d->num_instances, d->meshes, d->materials, out->mesh_lo.data(), out->mesh_hi.data(),
+                                   mesh_root.data(), out->tlas_base, &out->instances, &tlas, &out->tlas_root, &out->tlas_depth, sb_lo, sb_hi, err);
+        if (ts != GBL_OK) return ts;
+    }
+    for (const DevInstance& di : out->instances)
         if (di.is_mask) out->has_masks = out->extended = 1;
-        // Transform::onBBox: the 8 corners of the mesh bound
-        const Aabb& mb = mesh_bounds[gi.mesh];
-        Prim& p = iprims[i];
-        for (int c = 0; c < 8; ++c) {
-            float corner[3] = {(c & 1) ? mb.hi[0] : mb.lo[0], (c & 2) ? mb.hi[1] : mb.lo[1], (c & 4) ? mb.hi[2] : mb.lo[2]};
-            float w[3];
-            point_by(t.m, corner, w);
-            p.box.grow(w);
-        }
-        for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
-        p.id = i;
-    }
     Aabb scene_bound;   // BVH::getAABB of the scene BVH: the union of the instance boxes (GoblinBVH.cpp:46-50)
-    for (const Prim& p : iprims) {
-        scene_bound.grow(p.box.lo);
-        scene_bound.grow(p.box.hi);
-    }
-    out->tlas_depth = 0;
-    out->tlas_root = 0;
-    if (d->num_instances > 0) {
-        Builder tb(iprims, 1, kTlasCap);
-        int root = tb.build(0, iprims.size(), 1);
-        Flat4 t4(tb, out->nodes);
-        auto inst_ref = [&](uint32_t first, uint32_t) { return ~static_cast<int32_t>(iprims[first].id << 2); };
-        out->tlas_root = t4.emit(root, 1, inst_ref);
-        out->tlas_depth = t4.depth;
-    }
-    out->tlas_nodes = out->nodes.size() - out->blas_nodes;
+    scene_bound.grow(sb_lo);
+    scene_bound.grow(sb_hi);
+    out->nodes.insert(out->nodes.end(), tlas.begin(), tlas.end());
+    out->tlas_nodes = tlas.size();
+    // room for any TLAS over the same instances (gbl_update_instances rebuilds it in place)
+    out->nodes.resize(static_cast<size_t>(out->tlas_base) + out->tlas_capacity, DevNode());
     // every 4-wide level can leave up to 3 siblings on the stack; + exit marker + instance sentinel
     out->stack_entries = 3 * (out->tlas_depth + out->blas_max_depth) + 2;
 

@@ -25,6 +25,9 @@ struct PackedScene {
     uint64_t blas_nodes = 0, tlas_nodes = 0;
     int blas_max_depth = 0, tlas_depth = 0;
     std::vector<float> mesh_lo, mesh_hi;   // 3 per mesh: object bounds
+    std::vector<int32_t> mesh_root;        // per mesh: BLAS root reference
+    int32_t tlas_base = 0;                 // device index of TLAS node 0
+    uint32_t tlas_capacity = 0;            // nodes reserved at tlas_base (any TLAS over the instances fits)
     DevCamera camera;
     DevFilm film;
 };
@@ -34,3 +37,8 @@ struct PackedScene {
 // (at indices 0..), `tris` stays empty, mesh instances get root = 0 (patched after the device build) and
 // `mesh_lo/hi` carry the object bounds the Morton codes are scaled by.
 gbl_status pack_scene(const gbl_scene_desc* desc, PackedScene* out, std::string* err, bool device_blas = false);
+
+// The instance records and the TLAS over them (also used by gbl_update_instances to rebuild after transform edits).
+gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* meshes, const gbl_material* materials, const float* mesh_lo,
+                      const float* mesh_hi, const int32_t* mesh_root, int32_t tlas_base, std::vector<DevInstance>* out_inst,
+                      std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err);

@@ -70,4 +70,8 @@ def allreduce_film(accum):
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":   # name the device: RCCL otherwise guesses it from the rank
+            import torch
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -69,6 +69,18 @@ class HipPathTracer:
         self.info = info
         self.window = tuple(info.window)
 
+    def update_instances(self, first, transforms):
+        """Move instances first.. to new (position, orientation wxyz, scale) transforms and rebuild the TLAS in place."""
+        arr = (_abi.gbl_trs * len(transforms))()
+        for i, (pos, quat, scale) in enumerate(transforms):
+            arr[i].position[:] = pos
+            arr[i].orientation[:] = quat
+            arr[i].scale[:] = scale
+        st = self.lib.gbl_update_instances(self.handle, first, len(transforms), arr)
+        if st != _abi.GBL_OK:
+            raise _abi.GoblinError(st, self.lib.gbl_last_error(self.handle).decode())
+        self.lib.gbl_get_info(self.handle, C.byref(self.info))
+
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:

@@ -406,6 +406,12 @@ typedef struct gbl_info {
 } gbl_info;
 gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out);
 
+/* Instance edits: give instances [first, first + count) new transforms and rebuild the TLAS over all instances in
+ * place (BLASes untouched; the reference would rebuild its whole scene BVH, GoblinScene.cpp:11-27).  Synchronises
+ * the device.  Instances that carry an area light, and scenes with a directional light (whose power depends on
+ * the scene bound), are GBL_ERR_UNSUPPORTED: re-create the context for those. */
+gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world);
+
 void gbl_destroy(gbl_ctx* ctx);
 /* Message for the last failing call on ctx (or on creation when ctx == NULL). */
 const char* gbl_last_error(const gbl_ctx* ctx);

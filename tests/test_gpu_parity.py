@@ -13,6 +13,8 @@ Tolerances (floating point path):
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -243,6 +245,48 @@ def test_device_built_bvh_traces_the_same_radiance(torch, schedule, name, ov):
     assert flips <= LI_FLIP_TOL
     assert helpers.li_mismatch_fraction(li_dev, li_host) <= LI_FLIP_TOL
     assert helpers.rel_l2(li_dev[:, :3], li_host[:, :3]) <= 1e-4
+
+
+@pytest.mark.parametrize("bvh", ["host", "device"])
+def test_instance_edits_rebuild_the_tlas_in_place(torch, schedule, bvh):
+    """gbl_update_instances: moving instances and re-rendering equals creating a context for the edited scene."""
+    import json
+    from goblin_amd.renderer import HipPathTracer
+    ov = gs.config_overrides(resolution=(40, 40), spp=4, depth=5)
+    scene = gs.load_scene("grid", ov)
+    with open(gs.scene_path("grid")) as f:
+        doc = json.load(f)
+    gs._merge(doc, ov)
+    inst = [p for p in doc["primitives"] if p["type"] == "instance"]
+    # spread the first 6 instances out and spin them: the TLAS changes shape
+    moves = []
+    for k in range(6):
+        p = inst[k]
+        pos = [p["position"][0] * 1.3 + 0.1 * k, p["position"][1] + 0.15 * k, p["position"][2] * 0.8 - 0.05 * k]
+        quat = [0.9238795, 0.0, 0.3826834, 0.0]
+        scale = [s * (1.0 + 0.1 * k) for s in p.get("scale", [1, 1, 1])]
+        moves.append((pos, quat, scale))
+        p["position"], p["orientation"], p["scale"] = pos, quat, scale
+    edited_scene = gs.load_scene_text(json.dumps(doc), os.path.dirname(gs.scene_path("grid")))
+    seed = 77
+    r = _Scheduled(HipPathTracer(scene, 0, bvh=bvh), schedule)
+    before = r.render(seed=seed, want_li=True)["li"].cpu().numpy()
+    first = 0   # desc.instances follows the order of the "instance" entries (GoblinContextLoader.cpp:381-383)
+    r.update_instances(first, moves)
+    after = r.render(seed=seed, want_li=True)["li"].cpu().numpy()
+    fresh = _Scheduled(HipPathTracer(edited_scene, 0, bvh=bvh), schedule).render(seed=seed, want_li=True)["li"].cpu().numpy()
+    assert not np.allclose(before, after)
+    assert helpers.li_mismatch_fraction(after, fresh) <= LI_FLIP_TOL
+    assert helpers.rel_l2(after[:, :3], fresh[:, :3]) <= 1e-5
+    # emissive instances and out-of-range edits are refused
+    cornell = HipPathTracer(gs.load_scene("cornell", ov), 0)
+    light_inst = next(i for i in range(cornell.scene.desc.num_instances) if cornell.scene.desc.instances[i].area_light >= 0)
+    with pytest.raises(_abi.GoblinError) as e:
+        cornell.update_instances(light_inst, [moves[0]])
+    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+    with pytest.raises(_abi.GoblinError) as e:
+        cornell.update_instances(cornell.scene.desc.num_instances, [moves[0]])
+    assert e.value.status == _abi.GBL_ERR_INVALID
 
 
 def test_masks_run_on_the_megakernel_only(torch):
