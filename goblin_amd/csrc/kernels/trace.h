@@ -166,7 +166,9 @@ __device__ __forceinline__ float child_entry(uint32_t nx, uint32_t ny, uint32_t 
     } while (0)
 
 // Interior step: st.cur must be an interior node reference.
-template <bool STATS, class STK>
+// SORTED: visit the children front to back (closest-hit queries).  An any-hit query is done at the first accepted
+// triangle wherever it lies, so it skips the 5-comparator sorting network and takes the hit children in slot order.
+template <bool STATS, bool SORTED, class STK>
 __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt) {
     const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
     const uint4 w0 = np[0];   // o.x o.y o.z scale.x
@@ -191,20 +193,29 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
         cnt.nodes += 4;
         probe(cnt.int_lane, cnt.int_wave);
     }
-    // sort the four (entry, ref) pairs by entry distance (5 compare-exchanges)
-    GBL_CSWAP(t0, r0, t1, r1);
-    GBL_CSWAP(t2, r2, t3, r3);
-    GBL_CSWAP(t0, r0, t2, r2);
-    GBL_CSWAP(t1, r1, t3, r3);
-    GBL_CSWAP(t1, r1, t2, r2);
-    // nearest child next; push the others farthest first
     int sp = st.sp;
-    if (t3 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r3));
-    if (t2 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r2));
-    if (t1 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r1));
-    if (t0 < INFINITY) {
-        st.cur = r0;
+    if (SORTED) {
+        // sort the four (entry, ref) pairs by entry distance (5 compare-exchanges)
+        GBL_CSWAP(t0, r0, t1, r1);
+        GBL_CSWAP(t2, r2, t3, r3);
+        GBL_CSWAP(t0, r0, t2, r2);
+        GBL_CSWAP(t1, r1, t3, r3);
+        GBL_CSWAP(t1, r1, t2, r2);
+        // nearest child next; push the others farthest first (misses sort to the end: INFINITY)
+        if (t3 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r3));
+        if (t2 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r2));
+        if (t1 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r1));
+        if (t0 < INFINITY) {
+            st.cur = r0;
+        } else {
+            st.cur = static_cast<int>(stk.load(--sp));
+        }
     } else {
+        // any order: push every hit child, then pop one
+        if (t3 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r3));
+        if (t2 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r2));
+        if (t1 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r1));
+        if (t0 < INFINITY) stk.store(sp++, static_cast<uint32_t>(r0));
         st.cur = static_cast<int>(stk.load(--sp));
     }
     st.sp = sp;
@@ -344,7 +355,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
     // 76.3 ms per 68 M-path frame here, 82.4 ms vs 79.6 ms there).
     for (;;) {
         if (trav_at_interior(st)) {
-            trav_interior<STATS>(sc, st, stk, cnt);
+            trav_interior<STATS, !ANY>(sc, st, stk, cnt);
         } else if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded, filter)) {
             break;
         }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
             const bool at_oth = busy && !at_int;
             const unsigned long long mi = __ballot(at_int), mo = __ballot(at_oth);
             if (mo == 0ull || __popcll(mi) >= GBL_TRAV_TH) {
-                if (at_int) trav_interior<STATS>(sc, st, stk, cnt);
+                if (at_int) trav_interior<STATS, !ANY>(sc, st, stk, cnt);
             } else if (at_oth) {
                 bool occluded = false;
                 if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded)) {
