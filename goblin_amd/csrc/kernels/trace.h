@@ -195,7 +195,8 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
     }
     int sp = st.sp;
     if (SORTED) {
-        // sort the four (entry, ref) pairs by entry distance (5 compare-exchanges)
+        // sort the four (entry, ref) pairs by entry distance (5 compare-exchanges).  (Singling out only the nearest
+        // child and pushing the rest unsorted was measured: -1.7 % on config 2, +2.4 % on the instanced grid.)
         GBL_CSWAP(t0, r0, t1, r1);
         GBL_CSWAP(t2, r2, t3, r3);
         GBL_CSWAP(t0, r0, t2, r2);
