@@ -514,7 +514,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     }
     ctx->allocations.push_back(p);
     ctx->work_counter = static_cast<uint32_t*>(p);
-    if (hipMalloc(&p, 16 * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc(&p, 32 * sizeof(unsigned long long)) != hipSuccess) {
         ctx->error = "hipMalloc(stats) failed";
         return bail(GBL_ERR_OOM);
     }
@@ -716,7 +716,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(uint32_t), stream));
     const bool want_stats = p->collect_stats != 0;
-    if (want_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->stats, 0, 16 * sizeof(unsigned long long), stream));
+    if (want_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->stats, 0, 32 * sizeof(unsigned long long), stream));
     const int tp = GBL_TILE + 2 * sc.film.halo;
     size_t lds = sizeof(float) * (4 * tp * tp + 256) + 4 * sizeof(uint32_t) +
                  static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
@@ -815,11 +815,23 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         }
         stats->paths = shard_pixels * ra.spp;
         if (want_stats) {
-            unsigned long long h[16];
+            unsigned long long h[32];
             HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));
             if (getenv("GBL_PROBE"))
                 fprintf(stderr, "probe: interior lane-steps %llu wave-steps %llu (util %.3f) | leaf/other lane %llu wave %llu (util %.3f)\n", h[7], h[8],
                         h[8] ? h[7] / (64.0 * h[8]) : 0.0, h[9], h[10], h[10] ? h[9] / (64.0 * h[10]) : 0.0);
+            if (getenv("GBL_PROBE") && h[11] + h[12] + h[13] + h[14] + h[15] + h[16] + h[17]) {
+                const char* names[7] = {"<=3", "4-7", "8-15", "16-31", "32-63", "64-127", ">=128"};
+                unsigned long long rays = 0, steps = 0;
+                for (int i = 0; i < 7; ++i) {
+                    rays += h[11 + i];
+                    steps += h[18 + i];
+                }
+                fprintf(stderr, "probe: closest-hit rays by interior steps (share of rays / share of steps):");
+                for (int i = 0; i < 7; ++i)
+                    fprintf(stderr, " %s %.1f%%/%.1f%%", names[i], 100.0 * h[11 + i] / rays, 100.0 * h[18 + i] / std::max(1ull, steps));
+                fprintf(stderr, "\n");
+            }
             stats->paths = h[0];
             stats->extension_rays = h[1];
             stats->shadow_rays = h[2];

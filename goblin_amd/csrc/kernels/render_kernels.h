@@ -202,8 +202,12 @@ __device__ __forceinline__ int wave_fetch(bool want, uint32_t* next_path) {
 }
 
 __device__ __forceinline__ void accumulate_stats(const RenderArgs& ra, const LaneCounters& c, uint32_t paths) {
-    unsigned long long v[11] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims, c.int_lane, c.int_wave, c.oth_lane, c.oth_wave};
-    for (int i = 0; i < 11; ++i) {
+    unsigned long long v[25] = {paths, c.ext, c.shadow, c.nodes, c.tris, c.splats, c.dims, c.int_lane, c.int_wave, c.oth_lane, c.oth_wave};
+    for (int i = 0; i < 7; ++i) {
+        v[11 + i] = c.hist[i];
+        v[18 + i] = c.hist_steps[i];
+    }
+    for (int i = 0; i < 25; ++i) {
         unsigned long long x = v[i];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(ra.stats + i, x);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
     const LdsStack stk = {stack + threadIdx.x};
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
 
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
     const LdsStack stk = {stack + threadIdx.x};
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
 
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];

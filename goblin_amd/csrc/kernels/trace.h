@@ -41,6 +41,9 @@ struct LaneCounters {
     // SIMD-efficiency probes (instrumented builds only): per phase, lane-steps executed and
     // wave-steps issued; utilisation = lane / (64 * wave)
     uint32_t int_lane, int_wave, oth_lane, oth_wave;
+    // rays by interior steps: [0] <= 3, [1] 4-7, [2] 8-15, [3] 16-31, [4] 32-63, [5] 64-127, [6] >= 128;
+    // hist_steps[b] sums the steps of bin b (closest-hit rays of the megakernel's trace())
+    uint32_t hist[7], hist_steps[7];
 };
 
 // first active lane of the current exec mask adds one wave-step
@@ -354,12 +357,19 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
     // simply takes the step it needs; phasing by majority state (GBL_TRAV_TH) only pays in the
     // wavefront trace kernel, whose waves mix rays of many pixels and depths (measured: 64.6 ms vs
     // 76.3 ms per 68 M-path frame here, 82.4 ms vs 79.6 ms there).
+    uint32_t steps = 0;
     for (;;) {
         if (trav_at_interior(st)) {
             trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+            if (STATS) ++steps;
         } else if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded, filter)) {
             break;
         }
+    }
+    if (STATS && !ANY) {
+        int b = steps <= 3 ? 0 : min(6, 30 - __clz(static_cast<int>(steps)));
+        cnt.hist[b] += 1;
+        cnt.hist_steps[b] += steps;
     }
     if (ANY) return occluded;
     hit = st.hit;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra
     extern __shared__ __align__(16) unsigned char smem[];
     const SplitStack stk = {reinterpret_cast<uint32_t*>(smem) + threadIdx.x, wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x,
                             gridDim.x * GBL_BLOCK};
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     const int lane = threadIdx.x & 63;
     const uint32_t n_regions = wa.pool_size / 64u;
     const uint32_t n_waves = gridDim.x * (GBL_BLOCK / 64);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;   // grid covers the pool exactly
     const int lane = threadIdx.x & 63;
     const uint32_t wave_gid = slot >> 6;
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     uint32_t paths_done = 0;
     PathState ps;
     ps.bounce = WF_BOUNCE_EMPTY;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
     __syncthreads();
-    LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LaneCounters cnt = {};
     const uint32_t lt = blockIdx.x;
     const uint32_t tile_id = ra.shard_index + lt * ra.shard_count;
     const int tx = tile_id % ra.tiles_x, ty = tile_id / ra.tiles_x;
