@@ -289,6 +289,58 @@ def test_instance_edits_rebuild_the_tlas_in_place(torch, schedule, bvh):
     assert e.value.status == _abi.GBL_ERR_INVALID
 
 
+def test_full_size_properties_on_the_headline_config(torch):
+    """BASELINE configs[1] at full size (512x512 film, 256 spp, depth 8: 68 161 536 paths), checked through
+    size-independent properties: determinism of the per-sample radiance, agreement of the two schedules sample by
+    sample, the tile-shard split summing to the whole film, the film's weight channel being a pure function of the
+    sample positions (equal for both schedules and for a depth-1 render), and a pixel-block checksum of the radiance
+    against the CPU oracle rendering the same counter-based samples on a sub-window."""
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(512, 512), spp=256, depth=8))
+    assert scene.num_paths() == 68161536
+    r = HipPathTracer(scene, 0)
+    seed = 20261003
+    mk = r.render(seed=seed, want_li=True, schedule="megakernel", stats=True)
+    assert mk["stats"]["paths"] == 68161536
+    li_mk = mk["li"]
+    film_mk = mk["film"].numpy()
+    wf = r.render(seed=seed, want_li=True, schedule="wavefront")
+    li_wf = wf["li"]
+    assert torch.isfinite(li_mk).all()
+    # same arithmetic under both schedules: identical per-sample radiance
+    assert torch.equal(li_mk, li_wf)
+    del li_wf
+    # determinism
+    again = r.render(seed=seed, want_li=True, schedule="megakernel")["li"]
+    assert torch.equal(li_mk, again)
+    del again
+    # films: same up to float summation order
+    np.testing.assert_allclose(wf["film"].numpy(), film_mk, rtol=1e-4, atol=1e-5)
+    # shards sum to the whole
+    film = r.new_film()
+    for rank in range(4):
+        r.render(film=film, seed=seed, shard=(rank, 4), schedule="megakernel")
+    np.testing.assert_allclose(film.numpy(), film_mk, rtol=1e-4, atol=1e-5)
+    # the weight channel only depends on where the samples fall
+    s1 = _abi.gbl_render_setting.from_buffer_copy(scene.desc.setting)
+    s1.max_ray_depth = 1
+    w1 = r.render(setting=s1, seed=seed, schedule="megakernel")["film"].numpy()[..., 3]
+    np.testing.assert_allclose(w1, film_mk[..., 3], rtol=1e-5)
+    assert film_mk[..., 3].min() > 0.0
+    # a 24x16-pixel block of the frame against the oracle on the very same samples
+    x0, x1, y0, y1 = r.window
+    o = ob.Oracle(scene)
+    w = x1 - x0
+    spp = scene.spp()
+    for bx, by in ((x0 + 250, y0 + 300), (x0 + 236, y0 + 200), (x0 + 300, y0 + 120)):   # floor, bunny, background
+        sub = (bx, bx + 16, by, by + 12)
+        li_ref, _ = o.li_replay(o.native_samples(seed, window=sub), threads=8)
+        li_cpu = li_mk.view(y1 - y0, w, spp, 4)[by - y0:by - y0 + 12, bx - x0:bx - x0 + 16].reshape(-1, 4).cpu().numpy()
+        flips = helpers.li_mismatch_fraction(li_cpu, li_ref)
+        print("full-size block", (bx, by), "flips", flips, "means", li_cpu[:, :3].mean(), li_ref[:, :3].mean())
+        assert flips <= LI_FLIP_TOL
+
+
 def test_masks_run_on_the_megakernel_only(torch):
     scene = gs.load_scene("masked", gs.config_overrides(resolution=(16, 16), spp=1, depth=3))
     from goblin_amd.renderer import HipPathTracer
