@@ -43,6 +43,8 @@ struct gbl_ctx {
     // wavefront pool (allocated on first use)
     uint32_t wf_pool = 0;
     uint32_t* wf_spill = nullptr;   // wf_ensure_spill()
+    hipStream_t wf_aux = nullptr;   // shadow rays of iteration k trace here while the main stream traces extension rays k+1
+    hipEvent_t wf_ev_shade = nullptr, wf_ev_shadow = nullptr;
     int wf_spill_levels = 0;
     WfArgs wf;
     float4* wf_li = nullptr;
@@ -112,6 +114,9 @@ uint32_t host_mix(uint32_t a, uint32_t b) {   // same integer hash as kernels/sa
 
 
 // ---------------------------------------------------------------------------
+#ifndef GBL_WF_SHADOW_WGS
+#define GBL_WF_SHADOW_WGS 1   // workgroups per CU of the concurrent shadow-ray trace launch
+#endif
 // Wavefront schedule: host side of kernels/wavefront.h
 // ---------------------------------------------------------------------------
 template <class T>
@@ -242,9 +247,26 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_shd, reinterpret_cast<const void*>(k_shd), GBL_BLOCK, lds_stack) != hipSuccess || occ_shd < 1) occ_shd = 1;
     occ_ext = std::min(occ_ext, 8);   // stack_spill is sized for 8 workgroups per CU
     occ_shd = std::min(occ_shd, 8);
+    // The shadow rays of iteration k and the extension rays of iteration k+1 are both known once wf_shade(k) has run
+    // and do not depend on each other, so they trace CONCURRENTLY: the shadow launch goes to a second stream with
+    // GBL_WF_SHADOW_WGS workgroups per CU, the extension launch keeps the rest of the occupancy (both grids are
+    // persistent, so together they must not exceed what is resident).  One launch tail per iteration instead of two.
+    const bool overlap = occ_ext > GBL_WF_SHADOW_WGS && !getenv("GBL_WF_NO_OVERLAP");
+    if (overlap) {
+        occ_ext -= GBL_WF_SHADOW_WGS;
+        occ_shd = GBL_WF_SHADOW_WGS;
+        if (!ctx->wf_aux) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->wf_aux, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev_shade, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev_shadow, hipEventDisableTiming));
+        }
+    }
     const uint64_t max_wgs = (pool / 64 + 3) / 4;
     unsigned ext_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_ext, max_wgs)));
     unsigned shd_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_shd, max_wgs)));
+    // the two trace launches may run at the same time: disjoint columns of the stack backing
+    uint32_t* const spill_ext = ctx->wf_spill;
+    uint32_t* const spill_shd = ctx->wf_spill + static_cast<size_t>(ctx->wf_spill_levels) * ext_wgs * GBL_BLOCK;
     dim3 block(GBL_BLOCK), grid_ext(ext_wgs), grid_shd(shd_wgs), grid_shade(pool / GBL_BLOCK);
     auto k_shade = replay ? (want_stats ? wf_shade<true, true, true> : (ext ? wf_shade<true, false, true> : wf_shade<true, false, false>))
                           : (want_stats ? wf_shade<false, true, true> : (ext ? wf_shade<false, false, true> : wf_shade<false, false, false>));
@@ -265,15 +287,26 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
         wa.init = 0;
         // slot s traces ceil((total - s) / pool) paths, each at least one iteration
         uint64_t iter = 0, min_iters = total / pool;
-        bool done = false;
+        bool done = false, shadow_pending = false;
         while (!done) {
             HIP_TRY(ctx, hipMemsetAsync(wa.live_flags, 0, 8 * sizeof(uint32_t), stream));
             int batch = iter + 4 <= min_iters ? static_cast<int>(std::min<uint64_t>(min_iters - iter, 64)) : 4;
             for (int b = 0; b < batch; ++b) {
                 wa.flag_index = b & 7;
+                wa.stack_spill = spill_ext;
                 hipLaunchKernelGGL(k_ext, grid_ext, block, lds_stack, stream, sc, ra, wa);
+                if (overlap && shadow_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev_shadow, 0));   // wf_shade reads s_ld, rewrites the shadow queue
                 hipLaunchKernelGGL(k_shade, grid_shade, block, 0, stream, sc, ra, wa);
-                hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, stream, sc, ra, wa);
+                wa.stack_spill = spill_shd;
+                if (overlap) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->wf_ev_shade, stream));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->wf_aux, ctx->wf_ev_shade, 0));
+                    hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, ctx->wf_aux, sc, ra, wa);
+                    HIP_TRY(ctx, hipEventRecord(ctx->wf_ev_shadow, ctx->wf_aux));
+                    shadow_pending = true;
+                } else {
+                    hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, stream, sc, ra, wa);
+                }
                 ++iter;
             }
             if (iter >= min_iters) {
@@ -286,6 +319,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
                 return GBL_ERR_DEVICE;
             }
         }
+        if (overlap && shadow_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev_shadow, 0));   // rejoin before the pool is reused
         hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), block, lds_tile, stream, sc, ra, wa);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -607,6 +641,9 @@ void gbl_destroy(gbl_ctx* ctx) {
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
     if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
+    if (ctx->wf_ev_shade) (void)hipEventDestroy(ctx->wf_ev_shade);
+    if (ctx->wf_ev_shadow) (void)hipEventDestroy(ctx->wf_ev_shadow);
+    if (ctx->wf_aux) (void)hipStreamDestroy(ctx->wf_aux);
     if (ctx->wf_host_flags) (void)hipHostFree(ctx->wf_host_flags);
     for (int i = 0; i < gbl_ctx::kTimingRing; ++i)
         for (int k = 0; k < 3; ++k)
