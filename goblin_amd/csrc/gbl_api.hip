@@ -114,6 +114,9 @@ uint32_t host_mix(uint32_t a, uint32_t b) {   // same integer hash as kernels/sa
 
 
 // ---------------------------------------------------------------------------
+#ifndef GBL_WF_POOL_LOG2
+#define GBL_WF_POOL_LOG2 23   // 8 Mi path slots in flight (1.9 GB of path state): 2^21 -> 2^23 is -9 % on config 3, -10 % on config 4
+#endif
 #ifndef GBL_WF_SHADOW_WGS
 #define GBL_WF_SHADOW_WGS 1   // workgroups per CU of the concurrent shadow-ray trace launch
 #endif
@@ -134,7 +137,9 @@ gbl_status wf_alloc(gbl_ctx* ctx, T** out, size_t count) {
 
 gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     if (ctx->wf_pool) return GBL_OK;
-    const uint32_t pool = 1u << 21;   // 2 Mi path slots (~190 B each)
+    uint32_t pool_log2 = GBL_WF_POOL_LOG2;
+    if (const char* e = getenv("GBL_WF_POOL_LOG2")) pool_log2 = static_cast<uint32_t>(std::min(26, std::max(16, atoi(e))));
+    const uint32_t pool = 1u << pool_log2;   // path slots (~230 B each)
     WfArgs& w = ctx->wf;
     memset(&w, 0, sizeof(w));
     gbl_status st;
