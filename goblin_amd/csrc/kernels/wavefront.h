@@ -99,7 +99,9 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 // ---------------------------------------------------------------------------
 // wf_trace: persistent traversal with in-wave dynamic fetch.
 // ---------------------------------------------------------------------------
+#ifndef WF_REFILL
 #define WF_REFILL 16   // refill as soon as this many lanes of the wave are idle
+#endif
 
 template <bool ANY, bool STATS, bool EXT>
 __global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
