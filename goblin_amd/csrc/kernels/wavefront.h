@@ -103,8 +103,11 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 #define WF_REFILL 16   // refill as soon as this many lanes of the wave are idle
 #endif
 
+#ifndef GBL_WF_TRACE_WAVES
+#define GBL_WF_TRACE_WAVES 5   // 96 VGPRs (4 spilled): 5 waves per SIMD measured 3-5 % faster than 4; 6 spills too much
+#endif
 template <bool ANY, bool STATS, bool EXT>
-__global__ __launch_bounds__(GBL_BLOCK) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
+__global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     const SplitStack stk = {reinterpret_cast<uint32_t*>(smem) + threadIdx.x, wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x,
                             gridDim.x * GBL_BLOCK};
