@@ -30,6 +30,26 @@
 #define WF_BOUNCE_EMPTY (-2)   // slot needs a new path
 #define WF_BOUNCE_DEAD (-3)    // slot has traced all its paths of this pass
 
+// Path state streams through the pool once per iteration: non-temporal accesses keep it from evicting the BVH nodes
+// and triangles the trace kernels re-read from L2 (measured -3.5 % on config 2's size, neutral on the others).
+typedef float wf_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wf_ld_nt(const float4* p) {
+#ifndef GBL_WF_NO_NT
+    wf_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wf_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void wf_st_nt(float4* p, float4 v) {
+#ifndef GBL_WF_NO_NT
+    wf_f4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<wf_f4*>(p));
+#else
+    *p = v;
+#endif
+}
+
 struct WfArgs {
     // pool (one entry per slot)
     float4* ray_o;      // o.xyz, mint
@@ -154,16 +174,16 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevSce
                 float4 a, b;
                 float maxt;
                 if (ANY) {
-                    a = wa.sh_o[my_entry];
-                    b = wa.sh_d[my_entry];
-                    float4 c = wa.sh_c[my_entry];
+                    a = wf_ld_nt(&wa.sh_o[my_entry]);
+                    b = wf_ld_nt(&wa.sh_d[my_entry]);
+                    float4 c = wf_ld_nt(&wa.sh_c[my_entry]);
                     contrib = f3(c.x, c.y, c.z);
                     slot = __float_as_uint(c.w);
                     maxt = b.w;
                 } else {
                     slot = wa.ext_q[my_entry];
-                    a = wa.ray_o[slot];
-                    b = wa.ray_d[slot];
+                    a = wf_ld_nt(&wa.ray_o[slot]);
+                    b = wf_ld_nt(&wa.ray_d[slot]);
                     maxt = INFINITY;
                 }
                 trav_begin(sc, st, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), a.w, maxt, stk);
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevSce
                             wa.s_ld[slot] = ld;
                         }
                     } else {
-                        wa.hit[slot] = make_float4(st.hit.t, st.hit.b1, st.hit.b2, __uint_as_float(st.hit.tri));
+                        wf_st_nt(&wa.hit[slot], make_float4(st.hit.t, st.hit.b1, st.hit.b2, __uint_as_float(st.hit.tri)));
                         wa.hit_inst[slot] = st.hit.inst;
                     }
                     busy = false;
@@ -239,9 +259,9 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     Frag fr;
     TexFrag tf;
     if (alive) {
-        float4 o = wa.ray_o[slot], d = wa.ray_d[slot];
-        float4 h = wa.hit[slot];
-        float4 a = wa.s_thr[slot], b = wa.s_li[slot], c = wa.s_ld[slot], e = wa.s_f[slot];
+        float4 o = wf_ld_nt(&wa.ray_o[slot]), d = wf_ld_nt(&wa.ray_d[slot]);
+        float4 h = wf_ld_nt(&wa.hit[slot]);
+        float4 a = wf_ld_nt(&wa.s_thr[slot]), b = wf_ld_nt(&wa.s_li[slot]), c = wf_ld_nt(&wa.s_ld[slot]), e = wf_ld_nt(&wa.s_f[slot]);
         ps.o = f3(o.x, o.y, o.z); ps.mint = o.w;
         ps.d = f3(d.x, d.y, d.z);
         ps.throughput = f3(a.x, a.y, a.z); ps.cosw = a.w;
@@ -483,14 +503,14 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     const bool keep = (alive && !finished) || started;
     if (keep) {
         if (has_ray) {
-            wa.ray_o[slot] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.mint);
-            wa.ray_d[slot] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f);
+            wf_st_nt(&wa.ray_o[slot], make_float4(ps.o.x, ps.o.y, ps.o.z, ps.mint));
+            wf_st_nt(&wa.ray_d[slot], make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f));
         }
         if (zombie) wa.hit_inst[slot] = -1;
-        wa.s_thr[slot] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.cosw);
-        wa.s_li[slot] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, ps.fw);
-        wa.s_ld[slot] = make_float4(ps.Ld.x, ps.Ld.y, ps.Ld.z, ps.bsdf_pdf);
-        wa.s_f[slot] = make_float4(ps.f.x, ps.f.y, ps.f.z, ps.pick_pdf);
+        wf_st_nt(&wa.s_thr[slot], make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.cosw));
+        wf_st_nt(&wa.s_li[slot], make_float4(ps.Li.x, ps.Li.y, ps.Li.z, ps.fw));
+        wf_st_nt(&wa.s_ld[slot], make_float4(ps.Ld.x, ps.Ld.y, ps.Ld.z, ps.bsdf_pdf));
+        wf_st_nt(&wa.s_f[slot], make_float4(ps.f.x, ps.f.y, ps.f.z, ps.pick_pdf));
         wa.s_pixel[slot] = pixel_key;
     }
     if (keep || dead || want_new || wa.init)
