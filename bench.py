@@ -199,11 +199,13 @@ def main():
         alg_bytes = algorithmic_bytes(counted)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         req_bytes = requested_bytes(counted)
-        traffic = None
+        traffic, pmc = None, {}
         tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath) and args.spp == 256 and args.resolution == [512, 512] and args.depth == 8 and world == 1:
+        if os.path.exists(tpath) and args.spp == 256 and args.resolution == [512, 512] and args.depth == 8 and world == 1 \
+                and resolved == "megakernel":
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                pmc = json.load(f)
+            traffic = pmc.get("hbm_bytes_per_launch")
         rays = counted["extension_rays"] + counted["shadow_rays"]
         value = job_paths * args.steps / elapsed * 1e-6
         line = {
@@ -250,6 +252,9 @@ def main():
                         "quantised node layout really loads (16 B per box); traffic = HBM bytes from rocprofv3 PMC "
                         "(profiles/), the scene is cache resident",
                 "counters": {k: int(v) for k, v in counted.items() if k != "kernel_ms"},
+                # from the committed rocprofv3 PMC passes of this command (profiles/): what really bounds the kernel
+                "valu_busy_frac": pmc.get("valu_busy_frac"),
+                "l2_hit_rate": pmc.get("l2_hit_rate"),
             },
         }
         if world == 1 and not args.no_cpu:
