@@ -35,3 +35,90 @@ def li_mismatch_fraction(a, b, rtol=1e-3, atol=1e-5):
     b = np.asarray(b, np.float64)[:, :3]
     bad = np.any(np.abs(a - b) > atol + rtol * np.abs(b), axis=1)
     return float(bad.mean())
+
+
+# ---------------------------------------------------------------------------
+# Random scenes over the supported feature set (tests/test_gpu_fuzz.py, tests/test_oracle_fuzz.py)
+# ---------------------------------------------------------------------------
+def quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return [float(x) for x in q]
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    U = lambda a, b: float(rng.uniform(a, b))
+    tex = [
+        {"format": "color", "name": "c0", "type": "constant", "color": [U(.1, .9), U(.1, .9), U(.1, .9)]},
+        {"format": "color", "name": "c1", "type": "constant", "color": [U(.1, .9), U(.1, .9), U(.1, .9)]},
+        {"format": "color", "name": "c2", "type": "constant", "color": [U(.5, 1), U(.5, 1), U(.5, 1)]},
+        {"format": "float", "name": "f0", "type": "constant", "float": U(2, 60)},
+        {"format": "float", "name": "f1", "type": "constant", "float": U(.2, .9)},
+        {"format": "float", "name": "one", "type": "constant", "float": 1.0},
+        {"format": "float", "name": "zero", "type": "constant", "float": 0.0},
+        {"format": "color", "name": "chk", "type": "checkerboard", "texture1": "c0", "texture2": "c1",
+         "scale": [U(2, 9), U(2, 9)], "filter": bool(rng.integers(2))},
+        {"format": "color", "name": "sph", "type": "checkerboard", "texture1": "c1", "texture2": "c2", "mapping": "spherical",
+         "position": [U(-1, 1), U(0, 1), U(-1, 1)], "orientation": quat(rng), "scale": [U(.1, .4)] * 3, "filter": bool(rng.integers(2))},
+        {"format": "color", "name": "dim", "type": "scale", "texture": "chk", "scale": "f1"},
+        {"format": "float", "name": "cut", "type": "checkerboard", "texture1": "one", "texture2": "zero", "scale": [U(2, 6), U(2, 6)]},
+    ]
+    kd = lambda: str(rng.choice(["c0", "c1", "chk", "sph", "dim"]))
+    mats = [
+        {"name": "floor", "type": "lambert", "Kd": kd()},
+        {"name": "m0", "type": "lambert", "Kd": kd()},
+        {"name": "m1", "type": "blinn", "Kg": kd(), "exponent": "f0", "index": U(1.2, 2.0)},
+        {"name": "m2", "type": "transparent", "Kr": "c2", "Kt": str(rng.choice(["c2", "chk"])), "index": U(1.2, 1.8)},
+        {"name": "m3", "type": "mirror", "Kr": "c2"},
+    ]
+    use_mask = bool(rng.integers(2))
+    if use_mask:
+        mats.append({"name": "m4", "type": "mask", "material": str(rng.choice(["m0", "m1", "m2", "m3"])),
+                     "alpha": str(rng.choice(["f1", "cut"])), "transparent_color": "c2"})
+    geoms = [
+        {"name": "quad", "type": "mesh", "file": "models/plane.obj"},
+        {"name": "cube", "type": "mesh", "file": "models/cube.obj"},
+        {"name": "bunny", "type": "mesh", "file": "models/bunny_vn.obj"},
+        {"name": "ball", "type": "sphere", "radius": U(.3, 1.0)},
+        {"name": "plate", "type": "disk", "radius": U(.4, 1.0)},
+    ]
+    prims = [{"type": "model", "name": "mfloor", "geometry": "quad", "material": "floor"},
+             {"type": "instance", "name": "floor", "model": "mfloor", "position": [0, 0, 0], "orientation": [1, 0, 0, 0], "scale": [4, 4, 4]}]
+    names = [m["name"] for m in mats if m["name"] != "floor"]
+    for i in range(int(rng.integers(3, 7))):
+        g = str(rng.choice(["cube", "bunny", "ball", "plate"]))
+        prims.append({"type": "model", "name": "mod%d" % i, "geometry": g, "material": str(rng.choice(names))})
+        sc = U(.25, .6) * (6.0 if g == "bunny" else 1.0)
+        scale = [sc * U(.7, 1.3), sc * U(.7, 1.3), sc * U(.7, 1.3)] if rng.integers(2) else [sc] * 3
+        prims.append({"type": "instance", "name": "inst%d" % i, "model": "mod%d" % i,
+                      "position": [U(-1.3, 1.3), U(.3, 1.2) - (0.9 if g == "bunny" else 0.0), U(-1.0, 1.4)], "orientation": quat(rng), "scale": scale})
+    lights = []
+    for i in range(int(rng.integers(1, 4))):
+        t = str(rng.choice(["point", "spot", "area", "directional"]))
+        if t == "point":
+            lights.append({"name": "l%d" % i, "type": "point", "intensity": [U(3, 9)] * 3, "position": [U(-2, 2), U(1.5, 3), U(-2, 1)]})
+        elif t == "spot":
+            lights.append({"name": "l%d" % i, "type": "spot", "intensity": [U(8, 20)] * 3, "position": [U(-2, 2), U(2, 3), U(-2, 1)],
+                           "target": [U(-.5, .5), 0.2, U(-.5, .5)], "theta_max": U(25, 50), "falloff_start": U(5, 20)})
+        elif t == "directional":
+            d = np.array([U(-.5, .5), -1.0, U(-.5, .5)])
+            d /= np.linalg.norm(d)
+            lights.append({"name": "l%d" % i, "type": "directional", "radiance": [U(.3, 1)] * 3, "direction": [float(x) for x in d]})
+        else:
+            s = U(.15, .5)
+            lights.append({"name": "l%d" % i, "type": "area", "geometry": str(rng.choice(["quad", "ball", "plate"])),
+                           "radiance": [U(5, 20), U(5, 20), U(5, 20)], "position": [U(-1.5, 1.5), U(2.0, 3.0), U(-1, 1)],
+                           "orientation": [0, 1, 0, 0] if rng.integers(2) else [0.70710678, 0.70710678, 0, 0], "scale": [s, s, s]})
+    cam = {"position": [U(-.5, .5), U(1.0, 1.6), U(-4.6, -3.8)], "orientation": [0.9961947, 0.0871557, 0, 0], "fov": U(35, 55),
+           "film": {"resolution": [40, 32]}, "filter": {"type": str(rng.choice(["gaussian", "box", "triangle", "mitchell"])), "width": [U(.6, 2.0)] * 2}}
+    c = int(rng.integers(3))
+    if c == 1:
+        cam.update({"type": "orthographic", "film_width": U(4, 7)})
+    elif c == 2:
+        cam.update({"lens_radius": U(.03, .15), "focal_distance": U(3.5, 5)})
+    doc = {"render_setting": {"render_method": "path_tracing", "sample_per_pixel": 4, "max_ray_depth": int(rng.integers(3, 9))},
+           "camera": cam, "geometries": geoms, "textures": tex, "materials": mats, "primitives": prims, "lights": lights}
+    return doc, use_mask
+
+

@@ -1,0 +1,46 @@
+"""Randomised scenes: the device against the oracle, sample by sample (counter-based sampler on both sides).
+
+Every seed draws a scene from the supported feature set -- meshes, spheres and disks under random (also non-uniform)
+transforms, the five material types incl. masks, procedural textures, point / spot / directional / area lights over
+meshes, spheres and disks, the three cameras -- and renders a small frame through the C ABI.  The oracle is bit-exact
+with the reference on the fixtures, so disagreement here is a device bug on a path the fixtures do not reach."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle_binding as ob
+from goblin_amd import _abi
+from goblin_amd import scene as gs
+
+pytestmark = pytest.mark.gpu
+SCENE_DIR = os.path.dirname(gs.scene_path("bunny"))
+
+
+from helpers import random_scene  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_scene_matches_oracle(seed):
+    import torch
+    assert torch.cuda.is_available()
+    from goblin_amd.renderer import HipPathTracer
+    doc, use_mask = random_scene(1000 + seed)
+    scene = gs.load_scene_text(json.dumps(doc), SCENE_DIR)
+    o = ob.Oracle(scene)
+    rseed = 4242 + seed
+    samples = o.native_samples(rseed)
+    li_ref, _ = o.li_replay(samples, threads=4)
+    assert np.isfinite(li_ref).all()
+    masks_in_use = any(scene.desc.materials[scene.desc.instances[i].material].type == _abi.GBL_MAT_MASK for i in range(scene.desc.num_instances))
+    for bvh in ("host", "device"):
+        r = HipPathTracer(scene, 0, bvh=bvh)
+        for schedule in (["megakernel"] if masks_in_use else ["megakernel", "wavefront"]):
+            li = r.render(seed=rseed, want_li=True, schedule=schedule)["li"].cpu().numpy()
+            assert np.isfinite(li).all(), (seed, bvh, schedule)
+            flips = helpers.li_mismatch_fraction(li, li_ref)
+            rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
+            print("seed", seed, bvh, schedule, "flips %.5f relL2 %.2e" % (flips, rel), "mask" if masks_in_use else "")
+            assert flips <= 3e-3 and rel <= 2e-2, (seed, bvh, schedule, flips, rel)
