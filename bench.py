@@ -146,11 +146,13 @@ def main():
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback on the product path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device_index = local_rank % max(1, ndev)   # one GPU per rank on a full node; ranks share GPUs only in the gloo rehearsal
+    torch.cuda.set_device(device_index)
 
     overrides = gs.config_overrides(resolution=tuple(args.resolution), spp=args.spp, depth=args.depth)
     scene = gs.load_scene("bunny", overrides)
-    tracer = HipPathTracer(scene, local_rank)
+    tracer = HipPathTracer(scene, device_index)
     film = tracer.new_film()
     base_seed = 20261003
     part = gd.shard_for(rank, world, "samples" if args.scaling == "weak" else "tiles", base_seed)
@@ -182,8 +184,9 @@ def main():
     gd.barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=tracer.device)
-    paths = torch.tensor([float(my_paths)], dtype=torch.float64, device=tracer.device)
+    red_dev = tracer.device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    paths = torch.tensor([float(my_paths)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(paths, op=dist.ReduceOp.SUM)

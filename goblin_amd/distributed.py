@@ -27,9 +27,10 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GBL_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (RCCL refuses that)
+            backend = os.environ.get("GBL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -63,7 +64,12 @@ def allreduce_film(accum):
     rank's device (RCCL) or on the CPU (gloo)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and accum.is_cuda:   # rehearsal mode: stage through the host
+            host = accum.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
+        else:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
     return accum
 
 
