@@ -95,6 +95,23 @@ gbl_status upload(gbl_ctx* ctx, const std::vector<T>& v, const T** out) {
     return GBL_OK;
 }
 
+// hipMalloc `capacity` elements and copy the first `count` from the host
+template <class T>
+gbl_status upload_raw(gbl_ctx* ctx, const T* src, size_t count, size_t capacity, const T** out) {
+    size_t bytes = std::max<size_t>(1, capacity) * sizeof(T);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        ctx->error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? GBL_ERR_OOM : GBL_ERR_DEVICE;
+    }
+    ctx->allocations.push_back(p);
+    ctx->info.scene_bytes += bytes;
+    if (count) HIP_TRY(ctx, hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return GBL_OK;
+}
+
 int round_to_square(int n, int* root) {
     int s = static_cast<int>(std::ceil(std::sqrt(static_cast<float>(n))));
     *root = s;
@@ -489,17 +506,14 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
                 node_cap += desc->meshes[m].tri_count;
                 tri_cap += desc->meshes[m].tri_count;
             }
-        std::vector<DevNode> nodes_h(node_cap);
-        std::copy(packed.nodes.begin(), packed.nodes.end(), nodes_h.begin());
-        std::vector<DevTri> tris_h(tri_cap);
-        if ((st = upload(ctx, nodes_h, &sc.nodes)) != GBL_OK) return bail(st);
-        if ((st = upload(ctx, tris_h, &sc.tris)) != GBL_OK) return bail(st);
-        std::vector<float> pos_h(desc->positions, desc->positions + 3 * static_cast<size_t>(desc->num_vertices));
-        std::vector<uint32_t> idx_h(desc->indices, desc->indices + 3 * static_cast<size_t>(desc->num_triangles));
+        // device buffers are allocated at their final size; only the TLAS nodes and the raw geometry cross PCIe
+        if ((st = upload_raw(ctx, packed.nodes.data(), packed.nodes.size(), node_cap, &sc.nodes)) != GBL_OK) return bail(st);
+        if ((st = upload_raw(ctx, static_cast<const DevTri*>(nullptr), 0, tri_cap, &sc.tris)) != GBL_OK) return bail(st);
         const float* d_pos = nullptr;
         const uint32_t* d_idx = nullptr;
-        if ((st = upload(ctx, pos_h, &d_pos)) != GBL_OK) return bail(st);
-        if ((st = upload(ctx, idx_h, &d_idx)) != GBL_OK) return bail(st);
+        const size_t n_pos = 3 * static_cast<size_t>(desc->num_vertices), n_idx = 3 * static_cast<size_t>(desc->num_triangles);
+        if ((st = upload_raw(ctx, desc->positions, n_pos, n_pos, &d_pos)) != GBL_OK) return bail(st);
+        if ((st = upload_raw(ctx, desc->indices, n_idx, n_idx, &d_idx)) != GBL_OK) return bail(st);
         std::vector<int32_t> mesh_root(desc->num_meshes, 0);
         int32_t node_base = static_cast<int32_t>(packed.nodes.size());
         uint32_t tri_base = 0;
