@@ -52,7 +52,7 @@ def build_hip(force=False, extra_flags=()):
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libgoblin_hip.so")
     if force or _stale(out, HIP_DEPS):
-        _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-o", out] + HIP_SOURCES + ["-ldl"])
+        _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-o", out] + HIP_SOURCES + ["-ldl", "-lpthread"])
     return out
 
 

@@ -13,8 +13,10 @@
 #include "scene_prep.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -188,7 +190,53 @@ struct Builder {
     std::vector<Prim>& prims;
     std::vector<TmpNode> nodes;
     int max_leaf, depth_cap, height = 0;
+    // parallel build: subranges of at most `defer_below` primitives are not descended into but recorded as tasks
+    struct Task {
+        int node;
+        size_t start, end;
+        int depth;
+    };
+    size_t defer_below = 0;
+    std::vector<Task> tasks;
     Builder(std::vector<Prim>& p, int leaf, int cap) : prims(p), max_leaf(leaf), depth_cap(cap) {}
+
+    // Same tree as build(0, n, 1), built on several host threads: the top of the tree sequentially, every subtree of
+    // <= n/64 primitives as an independent task (the tasks own disjoint ranges of `prims`), merged in task order --
+    // so the result does not depend on the number of threads.
+    int build_parallel(size_t n) {
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (n < 65536 || hw < 2) return build(0, n, 1);
+        defer_below = std::max<size_t>(4096, n / 64);
+        int root = build(0, n, 1);
+        defer_below = 0;
+        std::vector<Builder> subs;
+        subs.reserve(tasks.size());
+        for (size_t i = 0; i < tasks.size(); ++i) subs.emplace_back(prims, max_leaf, depth_cap);
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < tasks.size(); i = next.fetch_add(1)) subs[i].build(tasks[i].start, tasks[i].end, tasks[i].depth);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < std::min<size_t>(hw, tasks.size()); ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+        for (size_t i = 0; i < tasks.size(); ++i) {
+            const std::vector<TmpNode>& sn = subs[i].nodes;   // sn[0] is the subtree's root
+            const int offset = static_cast<int>(nodes.size()) - 1;
+            auto remap = [&](TmpNode nd) {
+                if (nd.count == 0) {
+                    nd.left += offset;
+                    nd.right += offset;
+                }
+                return nd;
+            };
+            nodes[tasks[i].node] = remap(sn[0]);
+            for (size_t k = 1; k < sn.size(); ++k) nodes.push_back(remap(sn[k]));
+            height = std::max(height, subs[i].height);
+        }
+        tasks.clear();
+        return root;
+    }
 
     int build(size_t start, size_t end, int depth) {
         int me = static_cast<int>(nodes.size());
@@ -201,6 +249,10 @@ struct Builder {
         nodes[me].box = box;
         height = std::max(height, depth);
         size_t n = end - start;
+        if (defer_below && depth > 1 && n <= defer_below && n > static_cast<size_t>(max_leaf)) {
+            tasks.push_back(Task{me, start, end, depth});
+            return me;
+        }
         int room = depth_cap - depth;   // levels available below this node
         // binned SAH over the centroid bounds, all three axes
         const int B = 16;
@@ -580,7 +632,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             s.flags = (gm.has_normal ? 1u : 0u) | (gm.has_uv ? 2u : 0u);
         }
         Builder b(prims, GBL_MAX_LEAF_TRIS, kBlasCap);
-        int root = b.build(0, prims.size(), 1);
+        int root = b.build_parallel(prims.size());
         Flat4 f4(b, out->nodes);
         uint32_t tri_base = static_cast<uint32_t>(out->tris.size());
         for (const Prim& p : prims) {
