@@ -167,6 +167,9 @@ gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     WF_A(sh_o, pool); WF_A(sh_d, pool); WF_A(sh_c, pool); WF_A(sh_count, pool / 64);
     WF_A(live_flags, 8);
     WF_A(wave_next, pool / 64);
+    if (ctx->scene.has_masks) {   // see WfArgs
+        WF_A(hit2, pool); WF_A(hit2_inst, pool); WF_A(mis_tr, pool); WF_A(sh_f, pool); WF_A(sh_L, pool);
+    }
 #undef WF_A
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_flags), 8 * sizeof(uint32_t)) != hipSuccess) {
         ctx->error = "hipHostMalloc(wavefront flags) failed";
@@ -260,8 +263,11 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     // EXT kernels carry the analytic shapes / directional light / non-pinhole cameras; plain scenes run the lean
     // build.  Instrumented launches always use the EXT build (same work, same counters).
     const bool ext = sc.extended != 0;
-    auto k_ext = want_stats ? wf_trace<false, true, true> : (ext ? wf_trace<false, false, true> : wf_trace<false, false, false>);
-    auto k_shd = want_stats ? wf_trace<true, true, true> : (ext ? wf_trace<true, false, true> : wf_trace<true, false, false>);
+    const bool masks = sc.has_masks != 0;
+    auto k_ext = masks ? (want_stats ? wf_trace<false, true, true, true> : wf_trace<false, false, true, true>)
+                       : (want_stats ? wf_trace<false, true, true> : (ext ? wf_trace<false, false, true> : wf_trace<false, false, false>));
+    auto k_shd = masks ? (want_stats ? wf_trace<true, true, true, true> : wf_trace<true, false, true, true>)
+                       : (want_stats ? wf_trace<true, true, true> : (ext ? wf_trace<true, false, true> : wf_trace<true, false, false>));
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
     // workgroup that has to wait for a free CU would serialise its share), never more waves than regions
     int occ_ext = 0, occ_shd = 0;
@@ -784,14 +790,15 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while a path is cheap
     // (short paths through a small scene: configs 1, 2), the wavefront formulation once traversal dominates and its
     // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 4.2 s against 6.4 s) or many
-    // instanced triangles (config 4, 15 bunnies: 387 ms against 440 ms).  AO, the Russian-roulette extension and
-    // mask scenes always run the megakernel.
-    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette && !sc.has_masks;
+    // instanced triangles (config 4, 15 bunnies: 317 ms against 438 ms).  AO and the Russian-roulette extension always
+    // run the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
+    // filtered MIS query and the attenuation walks inline in the trace kernel: 48.6 ms against 16.1 ms on masked.json).
+    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette;
     bool wavefront = wf_capable && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
-                                    (p->schedule == GBL_SCHEDULE_AUTO && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
+                                    (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
                                                                           ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS)));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
-        ctx->error = "the wavefront schedule covers the path tracer without Russian roulette and without mask materials";
+        ctx->error = "the wavefront schedule covers the path tracer without Russian roulette";
         return GBL_ERR_UNSUPPORTED;
     }
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));

@@ -72,6 +72,13 @@ struct WfArgs {
     uint32_t* wave_next;  // per shade-wave cursor into that wave's contiguous list of path ids (no atomics:
                           // only the owning wave ever touches its word)
     uint32_t paths_per_wave;
+    // mask scenes only (DevScene::has_masks): the isOpaque-filtered MIS hit + attenuation of an extension ray whose
+    // closest hit is a mask (-2 in hit2_inst: same as the closest hit), and the shadow queue's un-multiplied terms
+    float4* hit2;         // t, b1, b2, as_float(tri)
+    int32_t* hit2_inst;
+    float4* mis_tr;       // attenuation.xyz
+    float4* sh_f;         // f.xyz, |n.wi|
+    float4* sh_L;         // L.xyz, lWeight
     uint32_t* stack_spill; // global backing of the trace kernels' stacks beyond GBL_WF_STACK_LDS levels (SplitStack)
     uint32_t* live_flags; // [8]: set by wf_shade when any of its slots is still alive
     float4* li_buf;       // per-sample radiance of the pass, pixel-major: pixel * pass_spp + kk
@@ -126,8 +133,10 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 #ifndef GBL_WF_TRACE_WAVES
 #define GBL_WF_TRACE_WAVES 5   // 96 VGPRs (4 spilled): 5 waves per SIMD measured 3-5 % faster than 4; 6 spills too much
 #endif
-template <bool ANY, bool STATS, bool EXT>
-__global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
+// MASKS: the scene has mask materials (implies EXT); only those builds carry the filtered queries and the
+// attenuation walks, which would otherwise cost every EXT scene ~150 spilled registers.
+template <bool ANY, bool STATS, bool EXT, bool MASKS = false>
+__global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     const SplitStack stk = {reinterpret_cast<uint32_t*>(smem) + threadIdx.x, wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x,
                             gridDim.x * GBL_BLOCK};
@@ -146,8 +155,11 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevSce
     st.cur = GBL_STACK_EXIT;
     st.inst = -1;
     st.mint = st.maxt = 0.0f;
-    uint32_t slot = 0;
+    uint32_t slot = 0, entry = 0;
     F3 contrib = f3(0, 0, 0);
+    bool needs_mis = false;
+    constexpr bool masks = EXT && MASKS;
+    constexpr int filter = (ANY && masks) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE;   // shadow rays: scene->occluded(ray, isOpaque)
 
     for (;;) {
         // ---- refill idle lanes from this wave's regions (all scalar bookkeeping)
@@ -177,14 +189,16 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevSce
                     a = wf_ld_nt(&wa.sh_o[my_entry]);
                     b = wf_ld_nt(&wa.sh_d[my_entry]);
                     float4 c = wf_ld_nt(&wa.sh_c[my_entry]);
-                    contrib = f3(c.x, c.y, c.z);
+                    contrib = f3(c.x, c.y, c.z);   // mask scenes: (lightPdf, isArea, -) -- the product is formed after the walk
                     slot = __float_as_uint(c.w);
                     maxt = b.w;
+                    entry = my_entry;
                 } else {
                     slot = wa.ext_q[my_entry];
                     a = wf_ld_nt(&wa.ray_o[slot]);
                     b = wf_ld_nt(&wa.ray_d[slot]);
                     maxt = INFINITY;
+                    needs_mis = b.w != 0.0f;
                 }
                 trav_begin(sc, st, f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), a.w, maxt, stk);
                 busy = true;
@@ -208,8 +222,15 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevSce
                 if (at_int) trav_interior<STATS, !ANY>(sc, st, stk, cnt);
             } else if (at_oth) {
                 bool occluded = false;
-                if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded)) {
+                if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded, filter)) {
                     if (ANY) {
+                        if constexpr (masks) if (!occluded) {
+                            // evalAttenuation along the unoccluded shadow segment, then f * tr * L * |n.wi| (* lWeight) / lightPdf
+                            const F3 tr = eval_attenuation<STATS>(sc, st.world.o, st.world.d, st.mint, st.maxt, stk, cnt);
+                            const float4 ff = wa.sh_f[entry], LL = wa.sh_L[entry];
+                            const F3 lf = f3(ff.x, ff.y, ff.z), lL = f3(LL.x, LL.y, LL.z);
+                            contrib = contrib.y != 0.0f ? div(lf * tr * lL * ff.w * LL.w, contrib.x) : div(lf * tr * lL * ff.w, contrib.x);
+                        }
                         if (!occluded) {
                             float4 ld = wa.s_ld[slot];   // one shadow ray per slot per iteration: plain read-modify-write
                             ld.x += contrib.x;
@@ -220,6 +241,21 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WF_TRACE_WAVES) void wf_trace(DevSce
                     } else {
                         wf_st_nt(&wa.hit[slot], make_float4(st.hit.t, st.hit.b1, st.hit.b2, __uint_as_float(st.hit.tri)));
                         wa.hit_inst[slot] = st.hit.inst;
+                        if constexpr (masks) {
+                            int h2 = -2;   // the MIS query would find the same surface
+                            if (needs_mis && st.hit.inst >= 0 && sc.instances[st.hit.inst].is_mask != 0u) {
+                                // the closest surface is a mask: the isOpaque-filtered query and the masks in front of its hit
+                                const F3 ro = st.world.o, rd = st.world.d;
+                                const float rmint = st.mint;
+                                Hit ho;
+                                const bool go = trace<false, STATS, EXT>(sc, ro, rd, rmint, INFINITY, stk, ho, cnt, GBL_FILTER_OPAQUE);
+                                const F3 tr = eval_attenuation<STATS>(sc, ro, rd, rmint, go ? ho.t : INFINITY, stk, cnt);
+                                h2 = go ? ho.inst : -1;
+                                wa.hit2[slot] = make_float4(ho.t, ho.b1, ho.b2, __uint_as_float(ho.tri));
+                                wa.mis_tr[slot] = make_float4(tr.x, tr.y, tr.z, 0.0f);
+                            }
+                            wa.hit2_inst[slot] = h2;
+                        }
                     }
                     busy = false;
                 }
@@ -250,7 +286,11 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         ps.bounce = static_cast<int>(id.x >> 16) - 4;
         out_index = id.y;
         k = id.z;
+        ps.punch = (id.w & 1u) != 0u;
+    } else {
+        ps.punch = false;
     }
+    const bool masks = EXT && sc.has_masks != 0;
     const bool alive = ps.bounce >= -1;
     bool finished = false;
     Hit hit;
@@ -307,6 +347,25 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                     hit_differentials<REPLAY>(sc, src, ps.bounce < 0, image_x, image_y, fr, tf);
                 }
             }
+            // mask scenes: the MIS query (isOpaque) and its attenuation, prepared by wf_trace when they differ
+            int mis_inst = got ? hit.inst : -1;
+            F3 mis_n = fr.n, mis_tr = f3(1.0f, 1.0f, 1.0f);
+            if (masks && got && ps.bounce >= 0 && !ps.punch) {
+                const int h2 = wa.hit2_inst[slot];
+                if (h2 != -2) {
+                    mis_inst = h2;
+                    const float4 t4 = wa.mis_tr[slot];
+                    mis_tr = f3(t4.x, t4.y, t4.z);
+                    if (h2 >= 0) {
+                        const float4 q = wa.hit2[slot];
+                        Hit ho;
+                        ho.t = q.x; ho.b1 = q.y; ho.b2 = q.z; ho.tri = __float_as_uint(q.w); ho.inst = h2;
+                        Frag fo;
+                        make_fragment<EXT>(sc, ho, ps.o, ps.d, fo);
+                        mis_n = fo.n;
+                    }
+                }
+            }
             if (ps.bounce < 0) {
                 if (!got) {
                     finished = true;
@@ -315,11 +374,15 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                     ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
                     ps.bounce = 0;
                 }
+            } else if (EXT && ps.punch) {
+                ps.punch = false;   // the bounce that punched through a mask adds no direct light (GoblinPathtracer.cpp:122-136)
+                ps.bounce += 1;
+                if (!got) finished = true;
             } else {
-                if (got && sc.instances[hit.inst].area_light == ps.light) {
-                    F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                if (mis_inst >= 0 && sc.instances[mis_inst].area_light == ps.light) {
+                    F3 le = hit_Le(sc, mis_inst, mis_n, -ps.d);
                     if (!is_black(le)) {
-                        F3 term = div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
+                        F3 term = EXT ? div(ps.f * mis_tr * le * ps.cosw * ps.fw, ps.bsdf_pdf) : div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
                         ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
                     }
                 }
@@ -336,6 +399,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
 
     // ---- shade: light sample -> shadow entry, BSDF sample -> next ray
     bool need_shadow = false, has_ray = false, zombie = false;
+    float4 sh_f4 = make_float4(0, 0, 0, 0), sh_L4 = make_float4(0, 0, 0, 0);
     F3 shadow_d = f3(0, 0, 1), contrib = f3(0, 0, 0);
     float shadow_maxt = 0.0f;
     if (alive && !finished) {
@@ -363,34 +427,51 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         ps.pick_pdf = sc.light_pick_pdf[li];
         ps.Ld = f3(0, 0, 0);
         const DevMaterial* mat = sc.materials + sc.instances[hit.inst].material;
-        DevMaterial resolved;   // EXT: the hit material with its textures evaluated
-        if (EXT && mat->has_tex != 0u) {
-            resolve_material(sc, *mat, fr, tf, resolved);
-            mat = &resolved;
-        }
+        ResolvedMat rmat;   // EXT: the hit material with its textures evaluated / its mask unwrapped
+        if (EXT) resolve_hit_material(sc, sc.instances[hit.inst].material, fr, tf, rmat);
         const DevLight& light = sc.lights[li];
         LightSampleOut ls;
         light_sample<EXT>(sc, light, fr.p, fr.eps, u_light_c, u_light_1, u_light_2, ls);
         if (!is_black(ls.L) && ls.pdf > 0.0f) {
-            F3 f = mat_bsdf(*mat, fr.n, wo, ls.wi);
+            F3 f = EXT ? rmat_bsdf(rmat, fr.n, wo, ls.wi) : mat_bsdf(*mat, fr.n, wo, ls.wi);
             if (!is_black(f)) {
                 need_shadow = true;
                 shadow_d = ls.wi;
                 shadow_maxt = ls.maxt;
+                float lw = 1.0f;
                 if (light.type != GBL_LIGHT_AREA) {
                     contrib = div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);
                 } else {
-                    float bp = mat_pdf(*mat, fr.n, wo, ls.wi);
-                    float lw = power_heuristic(ls.pdf, bp);
+                    float bp = EXT ? rmat_pdf(rmat, fr.n, wo, ls.wi) : mat_pdf(*mat, fr.n, wo, ls.wi);
+                    lw = power_heuristic(ls.pdf, bp);
                     contrib = div(f * ls.L * absdot(fr.n, ls.wi) * lw, ls.pdf);
+                }
+                if (masks) {   // the shadow kernel multiplies the attenuation in, in the reference's order
+                    sh_f4 = make_float4(f.x, f.y, f.z, absdot(fr.n, ls.wi));
+                    sh_L4 = make_float4(ls.L.x, ls.L.y, ls.L.z, lw);
+                    contrib = f3(ls.pdf, light.type == GBL_LIGHT_AREA ? 1.0f : 0.0f, 0.0f);
                 }
             }
         }
         F3 wi;
         float pdf;
-        bool specular;
-        F3 f = mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
-        if (!is_black(f) && pdf > 0.0f) {
+        bool specular, null_sampled = false;
+        F3 f = EXT ? rmat_sample(rmat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular, &null_sampled)
+                   : mat_sample(*mat, fr, wo, u_bsdf_c, u_bsdf_1, u_bsdf_2, &wi, &pdf, &specular);
+        if (EXT && null_sampled && !is_black(f) && pdf > 0.0f) {
+            // punch through the mask: throughput *= f / pdf, and this bounce's direct light is dropped with its shadow ray
+            ps.throughput = ps.throughput * div(f, pdf);
+            ps.o = fr.p;
+            ps.d = wi;
+            ps.mint = fr.eps;
+            ps.punch = true;
+            ps.f = f3(0, 0, 0);
+            ps.fw = 0.0f;
+            ps.bsdf_pdf = 1.0f;
+            ps.cosw = 0.0f;
+            need_shadow = false;
+            has_ray = true;
+        } else if (!is_black(f) && pdf > 0.0f) {
             float fw = 1.0f;
             if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
             ps.f = f;
@@ -425,6 +506,10 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             wa.sh_o[pos] = make_float4(fr.p.x, fr.p.y, fr.p.z, fr.eps);
             wa.sh_d[pos] = make_float4(shadow_d.x, shadow_d.y, shadow_d.z, shadow_maxt);
             wa.sh_c[pos] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+            if (masks) {
+                wa.sh_f[pos] = sh_f4;
+                wa.sh_L[pos] = sh_L4;
+            }
         }
         if (lane == 0) wa.sh_count[wave_gid] = static_cast<uint32_t>(__popcll(m));
     }
@@ -488,6 +573,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                         ps.bsdf_pdf = ps.pick_pdf = 1.0f;
                         ps.light = 0;
                         ps.bounce = -1;
+                        ps.punch = false;
                         started = true;
                         has_ray = true;
                         if (STATS) cnt.dims += 2;
@@ -504,7 +590,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     if (keep) {
         if (has_ray) {
             wf_st_nt(&wa.ray_o[slot], make_float4(ps.o.x, ps.o.y, ps.o.z, ps.mint));
-            wf_st_nt(&wa.ray_d[slot], make_float4(ps.d.x, ps.d.y, ps.d.z, 0.0f));
+            // .w: this ray also serves the MIS estimate (not a camera ray, not a punch-through continuation)
+            wf_st_nt(&wa.ray_d[slot], make_float4(ps.d.x, ps.d.y, ps.d.z, (ps.bounce >= 0 && !ps.punch) ? 1.0f : 0.0f));
         }
         if (zombie) wa.hit_inst[slot] = -1;
         wf_st_nt(&wa.s_thr[slot], make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.cosw));
@@ -514,7 +601,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         wa.s_pixel[slot] = pixel_key;
     }
     if (keep || dead || want_new || wa.init)
-        wa.s_id[slot] = make_uint4(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16), out_index, k, 0u);
+        wa.s_id[slot] = make_uint4(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16), out_index, k, ps.punch ? 1u : 0u);
     // ---- extension queue: compacted into this wave's region
     {
         bool enq = keep && has_ray;

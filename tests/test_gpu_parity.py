@@ -54,9 +54,7 @@ class _Scheduled:
 
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
-        d = self._t.scene.desc
-        masks = any(d.materials[i].type == _abi.GBL_MAT_MASK for i in range(d.num_materials))   # megakernel only
-        kw.setdefault("schedule", "auto" if (s.integrator == _abi.GBL_INTEGRATOR_AO or kw.get("rr") or masks) else self._schedule)
+        kw.setdefault("schedule", "auto" if (s.integrator == _abi.GBL_INTEGRATOR_AO or kw.get("rr")) else self._schedule)
         return self._t.render(**kw)
 
 
@@ -341,15 +339,13 @@ def test_full_size_properties_on_the_headline_config(torch):
         assert flips <= LI_FLIP_TOL
 
 
-def test_masks_run_on_the_megakernel_only(torch):
-    scene = gs.load_scene("masked", gs.config_overrides(resolution=(16, 16), spp=1, depth=3))
+def test_masks_under_both_schedules_are_bit_identical(torch):
+    scene = gs.load_scene("masked", gs.config_overrides(resolution=(48, 48), spp=9, depth=6))
     from goblin_amd.renderer import HipPathTracer
     r = HipPathTracer(scene, 0)
-    r.render(schedule="auto")
-    r.render(schedule="megakernel")
-    with pytest.raises(_abi.GoblinError) as e:
-        r.render(schedule="wavefront")
-    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+    a = r.render(seed=3, want_li=True, schedule="megakernel")["li"]
+    b = r.render(seed=3, want_li=True, schedule="wavefront")["li"]
+    assert torch.equal(a, b)
 
 
 def test_error_behaviour(torch, schedule):
