@@ -790,15 +790,14 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while a path is cheap
     // (short paths through a small scene: configs 1, 2), the wavefront formulation once traversal dominates and its
     // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 4.2 s against 6.4 s) or many
-    // instanced triangles (config 4, 15 bunnies: 317 ms against 438 ms).  AO and the Russian-roulette extension always
-    // run the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
+    // instanced triangles (config 4, 15 bunnies: 317 ms against 438 ms).  AO always runs the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
     // filtered MIS query and the attenuation walks inline in the trace kernel: 48.6 ms against 16.1 ms on masked.json).
-    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH && !p->russian_roulette;
+    const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
     bool wavefront = wf_capable && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
                                                                           ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS)));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
-        ctx->error = "the wavefront schedule covers the path tracer without Russian roulette";
+        ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;
     }
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));

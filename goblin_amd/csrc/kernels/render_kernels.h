@@ -526,7 +526,10 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                             ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
                             finished = true;
                         } else {
-                            ps.throughput = div(ps.throughput, q);
+                            // survivors carry 1/q on what depends on the extension ray -- the BSDF-sampled light term and
+                            // the next throughput, both proportional to cosw -- NOT on this vertex's light-sampled term,
+                            // which is collected whether or not the path survives
+                            ps.cosw = ps.cosw * (1.0f / q);
                         }
                     }
                 } else {

@@ -471,13 +471,27 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             ps.cosw = 0.0f;
             need_shadow = false;
             has_ray = true;
-        } else if (!is_black(f) && pdf > 0.0f) {
+        }
+        // Russian roulette (build-side extension, off in every parity mode): as in the megakernel, a killed path still
+        // collects this vertex's direct light -- here through the zombie / immediate-finish branches below
+        bool rr_killed = false;
+        float rr_inv = 1.0f;
+        if (ra.russian_roulette && !REPLAY && !(EXT && null_sampled) && !is_black(f) && pdf > 0.0f && ps.bounce >= 2) {
+            F3 tn = ps.throughput * div(f * absdot(wi, fr.n), pdf);
+            float q = fminf(0.95f, fmaxf(tn.x, fmaxf(tn.y, tn.z)));
+            float u = nat_u01(nat_mix(nat_mix(src.pixel_key, 0xBADC0DEu + ps.bounce), src.k));
+            if (!(u < q)) rr_killed = true;
+            else rr_inv = 1.0f / q;   // carried by cosw, see the megakernel
+        }
+        if (EXT && null_sampled && !is_black(f) && pdf > 0.0f) {
+        } else if (!rr_killed && !is_black(f) && pdf > 0.0f) {
             float fw = 1.0f;
             if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
             ps.f = f;
             ps.fw = fw;
             ps.bsdf_pdf = pdf;
             ps.cosw = absdot(wi, fr.n);
+            if (ra.russian_roulette && !REPLAY && rr_inv != 1.0f) ps.cosw = ps.cosw * rr_inv;
             ps.o = fr.p;
             ps.d = wi;
             ps.mint = fr.eps;

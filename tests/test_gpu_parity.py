@@ -54,7 +54,7 @@ class _Scheduled:
 
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
-        kw.setdefault("schedule", "auto" if (s.integrator == _abi.GBL_INTEGRATOR_AO or kw.get("rr")) else self._schedule)
+        kw.setdefault("schedule", "auto" if s.integrator == _abi.GBL_INTEGRATOR_AO else self._schedule)
         return self._t.render(**kw)
 
 
@@ -337,6 +337,21 @@ def test_full_size_properties_on_the_headline_config(torch):
         flips = helpers.li_mismatch_fraction(li_cpu, li_ref)
         print("full-size block", (bx, by), "flips", flips, "means", li_cpu[:, :3].mean(), li_ref[:, :3].mean())
         assert flips <= LI_FLIP_TOL
+
+
+def test_russian_roulette_extension(torch):
+    """Off in every parity mode (the reference's loop is fixed length); when switched on both schedules kill the same
+    paths (counter-based draw) and the estimate stays unbiased: the film mean moves by noise only."""
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("cornell", gs.config_overrides(resolution=(48, 48), spp=64, depth=12))
+    r = HipPathTracer(scene, 0)
+    a = r.render(seed=11, want_li=True, rr=True, schedule="megakernel", stats=True)
+    b = r.render(seed=11, want_li=True, rr=True, schedule="wavefront")
+    assert torch.equal(a["li"], b["li"])
+    full = r.render(seed=11, want_li=True, stats=True, schedule="megakernel")
+    assert a["stats"]["extension_rays"] < 0.8 * full["stats"]["extension_rays"]      # paths really end earlier
+    ma, mf = float(a["li"][:, :3].mean()), float(full["li"][:, :3].mean())
+    assert abs(ma - mf) <= 0.03 * mf
 
 
 def test_masks_under_both_schedules_are_bit_identical(torch):
