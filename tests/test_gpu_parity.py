@@ -339,6 +339,25 @@ def test_full_size_properties_on_the_headline_config(torch):
         assert flips <= LI_FLIP_TOL
 
 
+def test_small_radiance_buffer_budget_paths(torch, schedule, monkeypatch):
+    """With the per-sample radiance buffer capped (GBL_LI_BUDGET_MB) the megakernel falls back to splatting through
+    its LDS tile and the wavefront schedule splits the samples into passes; the film must not change."""
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("cornell", gs.config_overrides(resolution=(64, 64), spp=64, depth=5))
+    ref = HipPathTracer(scene, 0).render(seed=21, schedule=schedule)["film"].numpy()
+    monkeypatch.setenv("GBL_LI_BUDGET_MB", "1")      # 65 536 samples: 68*68*64 = 295 936 do not fit
+    small = HipPathTracer(scene, 0)
+    film = small.render(seed=21, schedule=schedule)["film"].numpy()
+    np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
+    assert helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref)) <= 1e-5
+    ao = gs.load_scene("bunny", gs.config_overrides(resolution=(48, 48), spp=16, method="ao", ao_samples=9))
+    monkeypatch.delenv("GBL_LI_BUDGET_MB")
+    ref_ao = HipPathTracer(ao, 0).render(seed=5)["film"].numpy()
+    monkeypatch.setenv("GBL_LI_BUDGET_MB", "1")
+    film_ao = HipPathTracer(ao, 0).render(seed=5)["film"].numpy()
+    assert helpers.rel_l2(ob.normalize_film(film_ao), ob.normalize_film(ref_ao)) <= 1e-5
+
+
 def test_russian_roulette_extension(torch):
     """Off in every parity mode (the reference's loop is fixed length); when switched on both schedules kill the same
     paths (counter-based draw) and the estimate stays unbiased: the film mean moves by noise only."""
