@@ -339,6 +339,44 @@ def test_full_size_properties_on_the_headline_config(torch):
         assert flips <= LI_FLIP_TOL
 
 
+def test_c_level_film_allreduce_with_a_one_rank_communicator(torch):
+    """gbl_film_allreduce is the reduction a C++ host calls with its own ncclComm_t.  One GPU cannot host two ranks,
+    so this drives the entry point (dlopen of librccl, symbol lookup, ncclAllReduce on the caller's stream) with a
+    communicator of ONE rank: the film must come back unchanged."""
+    import ctypes.util
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(32, 32), spp=4, depth=3))
+    r = HipPathTracer(scene, 0)
+    film = r.render(seed=2)["film"]
+    before = film.numpy().copy()
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl not loadable here")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        st = r.lib.gbl_film_allreduce(r.handle, comm, C.c_void_p(film.accum.data_ptr()), None)
+        assert st == _abi.GBL_OK, r.lib.gbl_last_error(r.handle)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(film.numpy(), before)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_small_radiance_buffer_budget_paths(torch, schedule, monkeypatch):
     """With the per-sample radiance buffer capped (GBL_LI_BUDGET_MB) the megakernel falls back to splatting through
     its LDS tile and the wavefront schedule splits the samples into passes; the film must not change."""
