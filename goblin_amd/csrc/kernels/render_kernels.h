@@ -260,7 +260,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4;
-    const LdsStack stk = {stack + threadIdx.x};
+    const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
 
     LaneCounters cnt = {};
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4;
-    const LdsStack stk = {stack + threadIdx.x};
+    const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
 
     LaneCounters cnt = {};

@@ -106,8 +106,15 @@ struct TravState {
 // Traversal stacks.  LdsStack: the whole per-lane stack in LDS, column-major over the workgroup (megakernel, AO).
 // SplitStack: the first GBL_WF_STACK_LDS levels in LDS and the (rarely reached) deeper ones in a global backing
 // column, so the trace kernels of the wavefront schedule fit more workgroups per CU (44 KB -> 16 KB of LDS).
+// The pointers carry their address space explicitly: through a plain `uint32_t*` member the compiler loses track of
+// it on some paths and pops the stack with flat_load (slower than ds_read, and it ties vmcnt to lgkmcnt).
+typedef __attribute__((address_space(3))) uint32_t gbl_lds_u32;
+typedef __attribute__((address_space(1))) uint32_t gbl_glb_u32;
+__device__ __forceinline__ gbl_lds_u32* gbl_as_lds(uint32_t* p) { return (gbl_lds_u32*)p; }
+__device__ __forceinline__ gbl_glb_u32* gbl_as_global(uint32_t* p) { return (gbl_glb_u32*)p; }
+
 struct LdsStack {
-    uint32_t* p;
+    gbl_lds_u32* p;
     __device__ __forceinline__ void store(int i, uint32_t v) const { p[i * GBL_BLOCK] = v; }
     __device__ __forceinline__ uint32_t load(int i) const { return p[i * GBL_BLOCK]; }
 };
@@ -115,8 +122,8 @@ struct LdsStack {
 #define GBL_WF_STACK_LDS 16
 #endif
 struct SplitStack {
-    uint32_t* p;        // LDS column of this lane
-    uint32_t* g;        // global backing column of this thread
+    gbl_lds_u32* p;     // LDS column of this lane
+    gbl_glb_u32* g;     // global backing column of this thread
     uint32_t gstride;   // threads in the grid
     __device__ __forceinline__ void store(int i, uint32_t v) const {
         if (i < GBL_WF_STACK_LDS) p[i * GBL_BLOCK] = v;

@@ -138,8 +138,8 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 template <bool ANY, bool STATS, bool EXT, bool MASKS = false>
 __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SplitStack stk = {reinterpret_cast<uint32_t*>(smem) + threadIdx.x, wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x,
-                            gridDim.x * GBL_BLOCK};
+    const SplitStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x),
+                            gbl_as_global(wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x), gridDim.x * GBL_BLOCK};
     LaneCounters cnt = {};
     const int lane = threadIdx.x & 63;
     const uint32_t n_regions = wa.pool_size / 64u;
