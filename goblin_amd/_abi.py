@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 5
+GBL_ABI_VERSION = 6
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM = range(6)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM"}
@@ -48,14 +48,15 @@ class gbl_texture(C.Structure):
 
 
 GBL_TEX_CONSTANT, GBL_TEX_CHECKERBOARD, GBL_TEX_SCALE = 0, 1, 2
-GBL_MAT_LAMBERT, GBL_MAT_BLINN, GBL_MAT_TRANSPARENT, GBL_MAT_MIRROR, GBL_MAT_MASK = 0, 1, 2, 3, 4
+GBL_MAT_LAMBERT, GBL_MAT_BLINN, GBL_MAT_TRANSPARENT, GBL_MAT_MIRROR, GBL_MAT_MASK, GBL_MAT_SUBSURFACE = 0, 1, 2, 3, 4, 5
 GBL_MAP_UV, GBL_MAP_SPHERICAL = 0, 1
 
 
 class gbl_material(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", C.c_float * 3), ("color2", C.c_float * 3), ("index", C.c_float),
                 ("k", C.c_float), ("exponent", C.c_float), ("tex_color", C.c_int32), ("tex_color2", C.c_int32),
-                ("tex_exponent", C.c_int32), ("masked_material", C.c_int32)]
+                ("tex_exponent", C.c_int32), ("masked_material", C.c_int32), ("color3", C.c_float * 3),
+                ("tex_color3", C.c_int32)]
 
 
 class gbl_instance(C.Structure):

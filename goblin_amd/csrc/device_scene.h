@@ -82,6 +82,9 @@ struct DevMaterial {
     int32_t tex_color, tex_color2, tex_exponent;   // -1: the constant above; else an index into DevScene::textures
     uint32_t has_tex;                               // any of the three >= 0 (for a mask: also the wrapped material's)
     int32_t masked;                                 // type 4 (mask): the wrapped material; alpha = exponent, transparent colour = color
+    // type 5 (subsurface): color = sigma_a, color2 = sigma_s', color3 = Kr, index = eta, k = g, exponent = A = (1 + Fdr) / (1 - Fdr)
+    float color3[3];
+    int32_t tex_color3;
     float pad;
 };
 
@@ -161,6 +164,8 @@ struct DevScene {
     int32_t stack_entries;        // traversal stack depth this scene needs
     int32_t extended;             // scene uses analytic shapes, a directional light or a non-pinhole camera: EXT kernels
     int32_t has_masks;            // some instance carries a mask material: filtered queries + attenuation walks (megakernel only)
+    int32_t has_bssrdf;           // some material is a subsurface material: sss_kernel runs ahead of the path kernels
+    int32_t pad_scene;
     DevCamera camera;
     DevFilm film;
 };
@@ -180,6 +185,9 @@ struct RenderArgs {
     int32_t chunk_spp;
     uint32_t seed_key;
     uint32_t russian_roulette;
+    int32_t bssrdf_n;           // BSSRDFSampleIndex::samplesNum: roundToSquare(bssrdf_sample_num)
+    int32_t bssrdf_n2;          // size of its 2D patterns (rounded to a square once more)
+    const float* sss;           // per-sample Lsubsurface of this render (float4, pixel-major like li_out), or null
     const float* replay;        // Sample records for the sub-window, pixel-major
     float* li_out;
     float* li_defer;            // when set, the render kernel stores per-sample radiance here (pixel-major)

@@ -20,6 +20,7 @@
 #include "device_scene.h"
 #include "kernels/render_kernels.h"
 #include "kernels/wavefront.h"
+#include "kernels/subsurface.h"
 #include "kernels/lbvh.h"
 #include <hipcub/hipcub.hpp>
 #include "scene_prep.h"
@@ -50,6 +51,8 @@ struct gbl_ctx {
     float4* wf_li = nullptr;
     size_t wf_li_entries = 0;
     uint64_t li_budget = 0;   // li_budget_bytes()
+    float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
+    uint64_t sss_entries = 0;
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;
@@ -564,6 +567,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     sc.stack_entries = packed.stack_entries;
     sc.extended = packed.extended;
     sc.has_masks = packed.has_masks;
+    sc.has_bssrdf = packed.has_bssrdf;
     sc.camera = packed.camera;
     sc.film = packed.film;
     void* p = nullptr;
@@ -665,6 +669,7 @@ void gbl_destroy(gbl_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
+    if (ctx->sss_buf) (void)hipFree(ctx->sss_buf);
     if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
     if (ctx->wf_ev_shade) (void)hipEventDestroy(ctx->wf_ev_shade);
     if (ctx->wf_ev_shadow) (void)hipEventDestroy(ctx->wf_ev_shadow);
@@ -718,6 +723,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         int n2 = round_to_square(n1, &r2);
         ra.dims = 4 + 7 * ra.max_depth + 4 * n1 + 4 * n2;
         ra.off2_base = 4 + 3 * ra.max_depth + 4 * n1;
+        ra.bssrdf_n = n1;
+        ra.bssrdf_n2 = n2;
     }
     const int32_t* full = sc.film.window;
     bool whole = p->window[0] == 0 && p->window[1] == 0 && p->window[2] == 0 && p->window[3] == 0;
@@ -807,6 +814,36 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     for (int k = 0; k < 3; ++k)
         if (!tev[k]) HIP_TRY(ctx, hipEventCreate(&tev[k]));
     HIP_TRY(ctx, hipEventRecord(tev[0], stream));
+    if (sc.has_bssrdf != 0 && p->integrator == GBL_INTEGRATOR_PATH) {
+        // Lsubsurface of every camera sample, ahead of the path kernels that add it at the first hit (kernels/subsurface.h)
+        const uint64_t entries = npix * ra.spp;
+        if (entries * 16 > li_budget_bytes(ctx)) {
+            ctx->error = "a scene with subsurface materials keeps 16 bytes per camera sample: render this window in smaller pieces";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        if (entries > ctx->sss_entries) {
+            if (ctx->sss_buf) (void)hipFree(ctx->sss_buf);
+            ctx->sss_buf = nullptr;
+            ctx->sss_entries = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->sss_buf), entries * sizeof(float4));
+            if (e != hipSuccess) {
+                ctx->error = std::string("hipMalloc(subsurface term): ") + hipGetErrorString(e);
+                return GBL_ERR_OOM;
+            }
+            ctx->sss_entries = entries;
+        }
+        ra.sss = reinterpret_cast<const float*>(ctx->sss_buf);
+        auto k_sss = replay ? (want_stats ? sss_kernel<true, true> : sss_kernel<true, false>)
+                            : (want_stats ? sss_kernel<false, true> : sss_kernel<false, false>);
+        const size_t lds_sss = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+        if (lds_sss > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sss), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds_sss)));
+        const uint64_t total = static_cast<uint64_t>(ra.local_tiles) * 64 * ra.spp;
+        const uint64_t blocks = std::min<uint64_t>((total + GBL_BLOCK - 1) / GBL_BLOCK, static_cast<uint64_t>(ctx->num_cus) * 8);
+        hipLaunchKernelGGL(k_sss, dim3(static_cast<unsigned>(blocks)), dim3(GBL_BLOCK), lds_sss, stream, sc, ra, ctx->sss_buf);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (wavefront) {
         gbl_status wst = render_wavefront(ctx, ra, p, stream, want_stats, replay);
         if (wst != GBL_OK) return wst;

@@ -538,7 +538,7 @@ private:
         gbl_material black;
         memset(&black, 0, sizeof(black));
         black.type = GBL_MAT_LAMBERT;
-        black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = -1;
+        black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = black.tex_color3 = -1;
         material_ids_[camera_type_ + "_lens_material"] = static_cast<int>(s_->materials.size());
         s_->materials.push_back(black);
         ModelDecl d;
@@ -667,6 +667,31 @@ private:
         return static_cast<int>(s_->textures.size()) - 1;
     }
 
+    // BSSRDF(Kd, diffuseMeanFreePath, eta, g) -> sigma_a, sigma_s' (BSSRDF::convertFromDiffuse / diffuseReflectance /
+    // Fdr, GoblinMaterial.cpp:176-220, GoblinMaterial.h:94-105): 16 bisection steps on alpha' per channel.
+    static float bssrdf_fdr(float eta) {
+        if (eta < 1.0f) return -0.4399f + 0.7099f / eta - 0.3319f / (eta * eta) + 0.0636f / (eta * eta * eta);
+        return -1.4399f / (eta * eta) + 0.7099f / eta + 0.6681f + 0.0636f * eta;
+    }
+    static void convert_from_diffuse(const float kd[3], const float mean_free_path[3], float eta, float absorb[3], float scatter_prime[3]) {
+        const float fdr = bssrdf_fdr(eta);
+        const float A = (1.0f + fdr) / (1.0f - fdr);
+        for (int i = 0; i < 3; ++i) {
+            const float sigma_tr = 1.0f / mean_free_path[i];
+            float lo = 0.0f, hi = 1.0f;
+            for (int j = 0; j < 16; ++j) {
+                const float mid = 0.5f * (lo + hi);
+                const float sq = sqrtf(3.0f * (1.0f - mid));
+                const float rd = 0.5f * mid * (1.0f + expf(-(4.0f / 3.0f) * A * sq)) * expf(-sq);
+                if (rd > kd[i]) hi = mid; else lo = mid;
+            }
+            const float alpha = 0.5f * (lo + hi);
+            const float sigma_tp = sigma_tr / sqrtf(3.0f * (1.0f - alpha));
+            scatter_prime[i] = alpha * sigma_tp;
+            absorb[i] = sigma_tp - scatter_prime[i];
+        }
+    }
+
     gbl_status color_texture(const std::string& name, float out[3], int32_t* tex) {
         int id;
         gbl_status st = texture_ref(false, name, 1 << 30, &id, out);
@@ -712,7 +737,7 @@ private:
         std::string type = p.get_string("type");
         gbl_material m;
         memset(&m, 0, sizeof(m));
-        m.tex_color = m.tex_color2 = m.tex_exponent = m.masked_material = -1;
+        m.tex_color = m.tex_color2 = m.tex_exponent = m.masked_material = m.tex_color3 = -1;
         gbl_status st;
         if (type == "blinn") {
             m.type = GBL_MAT_BLINN;
@@ -748,11 +773,30 @@ private:
             if (!earlier) return fail(GBL_ERR_INVALID, "Material " + inner + " not defined!");
             int inner_id;
             if ((st = material_id(inner, &inner_id)) != GBL_OK) return st;
-            if (s_->materials[inner_id].type == GBL_MAT_MASK)
-                return fail(GBL_ERR_UNSUPPORTED, "a mask material wrapping another mask is outside the device path");
+            if (s_->materials[inner_id].type == GBL_MAT_MASK || s_->materials[inner_id].type == GBL_MAT_SUBSURFACE)
+                return fail(GBL_ERR_UNSUPPORTED, "a mask material wrapping a mask or a subsurface material is outside the device path");
             m.masked_material = inner_id;
         } else if (type == "subsurface") {
-            return fail(GBL_ERR_UNSUPPORTED, "material type \"" + type + "\" is outside the device path");
+            // createSubsurfaceMaterial (GoblinMaterial.cpp:881-927)
+            m.type = GBL_MAT_SUBSURFACE;
+            m.index = p.get_float("index", 1.5f);
+            m.k = p.get_float("g", 0.0f);
+            m.color3[0] = m.color3[1] = m.color3[2] = 1.0f;
+            if (p.has_string("Kr") && (st = color_texture(p.get_string("Kr"), m.color3, &m.tex_color3)) != GBL_OK) return st;
+            if (p.has_vec3("Kd")) {
+                const Vec kd = p.get_vec(p.vec3s, "Kd", vec(0, 0, 0));
+                const Vec mfp = p.get_vec(p.vec3s, "mean_free_path", vec(1.0f, 1.0f, 1.0f));
+                convert_from_diffuse(kd.v, mfp.v, m.index, m.color, m.color2);
+            } else {
+                const float marble_absorb[3] = {0.0021f, 0.0041f, 0.0071f}, marble_scatterp[3] = {2.19f, 2.62f, 3.00f};
+                for (int i = 0; i < 3; ++i) {
+                    m.color[i] = marble_absorb[i];
+                    m.color2[i] = marble_scatterp[i];
+                }
+                if (p.has_string("absorb") && (st = color_texture(p.get_string("absorb"), m.color, &m.tex_color)) != GBL_OK) return st;
+                if (p.has_string("scatter_prime") &&
+                    (st = color_texture(p.get_string("scatter_prime"), m.color2, &m.tex_color2)) != GBL_OK) return st;
+            }
         } else {  // "lambert" and the unknown-type fallback
             m.type = GBL_MAT_LAMBERT;
             if ((st = color_texture(p.get_string("Kd"), m.color, &m.tex_color)) != GBL_OK) return st;
@@ -928,7 +972,7 @@ private:
                 gbl_material black;
                 memset(&black, 0, sizeof(black));
                 black.type = GBL_MAT_LAMBERT;
-                black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = -1;
+                black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = black.tex_color3 = -1;
                 gbl_instance inst;
                 memset(&inst, 0, sizeof(inst));
                 inst.mesh = lt.mesh;

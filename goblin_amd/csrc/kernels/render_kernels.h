@@ -227,6 +227,8 @@ __device__ __forceinline__ F3 eval_attenuation(const DevScene& sc, F3 o, F3 d, f
         make_fragment<true>(sc, h, o, d, fr, &tf);
         uv_differential(fr, tf, false, o, o, o, o);
         const DevMaterial& m = sc.materials[sc.instances[h.inst].material];
+        // a subsurface material does not match the BSDFnullptr request (matchType, GoblinMaterial.cpp:733-736): Black
+        if (m.type == GBL_MAT_SUBSURFACE) return f3(0.0f, 0.0f, 0.0f);
         float alpha = m.tex_exponent >= 0 ? tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_exponent, fr, tf).x : m.exponent;
         F3 tcolor = m.tex_color >= 0 ? tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_color, fr, tf) : f3(m.color[0], m.color[1], m.color[2]);
         thr = thr * ((1.0f - alpha) * tcolor);
@@ -385,6 +387,10 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     } else {
                         F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
                         ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                        if (EXT && sc.has_bssrdf != 0) {   // Li += Lsubsurface (kernels/subsurface.h), GoblinPathtracer.cpp:69
+                            const float4 ss = reinterpret_cast<const float4*>(ra.sss)[out_index];
+                            ps.Li = f3(ps.Li.x + ss.x, ps.Li.y + ss.y, ps.Li.z + ss.z);
+                        }
                         ps.bounce = 0;
                     }
                 } else if (EXT && ps.punch) {

@@ -67,6 +67,24 @@ struct SampleSource {
         float off = j + nat_u01(nat_mix(ky, k));
         return 0u * strata + off * sub;
     }
+    // slot `slot` of an n-strata 1D pattern whose slots are consumed together with other patterns' (the BSSRDF block):
+    // the slot's stratum is a keyed bijection of it per camera sample, standing in for the reference's in-pattern shuffle
+    // (GoblinSampler.cpp:171-196) -- without it slot j of every pattern would sit in stratum j
+    __device__ __forceinline__ uint32_t slot_stratum(uint32_t pattern_id, uint32_t n, uint32_t slot) const {
+        return n > 1u ? nat_permute(slot, n, nat_mix(key(pattern_id, 0x5bd1e995u), k)) : slot;
+    }
+    __device__ __forceinline__ float native_1d_n(uint32_t pattern, uint32_t n, uint32_t slot) const {
+        uint32_t st = slot_stratum(2u + pattern, n, slot);
+        uint32_t ky = key(2u + pattern, st);
+        uint32_t j = nat_permute(k, static_cast<uint32_t>(spp), ky);
+        float strata = 1.0f / static_cast<float>(n);
+        float sub = strata / spp;
+        float off = j + nat_u01(nat_mix(ky, k));
+        return st * strata + off * sub;
+    }
+    __device__ __forceinline__ void native_2d_slot(uint32_t pattern_id, uint32_t n, uint32_t slot, float* u, float* v) const {
+        native_2d(pattern_id, n, slot_stratum(pattern_id, n, slot), true, u, v);
+    }
     // 2D pattern: stratum i of an n-point pattern (n a perfect square), sub-cell grid root x root
     __device__ __forceinline__ void native_2d(uint32_t pattern_id, uint32_t n, uint32_t i, bool permute, float* u, float* v) const {
         uint32_t ky = key(pattern_id, i);

@@ -17,6 +17,7 @@
 #define GBL_MAT_TRANSPARENT 2u
 #define GBL_MAT_MIRROR 3u
 #define GBL_MAT_MASK 4u
+#define GBL_MAT_SUBSURFACE 5u
 #define GBL_LIGHT_POINT 0u
 #define GBL_LIGHT_DIRECTIONAL 1u
 #define GBL_LIGHT_SPOT 2u
@@ -239,6 +240,10 @@ __device__ __forceinline__ void resolve_material(const DevScene& sc, const DevMa
         out.color2[0] = c.x; out.color2[1] = c.y; out.color2[2] = c.z;
     }
     if (m.tex_exponent >= 0) out.exponent = tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_exponent, fr, tf).x;
+    if (m.tex_color3 >= 0) {
+        F3 c = tex_eval<GBL_TEX_MAX_DEPTH>(sc, m.tex_color3, fr, tf);
+        out.color3[0] = c.x; out.color3[1] = c.y; out.color3[2] = c.z;
+    }
 }
 
 // shadeToWorld * v, shadeToWorld = transpose(rows t, b, n)
@@ -383,6 +388,18 @@ __device__ __forceinline__ F3 mat_sample(const DevMaterial& m, const Frag& fr, F
         *wi = w_refr;
         *pdf = 1.0f - chance;
         return f3(m.color2[0], m.color2[1], m.color2[2]) * refract;
+    }
+    if (m.type == GBL_MAT_SUBSURFACE) {
+        // SubsurfaceMaterial::sampleBSDF (GoblinMaterial.cpp:728-745): Kr * specularReflectDieletric(1, eta), pdf 1
+        float cosi = dot(n, wo);
+        bool entering = cosi > 0.0f;
+        F3 nn = entering ? n : -n;
+        float ci = entering ? cosi : -cosi;
+        float ei = entering ? 1.0f : m.index, et = entering ? m.index : 1.0f;
+        float f = fresnel_dielectric(ci, ei, et);
+        *wi = 2 * ci * nn - wo;
+        *pdf = 1.0f;
+        return f3(m.color3[0], m.color3[1], m.color3[2]) * (f / ci);
     }
     // mirror
     float cosi = dot(n, wo);

@@ -372,6 +372,10 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                 } else {
                     F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
                     ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                    if (EXT && sc.has_bssrdf != 0) {   // Li += Lsubsurface (kernels/subsurface.h), GoblinPathtracer.cpp:69
+                        const float4 ss = reinterpret_cast<const float4*>(ra.sss)[static_cast<size_t>(out_index / wa.pass_spp) * ra.spp + k];
+                        ps.Li = f3(ps.Li.x + ss.x, ps.Li.y + ss.y, ps.Li.z + ss.z);
+                    }
                     ps.bounce = 0;
                 }
             } else if (EXT && ps.punch) {

@@ -489,7 +489,8 @@ gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* mesh
         di.mesh = static_cast<int32_t>(gi.mesh);
         di.shape = meshes[gi.mesh].shape;
         di.radius = meshes[gi.mesh].radius;
-        di.is_mask = materials[gi.material].type == GBL_MAT_MASK ? 1u : 0u;
+        // MaskMaterial ORs BSDFnullptr into its type; SubsurfaceMaterial's type is BSDFAll, which holds the bit as well
+        di.is_mask = (materials[gi.material].type == GBL_MAT_MASK || materials[gi.material].type == GBL_MAT_SUBSURFACE) ? 1u : 0u;
         // Transform::onBBox: the 8 corners of the mesh bound
         const float* lo = mesh_lo + 3 * gi.mesh;
         const float* hi = mesh_hi + 3 * gi.mesh;
@@ -691,13 +692,14 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->materials.resize(d->num_materials);
     for (uint32_t i = 0; i < d->num_materials; ++i) {
         const gbl_material& m = d->materials[i];
-        if (m.type > GBL_MAT_MASK) {
+        if (m.type > GBL_MAT_SUBSURFACE) {
             *err = "unknown material type";
             return GBL_ERR_INVALID;
         }
         if (m.type == GBL_MAT_MASK && (m.masked_material < 0 || static_cast<uint32_t>(m.masked_material) >= d->num_materials ||
-                                       d->materials[m.masked_material].type == GBL_MAT_MASK)) {
-            *err = "mask material " + std::to_string(i) + " must wrap a non-mask material of the scene";
+                                       d->materials[m.masked_material].type == GBL_MAT_MASK ||
+                                       d->materials[m.masked_material].type == GBL_MAT_SUBSURFACE)) {
+            *err = "mask material " + std::to_string(i) + " must wrap a non-mask, non-subsurface material of the scene";
             return GBL_ERR_INVALID;
         }
         DevMaterial& dm = out->materials[i];
@@ -715,11 +717,23 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         dm.tex_exponent = m.tex_exponent;
         dm.has_tex = (m.tex_color >= 0 || m.tex_color2 >= 0 || m.tex_exponent >= 0) ? 1u : 0u;
         dm.masked = m.type == GBL_MAT_MASK ? m.masked_material : -1;
+        dm.tex_color3 = -1;
+        if (m.type == GBL_MAT_SUBSURFACE) {
+            for (int k = 0; k < 3; ++k) dm.color3[k] = m.color3[k];
+            dm.tex_color3 = m.tex_color3;
+            dm.has_tex = 1u;   // its fragments always carry dpdu / dpdv: BSSRDF::sampleProbeRay and MISWeight read them
+            // BSSRDF ctor (GoblinMaterial.cpp:32-38): A from the diffuse Fresnel reflectance polynomial (GoblinMaterial.h:94-105)
+            const float eta = m.index;
+            const float fdr = eta < 1.0f ? -0.4399f + 0.7099f / eta - 0.3319f / (eta * eta) + 0.0636f / (eta * eta * eta)
+                                         : -1.4399f / (eta * eta) + 0.7099f / eta + 0.6681f + 0.0636f * eta;
+            dm.exponent = (1.0f + fdr) / (1.0f - fdr);
+            out->has_bssrdf = out->extended = 1;
+        }
         if (m.type == GBL_MAT_MASK) {
             const gbl_material& in = d->materials[m.masked_material];
             if (in.tex_color >= 0 || in.tex_color2 >= 0 || in.tex_exponent >= 0) dm.has_tex = 1u;
         }
-        for (int32_t t : {m.tex_color, m.tex_color2, m.tex_exponent}) {
+        for (int32_t t : {m.tex_color, m.tex_color2, m.tex_exponent, m.type == GBL_MAT_SUBSURFACE ? m.tex_color3 : -1}) {
             if (t < 0) continue;
             out->extended = 1;
             int depth = texture_depth(d, t, 0);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 5
+#define GBL_ABI_VERSION 6
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -79,7 +79,8 @@ typedef enum gbl_material_type {
     GBL_MAT_BLINN = 1,       /* GoblinMaterial.cpp:540-644 */
     GBL_MAT_TRANSPARENT = 2, /* GoblinMaterial.cpp:647-706 */
     GBL_MAT_MIRROR = 3,      /* GoblinMaterial.cpp:709-726 */
-    GBL_MAT_MASK = 4         /* GoblinMaterial.cpp:747-811: alpha-masked wrapper, BSDFnullptr punch-through */
+    GBL_MAT_MASK = 4,        /* GoblinMaterial.cpp:747-811: alpha-masked wrapper, BSDFnullptr punch-through */
+    GBL_MAT_SUBSURFACE = 5   /* GoblinMaterial.cpp:728-745 + BSSRDF :32-220; Renderer::Lsubsurface, GoblinRenderer.cpp:128-296 */
 } gbl_material_type;
 
 typedef enum gbl_texture_type {
@@ -124,6 +125,14 @@ typedef struct gbl_material {
      * (default 1), masked_material = index of the wrapped material (which must
      * not be a mask itself); -1 for every other type. */
     int32_t masked_material;
+    /* Subsurface (createSubsurfaceMaterial, GoblinMaterial.cpp:881-927): color = "absorb" sigma_a, color2 =
+     * "scatter_prime" sigma_s', color3 = "Kr" (default white), index = eta (default 1.5), k = "g" (default 0).  The
+     * "Kd" + "mean_free_path" form is converted to sigma_a / sigma_s' by the loader exactly as the reference's
+     * constructor does (BSSRDF::convertFromDiffuse, :176-212).  The material's type is BSDFAll, which carries the
+     * BSDFnullptr bit: the path tracer's isOpaque / notOpaque filters treat it like a mask (GoblinPathtracer.cpp:5-11,
+     * GoblinMaterial.h:393). */
+    float color3[3];
+    int32_t tex_color3;
 } gbl_material;
 
 /* InstancedPrimitive over a Model(geometry, material[, areaLight])

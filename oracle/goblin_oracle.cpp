@@ -702,7 +702,8 @@ void prepare(orc_scene* s) {
         in.mesh = gi.mesh;
         in.material = gi.material;
         in.area_light = gi.area_light;
-        in.is_mask = d.materials[gi.material].type == GBL_MAT_MASK;
+        // MaskMaterial ORs BSDFnullptr into its type; SubsurfaceMaterial's type is BSDFAll, which holds that bit too
+        in.is_mask = d.materials[gi.material].type == GBL_MAT_MASK || d.materials[gi.material].type == GBL_MAT_SUBSURFACE;
         s->has_masks = s->has_masks || in.is_mask;
         in.xf.set(gi.to_world.position, gi.to_world.orientation, gi.to_world.scale);
         iboxes[i] = transform_box(in.xf, s->meshes[in.mesh].bounds);   // Model::getAABB = mesh bound
@@ -1285,8 +1286,12 @@ Col tex_lookup(const orc_scene* sc, int id, const Frag& f) {
 // The material with every texture slot evaluated at this fragment: all lookups a bounce makes see the same
 // Fragment, so they all return these values.
 inline gbl_material resolve_material(const orc_scene* sc, const gbl_material& m, const Frag& f) {
-    if (m.tex_color < 0 && m.tex_color2 < 0 && m.tex_exponent < 0) return m;
+    if (m.tex_color < 0 && m.tex_color2 < 0 && m.tex_exponent < 0 && m.tex_color3 < 0) return m;
     gbl_material r = m;
+    if (m.tex_color3 >= 0) {
+        Col c = tex_lookup(sc, m.tex_color3, f);
+        r.color3[0] = c.r; r.color3[1] = c.g; r.color3[2] = c.b;
+    }
     if (m.tex_color >= 0) {
         Col c = tex_lookup(sc, m.tex_color, f);
         r.color[0] = c.r; r.color[1] = c.g; r.color[2] = c.b;
@@ -1373,6 +1378,7 @@ inline int material_type_bits(const gbl_material& m) {
         case GBL_MAT_BLINN: return BSDF_GLOSSY | BSDF_REFLECTION;
         case GBL_MAT_TRANSPARENT: return BSDF_SPECULAR | BSDF_REFLECTION | BSDF_TRANSMISSION;
         case GBL_MAT_MIRROR: return BSDF_SPECULAR | BSDF_REFLECTION;
+        case GBL_MAT_SUBSURFACE: return BSDF_ALL;   // GoblinMaterial.h:393,401
         default: return BSDF_DIFFUSE | BSDF_REFLECTION;
     }
 }
@@ -1523,6 +1529,13 @@ Col mat_sample(const gbl_material& m, const Frag& frag, V3 wo, float u_comp, flo
             *sampled = BSDF_SPECULAR | BSDF_TRANSMISSION;
             *pdf = 1.0f - chance;
             return mat_color2(m) * refract;
+        }
+        case GBL_MAT_SUBSURFACE: {   // :728-745 with type == BSDFAll == getType(): the Fresnel mirror lobe, pdf 1
+            *wi = V3(0, 0, 0);
+            Col f = Col(m.color3[0], m.color3[1], m.color3[2]) * specular_reflect_dielectric(n, wo, wi, 1.0f, m.index);
+            *pdf = 1.0f;
+            *sampled = BSDF_ALL;
+            return f;
         }
         default: {   // mirror, :709-726
             *wi = V3(0, 0, 0);
@@ -1741,6 +1754,9 @@ struct Quota {
     std::vector<uint32_t> n1, n2;
     std::vector<uint32_t> off1, off2;   // float offsets into the record (after the 4 header floats)
     uint32_t size = 0;
+    // native sampler only: 1D / 2D patterns from these indices on get their strata shuffled per camera sample
+    // (the path tracer's BSSRDF block, whose n > 1 patterns are consumed slot by slot together)
+    uint32_t perm1_from = 0xffffffffu, perm2_from = 0xffffffffu;
     uint32_t one_d(uint32_t n) {   // SampleQuota::requestOneDQuota, :23-27
         n1.push_back(round_to_square(n));
         return static_cast<uint32_t>(n1.size() - 1);
@@ -1768,6 +1784,8 @@ struct Quota {
 
 struct PtIndices {   // PathTracer::querySampleQuota, GoblinPathtracer.cpp:181-208
     std::vector<uint32_t> light1, light2, bsdf1, bsdf2, pick;
+    // BSSRDFSampleIndex (GoblinLight.cpp:35-43): pattern indices and samplesNum
+    uint32_t sss_ls1 = 0, sss_ls2 = 0, sss_pick = 0, sss_axis = 0, sss_disc = 0, sss_single = 0, sss_n = 0;
 };
 
 Quota pt_quota(const gbl_render_setting& rs, PtIndices* ix) {
@@ -1783,13 +1801,20 @@ Quota pt_quota(const gbl_render_setting& rs, PtIndices* ix) {
             ix->pick.push_back(pk);
         }
     }
+    q.perm1_from = static_cast<uint32_t>(q.n1.size());
+    q.perm2_from = static_cast<uint32_t>(q.n2.size());
     // BSSRDFSampleIndex, GoblinLight.cpp:35-43
     int n = rs.bssrdf_sample_num;
-    q.one_d(n); q.two_d(n);   // lsIndex
-    q.one_d(n);               // pickLight
-    q.one_d(n);               // pickAxis
-    q.two_d(n);               // disc
-    q.one_d(n);               // singleScatter
+    uint32_t s_ls1 = q.one_d(n), s_ls2 = q.two_d(n);   // lsIndex
+    uint32_t s_pick = q.one_d(n);                      // pickLight
+    uint32_t s_axis = q.one_d(n);                      // pickAxis
+    uint32_t s_disc = q.two_d(n);                      // disc
+    uint32_t s_single = q.one_d(n);                    // singleScatter
+    if (ix) {
+        ix->sss_ls1 = s_ls1; ix->sss_ls2 = s_ls2; ix->sss_pick = s_pick; ix->sss_axis = s_axis; ix->sss_disc = s_disc;
+        ix->sss_single = s_single;
+        ix->sss_n = std::min(q.n1[s_ls1], q.n2[s_ls2]);   // LightSampleIndex::samplesNum, GoblinLight.cpp:16
+    }
     q.finish();
     return q;
 }
@@ -1995,13 +2020,268 @@ inline Col eval_attenuation(LiCtx* c, const Ray& ray) {
         if (!scene_intersect(s, cur, &hit, &c->cnt, FILTER_MASK)) break;
         compute_uv_differential(&hit.frag, nullptr);
         ResolvedMat rm = resolve_hit_material(s, s->instances[hit.instance].material, hit.frag);
-        // sampleBSDF(..., BSDFnullptr): sampleAlpha only -> (1 - alpha) * transparentColor (:784-791)
-        throughput *= (1.0f - rm.alpha) * rm.tcolor;
+        // sampleBSDF(..., BSDFnullptr): sampleAlpha only -> (1 - alpha) * transparentColor (:784-791).  A subsurface
+        // material does not match the request (matchType(BSDFnullptr, BSDFAll) fails, :733-736) and returns Black.
+        if (rm.m.type == GBL_MAT_SUBSURFACE && !rm.is_mask) throughput *= BLACK;
+        else throughput *= (1.0f - rm.alpha) * rm.tcolor;
         if (throughput == BLACK) break;
         cur.mint = cur.maxt + hit.epsilon;
         cur.maxt = maxt;
     }
     return throughput;
+}
+
+
+// ---------------------------------------------------------------------------
+// BSSRDF (GoblinMaterial.cpp:32-220, GoblinMaterial.h:61-116) and
+// Renderer::Lsubsurface (GoblinRenderer.cpp:128-296).  The textures of a
+// subsurface material are looked up per fragment: color = absorb (sigma_a),
+// color2 = scatterPrime (sigma_s'), index = eta, k = g.
+// ---------------------------------------------------------------------------
+inline Col operator-(Col a, Col b) { return Col(a.r - b.r, a.g - b.g, a.b - b.b, a.a); }
+inline Col operator-(Col a) { return Col(-a.r, -a.g, -a.b, a.a); }
+inline Col operator/(Col a, Col b) { return Col(a.r / b.r, a.g / b.g, a.b / b.b, a.a); }
+inline Col sqrt_color(Col c) { return Col(std::sqrt(c.r), std::sqrt(c.g), std::sqrt(c.b)); }
+inline Col exp_color(Col c) { return Col(std::exp(c.r), std::exp(c.g), std::exp(c.b)); }
+inline Col clamp_color(Col c) { return Col(clampf(c.r, 0.0f, INF), clampf(c.g, 0.0f, INF), clampf(c.b, 0.0f, INF)); }
+
+inline float bssrdf_fdr(float eta) {   // BSSRDF::Fdr, GoblinMaterial.h:94-105
+    if (eta < 1.0f) return -0.4399f + 0.7099f / eta - 0.3319f / (eta * eta) + 0.0636f / (eta * eta * eta);
+    return -1.4399f / (eta * eta) + 0.7099f / eta + 0.6681f + 0.0636f * eta;
+}
+inline float bssrdf_A(const gbl_material& m) {   // BSSRDF ctor, :35-36
+    float fdr = bssrdf_fdr(m.index);
+    return (1.0f + fdr) / (1.0f - fdr);
+}
+// `m` below is the material resolved at the fragment in question
+inline Col bssrdf_scatter(const gbl_material& m) { return mat_color2(m) / (1.0f - m.k); }           // getScatter, GoblinMaterial.h:111-114
+inline Col bssrdf_attenuation(const gbl_material& m) { return bssrdf_scatter(m) + mat_color(m); }   // getAttenuation, :107-109
+inline Col bssrdf_sigma_tr(const gbl_material& m) {                                                 // getSigmaTr, GoblinMaterial.cpp:166-171
+    Col sigma_a = mat_color(m), sigma_sp = mat_color2(m);
+    Col sigma_tp = sigma_a + sigma_sp;
+    return sqrt_color(3.0f * sigma_a * sigma_tp);
+}
+inline float phase_hg(V3 wi, V3 wo, float g) {   // GoblinVolume.h:126-134
+    if (g < 1e-3) return 0.25f * INV_PI;
+    float cos_theta = dot(wi, wo);
+    return 0.25f * INV_PI * (1.0f - g * g) / powf(1.0f + g * g - 2.0f * g * cos_theta, 1.5f);
+}
+inline V3 refract_dir(V3 wo, V3 n, float etai, float etat) {   // Goblin::specularRefract(wo, n, etai, etat), GoblinMaterial.cpp:418-434
+    float eta = etai / etat;
+    float cosi = absdot(n, wo);
+    return normalize(n * (eta * cosi - std::sqrt(std::max(0.0f, 1.0f - eta * eta * (1.0f - cosi * cosi)))) - eta * wo);
+}
+Col bssrdf_rd(const gbl_material& m, float A, float d2) {   // BSSRDF::Rd, :60-81
+    Col sigma_a = mat_color(m), sigma_sp = mat_color2(m);
+    Col sigma_tp = sigma_a + sigma_sp;
+    Col sigma_tr = sqrt_color(3.0f * sigma_a * sigma_tp);
+    Col one(1.0f);
+    Col zr = one / sigma_tp;
+    Col zv = zr * (1.0f + 4.0f / 3.0f * A);
+    Col dr = sqrt_color(zr * zr + Col(d2));
+    Col dv = sqrt_color(zv * zv + Col(d2));
+    Col alpha_p = sigma_sp / sigma_tp;
+    Col s_dr = sigma_tr * dr;
+    Col s_dv = sigma_tr * dv;
+    Col rd = 0.25f * INV_PI * alpha_p * ((zr * (one + s_dr) * exp_color(-s_dr) / (dr * dr * dr)) + (zv * (one + s_dv) * exp_color(-s_dv) / (dv * dv * dv)));
+    return clamp_color(rd);
+}
+inline float gaussian_pdf_2d(float x, float y, float falloff, float rmax) {   // GoblinSampler.h:194-204
+    return (INV_PI * falloff * std::exp(-falloff * (x * x + y * y))) / (1.0f - std::exp(-falloff * rmax * rmax));
+}
+inline float gaussian_pdf_proj(V3 center, V3 sample, V3 N, float falloff, float rmax) {   // GoblinSampler.cpp:645-657
+    V3 d = sample - center;
+    V3 projected = d - N * dot(d, N);
+    return (INV_PI * falloff * std::exp(-falloff * sqlen(projected))) / (1.0f - std::exp(-falloff * rmax * rmax));
+}
+enum { SSS_U_AXIS = 0, SSS_V_AXIS = 1, SSS_N_AXIS = 2 };
+float bssrdf_mis_weight(const Frag& fo, const Frag& fi, int axis, float pdf, float sigma_tr, float rmax) {   // BSSRDF::MISWeight, :83-127
+    float weight = 0.0f;
+    V3 pwo = fo.p, pwi = fi.p, ni = fi.n;
+    if (axis == SSS_N_AXIS) {
+        V3 u = normalize(fo.dpdu), v = normalize(fo.dpdv);
+        float u_pdf = 0.25f * gaussian_pdf_proj(pwo, pwi, u, sigma_tr, rmax) * absdot(u, ni);
+        float v_pdf = 0.25f * gaussian_pdf_proj(pwo, pwi, v, sigma_tr, rmax) * absdot(v, ni);
+        float num = 4 * pdf * pdf;
+        weight = num / (num + u_pdf * u_pdf + v_pdf * v_pdf);
+    } else if (axis == SSS_U_AXIS) {
+        V3 n = fo.n, v = normalize(fo.dpdv);
+        float n_pdf = 0.5f * gaussian_pdf_proj(pwo, pwi, n, sigma_tr, rmax) * absdot(n, ni);
+        float v_pdf = 0.25f * gaussian_pdf_proj(pwo, pwi, v, sigma_tr, rmax) * absdot(v, ni);
+        float num = pdf * pdf;
+        weight = num / (4 * n_pdf * n_pdf + num + v_pdf * v_pdf);
+    } else {
+        V3 n = fo.n, u = normalize(fo.dpdu);
+        float n_pdf = 0.5f * gaussian_pdf_proj(pwo, pwi, n, sigma_tr, rmax) * absdot(n, ni);
+        float u_pdf = 0.25f * gaussian_pdf_proj(pwo, pwi, u, sigma_tr, rmax) * absdot(u, ni);
+        float num = pdf * pdf;
+        weight = num / (4 * n_pdf * n_pdf + u_pdf * u_pdf + num);
+    }
+    return weight;
+}
+int bssrdf_sample_probe_ray(const Frag& frag, float u_axis, float u_disc0, float u_disc1, float sigma_tr, float rmax, Ray* probe,
+                            float* pdf) {   // BSSRDF::sampleProbeRay, :129-164
+    Frame fr = shade_frame(frag);
+    V3 pwo = frag.p;
+    // gaussianSample2D(u1, u2, falloff, Rmax), GoblinSampler.cpp:638-643
+    float r = sqrtf(std::log(1.0f - u_disc0 * (1.0f - std::exp(-sigma_tr * rmax * rmax))) / -sigma_tr);
+    float theta = TWO_PI * u_disc1;
+    float sx = r * std::cos(theta), sy = r * std::sin(theta);
+    float half_len = std::sqrt(rmax * rmax - (sx * sx + sy * sy));
+    int axis;
+    if (u_axis <= 0.5f) {
+        probe->o = pwo + shade_to_world(fr, V3(sx, sy, -half_len));
+        probe->d = frag.n;
+        axis = SSS_N_AXIS;
+        *pdf = 0.5f;
+    } else if (u_axis <= 0.75f) {
+        probe->o = pwo + shade_to_world(fr, V3(-half_len, sx, sy));
+        probe->d = normalize(frag.dpdu);
+        axis = SSS_U_AXIS;
+        *pdf = 0.25f;
+    } else {
+        probe->o = pwo + shade_to_world(fr, V3(sy, -half_len, sx));
+        probe->d = normalize(frag.dpdv);
+        axis = SSS_V_AXIS;
+        *pdf = 0.25f;
+    }
+    probe->mint = 0.0f;
+    probe->maxt = 2.0f * half_len;
+    *pdf *= gaussian_pdf_2d(sx, sy, sigma_tr, rmax);
+    return axis;
+}
+
+struct SssSample {   // BSSRDFSample(sample, index, n), GoblinLight.cpp:53-61
+    float ls_comp, ls_geo[2], pick_light, pick_axis, disc[2], single;
+};
+inline SssSample sss_sample(const LiCtx* c, const float* rec, uint32_t i) {
+    const Quota& q = *c->q;
+    const PtIndices& ix = *c->ix;
+    SssSample s;
+    s.ls_comp = rec[q.off1[ix.sss_ls1] + i];
+    s.ls_geo[0] = rec[q.off2[ix.sss_ls2] + 2 * i];
+    s.ls_geo[1] = rec[q.off2[ix.sss_ls2] + 2 * i + 1];
+    s.pick_light = rec[q.off1[ix.sss_pick] + i];
+    s.pick_axis = rec[q.off1[ix.sss_axis] + i];
+    s.disc[0] = rec[q.off2[ix.sss_disc] + 2 * i];
+    s.disc[1] = rec[q.off2[ix.sss_disc] + 2 * i + 1];
+    s.single = rec[q.off1[ix.sss_single] + i];
+    return s;
+}
+
+// Renderer::LbssrdfSingle, GoblinRenderer.cpp:128-204
+Col l_bssrdf_single(LiCtx* c, const Frag& frag, uint32_t material, V3 wo, const float* rec) {
+    const orc_scene* s = c->s;
+    const gbl_material mo = resolve_material(s, s->materials[material], frag);
+    V3 pwo = frag.p, no = frag.n;
+    float coso = absdot(wo, frag.n);
+    float eta = mo.index;
+    float Ft = 1.0f - fresnel_dielectric(coso, 1.0f, eta);
+    Col scatter = bssrdf_scatter(mo);
+    Col sigma_t = bssrdf_attenuation(mo);
+    float falloff = luminance(sigma_t);
+    V3 wo_refract = refract_dir(wo, no, 1.0f, eta);
+    Col Ls(0.0f);
+    for (uint32_t i = 0; i < c->ix->sss_n; ++i) {
+        const SssSample bs = sss_sample(c, rec, i);
+        c->dims_used += 8;
+        float d = -std::log(bs.single) / falloff;           // exponentialSample, GoblinSampler.h:219-221
+        V3 p_sample = pwo + d * wo_refract;
+        float sample_pdf = falloff * std::exp(-falloff * d);   // exponentialPdf, :223-225
+        float pick_pdf;
+        int light = s->light_power.sample_discrete(bs.pick_light, &pick_pdf);
+        V3 wi;
+        float light_pdf_v;
+        Ray shadow;
+        Col L = light_sample(s, light, p_sample, 1e-5f, bs.ls_comp, bs.ls_geo[0], bs.ls_geo[1], &wi, &light_pdf_v, &shadow);
+        if (L == BLACK || light_pdf_v == 0.0f) continue;
+        float maxt = shadow.maxt;
+        Hit wh;
+        wh.frag.n = V3(0, 0, 0);
+        wh.frag.dpdv = V3(0, 0, 0);
+        if (scene_intersect(s, shadow, &wh, &c->cnt)) {
+            if (s->instances[wh.instance].material == material) {   // getBSSRDF() == bssrdf: the same material object
+                const Frag& fwi = wh.frag;
+                V3 pwi = fwi.p, ni = fwi.n;
+                shadow.mint = shadow.maxt + wh.epsilon;
+                shadow.maxt = maxt;
+                if (!scene_occluded(s, shadow, &c->cnt)) {
+                    const gbl_material mi = resolve_material(s, s->materials[material], fwi);
+                    float ph = phase_hg(wi, wo_refract, mo.k);
+                    float cosi = absdot(ni, wi);
+                    float Fti = 1.0f - fresnel_dielectric(cosi, 1.0f, eta);
+                    Col sigma_ti = bssrdf_attenuation(mi);
+                    float G = absdot(ni, wo_refract) / cosi;
+                    Col sigma_tc = sigma_t + G * sigma_ti;
+                    float di = length(pwi - p_sample);
+                    float et = 1.0f / eta;
+                    float di_prime = di * absdot(wi, ni) / std::sqrt(1.0f - et * et * (1.0f - cosi * cosi));
+                    Ls += (Ft * Fti * ph * scatter / sigma_tc) * exp_color(-di_prime * sigma_ti) * exp_color(-d * sigma_t) * L /
+                          (light_pdf_v * pick_pdf * sample_pdf);
+                }
+            }
+        }
+    }
+    Ls = Ls / static_cast<float>(c->ix->sss_n);
+    return Ls;
+}
+
+// Renderer::LbssrdfDiffusion, GoblinRenderer.cpp:206-274
+Col l_bssrdf_diffusion(LiCtx* c, const Frag& frag, uint32_t material, V3 wo, const float* rec) {
+    const orc_scene* s = c->s;
+    const gbl_material mo = resolve_material(s, s->materials[material], frag);
+    const float A = bssrdf_A(mo);
+    V3 pwo = frag.p;
+    float coso = absdot(wo, frag.n);
+    float eta = mo.index;
+    float Ft = 1.0f - fresnel_dielectric(coso, 1.0f, eta);
+    float sigma_tr = luminance(bssrdf_sigma_tr(mo));
+    float skip_ratio = 0.01f;
+    float rmax = std::sqrt(std::log(skip_ratio) / -sigma_tr);
+    Col Lm(0.0f);
+    for (uint32_t i = 0; i < c->ix->sss_n; ++i) {
+        const SssSample bs = sss_sample(c, rec, i);
+        Ray probe;
+        float disc_pdf;
+        int axis = bssrdf_sample_probe_ray(frag, bs.pick_axis, bs.disc[0], bs.disc[1], sigma_tr, rmax, &probe, &disc_pdf);
+        Hit ph;
+        ph.frag.n = V3(0, 0, 0);
+        ph.frag.dpdv = V3(0, 0, 0);
+        if (scene_intersect(s, probe, &ph, &c->cnt)) {
+            if (s->instances[ph.instance].material == material) {
+                const Frag& pf = ph.frag;
+                V3 p_probe = pf.p;
+                const gbl_material mp = resolve_material(s, s->materials[material], pf);
+                Col Rd = bssrdf_rd(mp, A, sqlen(p_probe - pwo));
+                float pick_pdf;
+                int light = s->light_power.sample_discrete(bs.pick_light, &pick_pdf);
+                V3 wi;
+                float light_pdf_v;
+                Ray shadow;
+                V3 ni = pf.n;
+                Col L = light_sample(s, light, p_probe, ph.epsilon, bs.ls_comp, bs.ls_geo[0], bs.ls_geo[1], &wi, &light_pdf_v, &shadow);
+                if (L == BLACK || light_pdf_v == 0.0f || scene_occluded(s, shadow, &c->cnt)) continue;
+                float cosi = absdot(ni, wi);
+                Col irradiance = L * cosi / (light_pdf_v * pick_pdf);
+                float Fti = 1.0f - fresnel_dielectric(cosi, 1.0f, eta);
+                float pdf = disc_pdf * absdot(probe.d, ni);
+                float w = bssrdf_mis_weight(frag, pf, axis, pdf, sigma_tr, rmax);
+                Lm += (w * INV_PI * Ft * Fti * Rd * irradiance) / pdf;
+            }
+        }
+    }
+    Lm = Lm / static_cast<float>(c->ix->sss_n);
+    return Lm;
+}
+
+// Renderer::Lsubsurface, GoblinRenderer.cpp:276-296
+Col l_subsurface(LiCtx* c, const Hit& hit, V3 wo, const float* rec) {
+    const orc_scene* s = c->s;
+    const uint32_t material = s->instances[hit.instance].material;
+    if (s->materials[material].type != GBL_MAT_SUBSURFACE || s->lights.empty()) return Col(0.0f);
+    Col single = l_bssrdf_single(c, hit.frag, material, wo, rec);
+    Col multi = l_bssrdf_diffusion(c, hit.frag, material, wo, rec);
+    return single + multi;
 }
 
 // PathTracer::Li, GoblinPathtracer.cpp:50-179
@@ -2015,7 +2295,7 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
     hit.frag.dpdv = V3(0, 0, 0);
     if (!scene_intersect(s, ray, &hit, &c->cnt)) return Li;   // no IBL lights on this path: evalEnvironmentLight = 0
     Li += hit_Le(s, hit, -ray.d);
-    // Lsubsurface: 0 without a BSSRDF (GoblinRenderer.cpp:282-286)
+    Li += l_subsurface(c, hit, -ray.d, rec);   // :69 -- before computeUVDifferential, so its lookups see zero differentials
     Ray cur = ray;
     Col throughput(1.0f);
     float epsilon = hit.epsilon;
@@ -2253,10 +2533,23 @@ struct NativeSampler {
         rec[1] = py + im[1];
         rec[2] = ln[0];
         rec[3] = ln[1];
+        // slot j of an n-strata pattern holds stratum j, or -- where the slots of several patterns are consumed together
+        // (Quota::perm*_from) -- stratum perm(j) under a per-sample keyed bijection, the stand-in for the reference's
+        // in-pattern shuffle (GoblinSampler.cpp:171-196); without it slot j of every pattern would share stratum j
         for (size_t i = 0; i < q.n1.size(); ++i)
-            for (uint32_t j = 0; j < q.n1[i]; ++j) rec[q.off1[i] + j] = one_d(pixel, static_cast<uint32_t>(i), q.n1[i], j, k);
+            for (uint32_t j = 0; j < q.n1[i]; ++j) {
+                uint32_t st = j;
+                if (i >= q.perm1_from && q.n1[i] > 1)
+                    st = nat_permute(j, q.n1[i], nat_mix(key(pixel, 2 + static_cast<uint32_t>(i), 0x5bd1e995u), k));
+                rec[q.off1[i] + j] = one_d(pixel, static_cast<uint32_t>(i), q.n1[i], st, k);
+            }
         for (size_t i = 0; i < q.n2.size(); ++i)
-            for (uint32_t j = 0; j < q.n2[i]; ++j) two_d(pixel, 0x10000u + static_cast<uint32_t>(i), q.n2[i], j, k, true, rec + q.off2[i] + 2 * j);
+            for (uint32_t j = 0; j < q.n2[i]; ++j) {
+                uint32_t st = j;
+                if (i >= q.perm2_from && q.n2[i] > 1)
+                    st = nat_permute(j, q.n2[i], nat_mix(key(pixel, 0x10000u + static_cast<uint32_t>(i), 0x5bd1e995u), k));
+                two_d(pixel, 0x10000u + static_cast<uint32_t>(i), q.n2[i], st, k, true, rec + q.off2[i] + 2 * j);
+            }
     }
 };
 

@@ -63,6 +63,10 @@ CASES = {
     "textured_ortho": ("textured", ov((48, 48), 4, 4, camera={"type": "orthographic", "film_width": 6.0}), 1024, False),
     # mask materials: BSDFnullptr punch-through, isOpaque-filtered shadow / MIS queries, evalAttenuation walks
     "masked_pt": ("masked", ov((64, 64), 9, 6), 2048, False),
+    # subsurface materials -- Lsubsurface at the camera hit (single scattering + dipole diffusion), the
+    # Fresnel mirror lobe of SubsurfaceMaterial, and its BSDFAll type under the isOpaque / notOpaque filters
+    "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
+    "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }
 
 

@@ -74,7 +74,8 @@ def fake_window(full, n_pixels):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box",
-                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt"])
+                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
+                                  "subsurface_pt", "subsurface_n9"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -102,7 +103,8 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
-                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt"])
+                                  "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
+                                  "subsurface_pt"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -134,6 +136,9 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     ("shapes", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("textured", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("masked", gs.config_overrides(resolution=(40, 40), spp=9, depth=6)),
+    ("subsurface", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
+    ("subsurface", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
+                        render_setting=dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4)["render_setting"], bssrdf_sample_num=7))),
     ("shapes", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
                     camera={"film": {"resolution": [32, 32]}, "lens_radius": 0.1, "focal_distance": 4.6})),
 ])
@@ -411,8 +416,9 @@ def test_russian_roulette_extension(torch):
     assert abs(ma - mf) <= 0.03 * mf
 
 
-def test_masks_under_both_schedules_are_bit_identical(torch):
-    scene = gs.load_scene("masked", gs.config_overrides(resolution=(48, 48), spp=9, depth=6))
+@pytest.mark.parametrize("name", ["masked", "subsurface"])
+def test_masks_under_both_schedules_are_bit_identical(torch, name):
+    scene = gs.load_scene(name, gs.config_overrides(resolution=(48, 48), spp=9, depth=6))
     from goblin_amd.renderer import HipPathTracer
     r = HipPathTracer(scene, 0)
     a = r.render(seed=3, want_li=True, schedule="megakernel")["li"]

@@ -74,7 +74,6 @@ def test_out_of_scope_features_fail_loudly():
     cases = [
         minimal(volume={"type": "homogeneous"}),
         minimal(lights=[{"type": "ibl", "name": "e", "file": "x.exr"}]),
-        minimal(materials=[{"name": "m", "type": "subsurface"}]),
         minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
         minimal(textures=[{"name": "w", "type": "image", "file": "x.png"}]),
     ]
@@ -170,6 +169,39 @@ def test_mask_material():
     with pytest.raises(_abi.GoblinError) as e:                          # mask of a mask
         load(minimal(materials=[mats[0], {"name": "m1", "type": "mask", "material": "inner"},
                                 {"name": "m", "type": "mask", "material": "m1"}], textures=tex))
+    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+
+
+def test_subsurface_material():
+    """createSubsurfaceMaterial (GoblinMaterial.cpp:881-927): marble coefficients, index 1.5, g 0 and a white Kr by
+    default; the Kd + mean_free_path form goes through BSSRDF::convertFromDiffuse on the host."""
+    s = load(minimal(materials=[{"name": "m", "type": "subsurface"}]))
+    m = s.desc.materials[s.desc.instances[0].material]
+    assert m.type == _abi.GBL_MAT_SUBSURFACE and (m.index, m.k) == (1.5, 0.0)
+    np.testing.assert_allclose(list(m.color), [0.0021, 0.0041, 0.0071], rtol=1e-6)
+    np.testing.assert_allclose(list(m.color2), [2.19, 2.62, 3.00], rtol=1e-6)
+    assert list(m.color3) == [1, 1, 1] and (m.tex_color, m.tex_color2, m.tex_color3) == (-1, -1, -1)
+    tex = [{"name": "w", "type": "constant", "color": [0.5, 0.6, 0.7]},
+           {"name": "c", "type": "checkerboard", "texture1": "w", "texture2": "w"}]
+    s = load(minimal(materials=[{"name": "m", "type": "subsurface", "absorb": "w", "scatter_prime": "c", "Kr": "w", "index": 1.3, "g": 0.25}],
+                     textures=tex))
+    m = s.desc.materials[s.desc.instances[0].material]
+    np.testing.assert_allclose(list(m.color), [0.5, 0.6, 0.7], rtol=1e-6)
+    np.testing.assert_allclose(list(m.color3), [0.5, 0.6, 0.7], rtol=1e-6)
+    assert m.tex_color == -1 and m.tex_color2 >= 0 and (np.float32(m.index), np.float32(m.k)) == (np.float32(1.3), np.float32(0.25))
+    # diffuse form: sigma_tr = 1 / mean free path and the dipole's total diffuse reflectance reproduces Kd
+    s = load(minimal(materials=[{"name": "m", "type": "subsurface", "Kd": [0.8, 0.5, 0.3], "mean_free_path": [0.5, 0.25, 0.125]}]))
+    m = s.desc.materials[s.desc.instances[0].material]
+    sa, ssp = np.array(list(m.color), np.float64), np.array(list(m.color2), np.float64)
+    np.testing.assert_allclose(np.sqrt(3 * sa * (sa + ssp)), [2.0, 4.0, 8.0], rtol=1e-4)
+    eta = 1.5
+    fdr = -1.4399 / eta ** 2 + 0.7099 / eta + 0.6681 + 0.0636 * eta
+    A = (1 + fdr) / (1 - fdr)
+    alpha = ssp / (sa + ssp)
+    root = np.sqrt(3 * (1 - alpha))
+    np.testing.assert_allclose(0.5 * alpha * (1 + np.exp(-4.0 / 3.0 * A * root)) * np.exp(-root), [0.8, 0.5, 0.3], atol=1e-3)   # 16 bisection steps
+    with pytest.raises(_abi.GoblinError) as e:                          # a mask around a subsurface material
+        load(minimal(materials=[{"name": "inner", "type": "subsurface"}, {"name": "m", "type": "mask", "material": "inner"}]))
     assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
 
 

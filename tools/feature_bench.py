@@ -1,4 +1,4 @@
-"""Throughput of the EXT kernels on the feature scenes (shapes / textured / masked), both schedules where available."""
+"""Throughput of the EXT kernels on the feature scenes (shapes / textured / masked / subsurface), both schedules where available."""
 import sys, os, json
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -6,7 +6,7 @@ import torch
 from goblin_amd import _abi
 from goblin_amd import scene as gs
 from goblin_amd.renderer import HipPathTracer
-for name in ("shapes", "textured", "masked"):
+for name in ("shapes", "textured", "masked", "subsurface"):
     scene = gs.load_scene(name, gs.config_overrides(resolution=(512, 512), spp=64))
     tr = HipPathTracer(scene, 0)
     film = tr.new_film()
