@@ -76,6 +76,18 @@ def random_scene(seed):
     if use_mask:
         mats.append({"name": "m4", "type": "mask", "material": str(rng.choice(["m0", "m1", "m2", "m3"])),
                      "alpha": str(rng.choice(["f1", "cut"])), "transparent_color": "c2"})
+    rng2 = np.random.default_rng(seed + 7919)   # its own stream: the scenes of earlier seeds keep their other draws
+    use_sss = bool(rng2.integers(2))
+    if use_sss:
+        V = lambda a, b: float(rng2.uniform(a, b))
+        if rng2.integers(2):
+            mats.append({"name": "m5", "type": "subsurface", "Kd": [V(.3, .9), V(.3, .9), V(.3, .9)],
+                         "mean_free_path": [V(.05, .3), V(.05, .3), V(.05, .3)], "index": V(1.2, 1.6)})
+        else:
+            tex.append({"format": "color", "name": "sa", "type": "constant", "color": [V(.5, 3), V(.5, 3), V(.5, 3)]})
+            tex.append({"format": "color", "name": "ss", "type": "constant", "color": [V(40, 120), V(40, 120), V(40, 120)]})
+            mats.append({"name": "m5", "type": "subsurface", "absorb": "sa", "scatter_prime": str(rng2.choice(["ss", "chk"])),
+                         "Kr": "c2", "index": V(1.2, 1.6), "g": V(0.0, 0.6)})
     geoms = [
         {"name": "quad", "type": "mesh", "file": "models/plane.obj"},
         {"name": "cube", "type": "mesh", "file": "models/cube.obj"},
@@ -117,8 +129,9 @@ def random_scene(seed):
         cam.update({"type": "orthographic", "film_width": U(4, 7)})
     elif c == 2:
         cam.update({"lens_radius": U(.03, .15), "focal_distance": U(3.5, 5)})
-    doc = {"render_setting": {"render_method": "path_tracing", "sample_per_pixel": 4, "max_ray_depth": int(rng.integers(3, 9))},
+    doc = {"render_setting": {"render_method": "path_tracing", "sample_per_pixel": 4, "max_ray_depth": int(rng.integers(3, 9)),
+                              "bssrdf_sample_num": int(rng2.integers(1, 6))},
            "camera": cam, "geometries": geoms, "textures": tex, "materials": mats, "primitives": prims, "lights": lights}
-    return doc, use_mask
+    return doc, use_mask or use_sss
 
 
