@@ -21,7 +21,7 @@ GBL_SHAPE_MESH, GBL_SHAPE_SPHERE, GBL_SHAPE_DISK = 0, 1, 2
 GBL_CAMERA_PERSPECTIVE, GBL_CAMERA_ORTHOGRAPHIC = 0, 1
 GBL_FILTER_BOX, GBL_FILTER_TRIANGLE, GBL_FILTER_GAUSSIAN, GBL_FILTER_MITCHELL = range(4)
 GBL_INTEGRATOR_PATH, GBL_INTEGRATOR_AO = 0, 1
-GBL_SAMPLES_NATIVE, GBL_SAMPLES_REPLAY = 0, 1
+GBL_SAMPLES_NATIVE, GBL_SAMPLES_REPLAY, GBL_SAMPLES_STREAM = 0, 1, 2
 GBL_SCHEDULE_AUTO, GBL_SCHEDULE_MEGAKERNEL, GBL_SCHEDULE_WAVEFRONT = 0, 1, 2
 
 

@@ -188,6 +188,13 @@ struct RenderArgs {
     int32_t bssrdf_n;           // BSSRDFSampleIndex::samplesNum: roundToSquare(bssrdf_sample_num)
     int32_t bssrdf_n2;          // size of its 2D patterns (rounded to a square once more)
     const float* sss;           // per-sample Lsubsurface of this render (float4, pixel-major like li_out), or null
+    // GBL_SAMPLES_STREAM (kernels/stream.h)
+    const uint32_t* tile_seeds; // the reference's per-tile mt19937 seeds, row-major over the FULL sample window's tiles
+    uint32_t* stream_scratch;   // stream_stride words per workgroup
+    uint64_t stream_stride;
+    int32_t full_tiles_x;
+    int32_t pad_stream;
+    float* image_xy;            // per camera sample (indexed like li_out): the image position its record held, for the splat
     const float* replay;        // Sample records for the sub-window, pixel-major
     float* li_out;
     float* li_defer;            // when set, the render kernel stores per-sample radiance here (pixel-major)

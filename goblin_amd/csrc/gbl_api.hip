@@ -51,6 +51,11 @@ struct gbl_ctx {
     float4* wf_li = nullptr;
     size_t wf_li_entries = 0;
     uint64_t li_budget = 0;   // li_budget_bytes()
+    uint32_t* stream_seeds = nullptr;     // GBL_SAMPLES_STREAM: per-tile mt19937 seeds of the full sample window
+    uint32_t* stream_scratch = nullptr;   // ... and the workgroups' sample-generation scratch
+    uint64_t stream_scratch_bytes = 0;
+    float* stream_xy = nullptr;           // ... and the image position of every camera sample of the call (for the splat)
+    uint64_t stream_xy_bytes = 0;
     float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
     uint64_t sss_entries = 0;
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
@@ -670,6 +675,9 @@ void gbl_destroy(gbl_ctx* ctx) {
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
     if (ctx->sss_buf) (void)hipFree(ctx->sss_buf);
+    if (ctx->stream_seeds) (void)hipFree(ctx->stream_seeds);
+    if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
+    if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
     if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
     if (ctx->wf_ev_shade) (void)hipEventDestroy(ctx->wf_ev_shade);
     if (ctx->wf_ev_shadow) (void)hipEventDestroy(ctx->wf_ev_shadow);
@@ -689,6 +697,34 @@ gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out) {
     *out = ctx->info;
     return GBL_OK;
 }
+
+}   // extern "C"
+
+namespace {
+// The first n values of libc rand() in a process that never called srand() -- what the reference seeds its per-tile
+// generators with (RNGImp::RNGImp, GoblinUtils.cpp:19-20).  glibc's default is the TYPE_3 additive feedback generator
+// over 31 words, r[i] = r[i-3] + r[i-31], seeded with 1 through the Park-Miller step and run 310 times before the
+// first output, which drops the low bit.
+std::vector<uint32_t> glibc_rand_sequence(size_t n) {
+    std::vector<uint32_t> st(344 + n);
+    int32_t r = 1;
+    st[0] = 1u;
+    for (int i = 1; i < 31; ++i) {
+        const int64_t hi = r / 127773, lo = r % 127773;
+        int64_t w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        r = static_cast<int32_t>(w);
+        st[i] = static_cast<uint32_t>(r);
+    }
+    for (int i = 31; i < 34; ++i) st[i] = st[i - 31];
+    for (size_t i = 34; i < st.size(); ++i) st[i] = st[i - 31] + st[i - 3];
+    std::vector<uint32_t> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = st[344 + i] >> 1;
+    return out;
+}
+}   // namespace
+
+extern "C" {
 
 gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accum, gbl_stats* stats) {
     if (!ctx) return GBL_ERR_INVALID;
@@ -738,7 +774,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ctx->error = "replay mode needs replay_samples";
         return GBL_ERR_INVALID;
     }
-    if (p->sample_mode != GBL_SAMPLES_REPLAY && p->sample_mode != GBL_SAMPLES_NATIVE) {
+    if (p->sample_mode != GBL_SAMPLES_REPLAY && p->sample_mode != GBL_SAMPLES_NATIVE && p->sample_mode != GBL_SAMPLES_STREAM) {
         ctx->error = "unknown sample_mode";
         return GBL_ERR_INVALID;
     }
@@ -766,6 +802,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     const uint64_t want_items = 16ull * ctx->num_cus * 4;
     while (static_cast<uint64_t>(ra.local_tiles) * chunks < want_items && ra.spp / chunks > 4 && ra.spp % (chunks * 2) == 0)
         chunks *= 2;
+    const bool stream_mode = p->sample_mode == GBL_SAMPLES_STREAM;
+    if (stream_mode) chunks = 1;   // a work item is a whole tile, walked pixel by pixel (kernels/stream.h)
     ra.chunks = chunks;
     ra.chunk_spp = ra.spp / chunks;
     ra.seed_key = host_mix(static_cast<uint32_t>(p->seed), static_cast<uint32_t>(p->seed >> 32));
@@ -793,14 +831,45 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ctx->error = "scene needs " + std::to_string(lds) + " bytes of LDS per workgroup (BVH too deep)";
         return GBL_ERR_UNSUPPORTED;
     }
-    const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY;
+    const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY || stream_mode;
+    if (stream_mode) {
+        if (p->integrator != GBL_INTEGRATOR_PATH || p->schedule == GBL_SCHEDULE_WAVEFRONT) {
+            ctx->error = "GBL_SAMPLES_STREAM covers the path tracer on the megakernel schedule";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        if (sc.has_bssrdf != 0) {
+            ctx->error = "GBL_SAMPLES_STREAM does not cover scenes with subsurface materials";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        // the tiles rendered must be tiles of the reference's own tiling of the full sample window
+        if ((ra.window[0] - full[0]) % GBL_TILE != 0 || (ra.window[2] - full[2]) % GBL_TILE != 0 ||
+            (ra.window[1] != full[1] && (ra.window[1] - full[0]) % GBL_TILE != 0) ||
+            (ra.window[3] != full[3] && (ra.window[3] - full[2]) % GBL_TILE != 0)) {
+            ctx->error = "GBL_SAMPLES_STREAM: the window must consist of whole 8x8 tiles of the full sample window";
+            return GBL_ERR_INVALID;
+        }
+        const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
+        if (static_cast<uint64_t>(sc.stack_entries) * GBL_BLOCK < L.S) {
+            ctx->error = "GBL_SAMPLES_STREAM: sample_per_pixel too large for the shuffle scratch";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        lds += GBL_STREAM_LDS_WORDS * sizeof(uint32_t);
+        const int ftx = (full[1] - full[0] + GBL_TILE - 1) / GBL_TILE, fty = (full[3] - full[2] + GBL_TILE - 1) / GBL_TILE;
+        ra.full_tiles_x = ftx;
+        if (!ctx->stream_seeds) {
+            const std::vector<uint32_t> seeds = glibc_rand_sequence(static_cast<size_t>(ftx) * fty);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->stream_seeds), seeds.size() * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMemcpy(ctx->stream_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        ra.tile_seeds = ctx->stream_seeds;
+    }
     // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while a path is cheap
     // (short paths through a small scene: configs 1, 2), the wavefront formulation once traversal dominates and its
     // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 4.2 s against 6.4 s) or many
     // instanced triangles (config 4, 15 bunnies: 317 ms against 438 ms).  AO always runs the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
     // filtered MIS query and the attenuation walks inline in the trace kernel: 48.6 ms against 16.1 ms on masked.json).
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
-    bool wavefront = wf_capable && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
+    bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
                                                                           ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS)));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
@@ -854,7 +923,38 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         dim3 grid(static_cast<unsigned>(grid64)), block(GBL_BLOCK);
         const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
-        if (p->integrator == GBL_INTEGRATOR_PATH) {
+        if (stream_mode) {
+            kernel = want_stats ? path_trace_kernel<true, true, true, true>
+                                : (ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>);
+            const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
+            ra.stream_stride = stream_scratch_words(L);
+            const uint64_t need = ra.stream_stride * sizeof(uint32_t) * grid64;
+            if (need > ctx->stream_scratch_bytes) {
+                if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
+                ctx->stream_scratch = nullptr;
+                ctx->stream_scratch_bytes = 0;
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_scratch), need);
+                if (e != hipSuccess) {
+                    ctx->error = std::string("hipMalloc(stream scratch): ") + hipGetErrorString(e);
+                    return GBL_ERR_OOM;
+                }
+                ctx->stream_scratch_bytes = need;
+            }
+            ra.stream_scratch = ctx->stream_scratch;
+            const uint64_t xy_bytes = npix * ra.spp * 2 * sizeof(float);
+            if (xy_bytes > ctx->stream_xy_bytes) {
+                if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
+                ctx->stream_xy = nullptr;
+                ctx->stream_xy_bytes = 0;
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_xy), xy_bytes);
+                if (e != hipSuccess) {
+                    ctx->error = std::string("hipMalloc(stream image positions): ") + hipGetErrorString(e);
+                    return GBL_ERR_OOM;
+                }
+                ctx->stream_xy_bytes = xy_bytes;
+            }
+            ra.image_xy = ctx->stream_xy;
+        } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = replay ? (want_stats ? path_trace_kernel<true, true, true> : (ext ? path_trace_kernel<true, false, true> : path_trace_kernel<true, false, false>))
                             : (want_stats ? path_trace_kernel<false, true, true> : (ext ? path_trace_kernel<false, false, true> : path_trace_kernel<false, false, false>));
         } else {
@@ -879,6 +979,10 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                 ra.li_defer = reinterpret_cast<float*>(ctx->wf_li);
                 defer = true;
             }
+        }
+        if (stream_mode && !defer) {
+            ctx->error = "GBL_SAMPLES_STREAM keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
+            return GBL_ERR_UNSUPPORTED;
         }
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
         HIP_TRY(ctx, hipGetLastError());

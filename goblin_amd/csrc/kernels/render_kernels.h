@@ -18,6 +18,7 @@
 #include "../device_scene.h"
 #include "sampler.h"
 #include "shade.h"
+#include "stream.h"
 #include "trace.h"
 #include "vecmath.h"
 
@@ -254,16 +255,31 @@ struct PathState {
     bool punch;         // EXT: the ray in flight left a mask surface through its alpha (sampledType == BSDFnullptr)
 };
 
-template <bool REPLAY, bool STATS, bool EXT>
+// STREAM (implies REPLAY): the records are the reference's own, generated per pixel from the tile's mt19937
+// (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
+#define GBL_STREAM_LDS_WORDS 640   // 624 state words + cursor, padded
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false>
 __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
-    uint32_t* stack = ctrl + 4;
+    uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
     const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+    StreamCtx scx = {};
+    StreamLayout slay = {};
+    if constexpr (STREAM) {
+        slay = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
+        scx.mt = ctrl + 4;
+        scx.pos = ctrl + 4 + GBL_MT_N;
+        scx.lperm = stack;
+        scx.lperm_words = static_cast<uint32_t>(sc.stack_entries) * GBL_BLOCK;
+        scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
+        scx.perm = scx.raw + slay.NF + slay.NU;
+        scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+    }
 
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
@@ -282,8 +298,27 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
         __syncthreads();
         const uint32_t item = ctrl[0];
         if (item >= n_items) break;
-        const ItemInfo it = decode_item(ra, item);
-        const int tx0 = it.px0 - sc.film.halo, ty0 = it.py0 - sc.film.halo;
+        const ItemInfo tile_item = decode_item(ra, item);
+        const int tx0 = tile_item.px0 - sc.film.halo, ty0 = tile_item.py0 - sc.film.halo;
+        if constexpr (STREAM) {
+            // RNGImp of this tile's RenderTask: seeded with the tile's rand() value (row-major over the FULL sample window)
+            const int ftx = (tile_item.px0 - sc.film.window[0]) / GBL_TILE, fty = (tile_item.py0 - sc.film.window[2]) / GBL_TILE;
+            mt_seed(scx, ra.tile_seeds[fty * ra.full_tiles_x + ftx]);
+        }
+        uint32_t stream_draws = 0;   // STREAM: BSDFSample(rng) floats this lane's paths discarded
+        const int n_sub = STREAM ? tile_item.tw * tile_item.th : 1;
+        for (int sub = 0; sub < n_sub; ++sub) {
+        ItemInfo it = tile_item;
+        if constexpr (STREAM) {
+            it.px0 = tile_item.px0 + sub % tile_item.tw;
+            it.py0 = tile_item.py0 + sub / tile_item.tw;
+            it.tw = it.th = 1;
+            it.paths = ra.spp;
+            stream_generate_pixel(scx, slay, it.px0, it.py0);
+            if (threadIdx.x == 0) ctrl[1] = ctrl[2] = 0u;
+            stream_draws = 0;
+            __syncthreads();
+        }
 
         PathState ps;
         bool active = false;
@@ -312,9 +347,13 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     int px = it.px0 + pix % it.tw, py = it.py0 + pix / it.tw;
                     out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
                     if (REPLAY) {
-                        src.rec = ra.replay + static_cast<size_t>(out_index) * ra.dims;
+                        src.rec = STREAM ? scx.recs + static_cast<size_t>(src.k) * ra.dims : ra.replay + static_cast<size_t>(out_index) * ra.dims;
                         image_x = src.rec[0];
                         image_y = src.rec[1];
+                        if (STREAM) {
+                            ra.image_xy[2 * static_cast<size_t>(out_index)] = image_x;
+                            ra.image_xy[2 * static_cast<size_t>(out_index) + 1] = image_y;
+                        }
                     } else {
                         uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
                         src.pixel_key = nat_mix(ra.seed_key, pixel);
@@ -495,6 +534,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     contrib = l_area ? div(l_f * tr * l_L * l_cos * l_w, l_pdf) : div(l_f * tr * l_L * l_cos, l_pdf);
                 }
                 if (!occluded) ps.Ld = f3(ps.Ld.x + contrib.x, ps.Ld.y + contrib.y, ps.Ld.z + contrib.z);
+                if (STREAM && !occluded) stream_draws += 3;   // evalAttenuation(scene, shadowRay, BSDFSample(rng)), :101-103
             }
             // ---- BSDF sample: the next ray
             if (active && !finished) {
@@ -514,6 +554,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 } else if (!is_black(f) && pdf > 0.0f) {
                     float fw = 1.0f;
                     if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
+                    if (STREAM) stream_draws += 3;   // evalAttenuation(scene, r, BSDFSample(rng)) on either branch, :150 / :159
                     ps.f = f;
                     ps.fw = fw;
                     ps.bsdf_pdf = pdf;
@@ -558,6 +599,15 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 paths_done += 1;
             }
         }
+        if constexpr (STREAM) {
+            // the stream moves past what this pixel's Li evaluations drew before the next pixel's records are taken from it
+            if (stream_draws) atomicAdd(ctrl + 2, stream_draws);
+            __syncthreads();
+            const uint32_t drawn = ctrl[2];
+            __syncthreads();
+            stream_emit(scx, nullptr, drawn);
+        }
+        }   // sub
         __syncthreads();
         if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }

@@ -1,0 +1,248 @@
+// The reference's OWN sample stream, generated on the device (sample_mode = GBL_SAMPLES_STREAM).
+//
+// RenderTask::run (GoblinRenderer.cpp:29-52) gives every 8x8 sample tile one mt19937 (RNGImp, GoblinUtils.cpp:13-56)
+// seeded with the next value of the never-seeded libc rand(), and walks the tile pixel by pixel:
+// Sampler::requestSamples (GoblinSampler.cpp:108-197) draws the pixel's S = roundToSquare(spp) Sample records from it
+// -- jittered strata, then the lens / per-column / in-pattern shuffles -- and every Li evaluation takes three more
+// floats per evalAttenuation call (BSDFSample(rng), GoblinPathtracer.cpp:103,150,159) whose VALUES are never used
+// but which move the stream.  The position of pixel p+1 in the stream therefore depends on how the paths of pixel p
+// went, so a tile is inherently sequential: one workgroup owns a tile, and per pixel
+//   1. emits the pixel's raw 32-bit draws (the twist runs over the 624-word state in LDS, four barrier phases),
+//   2. applies the reference's shuffles as position permutations (one lane per column, columns in LDS),
+//   3. assembles the S records in the reference's float layout,
+//   4. traces the S paths with the replay kernel's own code, counting the discarded draws,
+//   5. skips that many outputs.
+// Film accumulators then equal the reference's up to float summation order, at any size, with nothing uploaded.
+// Slower than the counter-based native law (the throughput mode): this is the bit-faithful one.
+//
+// Draw order per pixel (restated from requestSamples; F1 / F2 = total slots of the 1D / 2D patterns):
+//   floats  image 2S | lens 2S | 1D columns F1 x S | 2D columns F2 x 2S            = S (4 + F1 + 2 F2)
+//   uints   lens shuffle S | column shuffles (F1 + F2) x S | per sample (F1 + F2)   = S (1 + 2 F1 + 2 F2)
+// The path tracer's quota (PathTracer::querySampleQuota, GoblinPathtracer.cpp:181-208) is D x {light 1D, bsdf 1D,
+// pick 1D; light 2D, bsdf 2D} one-slot patterns followed by the BSSRDF block's 4 1D and 2 2D n-slot patterns.
+#pragma once
+#include <stdint.h>
+
+#include "../device_scene.h"
+
+#define GBL_MT_N 624
+#define GBL_MT_M 397
+
+struct StreamLayout {
+    uint32_t S, root, D, nb, nb2;   // samples per pixel and its root; bounces; BSSRDF slots (1D / 2D)
+    uint32_t F1, F2;                // total 1D / 2D slots
+    uint32_t NF, NU;                // float / uint draws per pixel
+    uint32_t ncols;                 // shuffled columns: lens, then every 1D slot, then every 2D slot
+    uint32_t dims;
+};
+__host__ __device__ inline StreamLayout stream_layout(int spp, int root, int max_depth, int nb, int nb2) {
+    StreamLayout L;
+    L.S = static_cast<uint32_t>(spp);
+    L.root = static_cast<uint32_t>(root);
+    L.D = static_cast<uint32_t>(max_depth);
+    L.nb = static_cast<uint32_t>(nb);
+    L.nb2 = static_cast<uint32_t>(nb2);
+    L.F1 = 3u * L.D + 4u * L.nb;
+    L.F2 = 2u * L.D + 2u * L.nb2;
+    L.NF = L.S * (4u + L.F1 + 2u * L.F2);
+    L.NU = L.S * (1u + 2u * L.F1 + 2u * L.F2);
+    L.ncols = 1u + L.F1 + L.F2;
+    L.dims = 4u + L.F1 + 2u * L.F2;
+    return L;
+}
+// words of global scratch one workgroup needs: raw draws, column permutations, records
+__host__ __device__ inline uint64_t stream_scratch_words(const StreamLayout& L) {
+    return static_cast<uint64_t>(L.NF) + L.NU + static_cast<uint64_t>(L.ncols) * L.S + static_cast<uint64_t>(L.S) * L.dims;
+}
+
+#ifdef __HIPCC__
+struct StreamCtx {
+    uint32_t* mt;       // LDS: GBL_MT_N state words
+    uint32_t* pos;      // LDS: next unread word of the state block (GBL_MT_N = exhausted)
+    uint32_t* lperm;    // LDS scratch for the shuffles (the traversal stacks' region, idle while samples are generated)
+    uint32_t lperm_words;
+    uint32_t* raw;      // global, this workgroup's: the pixel's NF + NU raw draws
+    uint32_t* perm;     // global: ncols x S positions
+    float* recs;        // global: S x dims floats
+};
+
+// std::mt19937(seed): the Knuth initialiser, serial over the state
+__device__ __forceinline__ void mt_seed(const StreamCtx& c, uint32_t seed) {
+    if (threadIdx.x == 0) {
+        uint32_t x = seed;
+        c.mt[0] = x;
+        for (uint32_t i = 1; i < GBL_MT_N; ++i) {
+            x = 1812433253u * (x ^ (x >> 30)) + i;
+            c.mt[i] = x;
+        }
+        *c.pos = GBL_MT_N;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t far) {
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+// One state refresh.  Word i of the new block needs old words i, i+1 and word i+M of whichever block is current
+// there: [0, N-M) reads old words only, [N-M, 2(N-M)) the first range's new words, and so on -- three barrier
+// phases of <= 227 independent words and the wrap-around word.
+__device__ __forceinline__ void mt_twist(const StreamCtx& c) {
+    const uint32_t t = threadIdx.x;
+    constexpr uint32_t R = GBL_MT_N - GBL_MT_M;   // 227
+    uint32_t v = 0;
+    if (t < R) v = mt_mix(c.mt[t], c.mt[t + 1], c.mt[t + GBL_MT_M]);
+    __syncthreads();
+    if (t < R) c.mt[t] = v;
+    __syncthreads();
+    if (t < R) v = mt_mix(c.mt[R + t], c.mt[R + t + 1], c.mt[t]);
+    __syncthreads();
+    if (t < R) c.mt[R + t] = v;
+    __syncthreads();
+    if (t < GBL_MT_N - 1 - 2 * R) v = mt_mix(c.mt[2 * R + t], c.mt[2 * R + t + 1], c.mt[R + t]);
+    __syncthreads();
+    if (t < GBL_MT_N - 1 - 2 * R) c.mt[2 * R + t] = v;
+    __syncthreads();
+    if (t == 0) {
+        c.mt[GBL_MT_N - 1] = mt_mix(c.mt[GBL_MT_N - 1], c.mt[0], c.mt[GBL_MT_M - 1]);
+        *c.pos = 0;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+// the next `count` outputs of the tile's generator, written to dst (null: skipped).  Called by the whole workgroup.
+__device__ __forceinline__ void stream_emit(const StreamCtx& c, uint32_t* dst, uint32_t count) {
+    uint32_t done = 0;
+    while (done < count) {
+        if (*c.pos == GBL_MT_N) mt_twist(c);
+        const uint32_t p = *c.pos;
+        const uint32_t n = min(GBL_MT_N - p, count - done);
+        if (dst)
+            for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) dst[done + t] = mt_temper(c.mt[p + t]);
+        __syncthreads();
+        if (threadIdx.x == 0) *c.pos = p + n;
+        __syncthreads();
+        done += n;
+    }
+}
+
+// RNGImp::randomFloat: uniform_real_distribution<float>(0, 1) over one 32-bit draw -- generate_canonical<float, 24>
+// divides the draw (rounded to float) by 2^32 and steps a result of 1.0 down to the float below it
+__device__ __forceinline__ float stream_u01(uint32_t x) {
+    float r = static_cast<float>(x) / 4294967296.0f;
+    return r >= 1.0f ? 0.99999994f : r;
+}
+
+// stratifiedUniform2D element: stratum `slot` of an n-point pattern, sub-cell p of the root x root grid (GoblinSampler.cpp:288-307)
+__device__ __forceinline__ void stream_strat2(const StreamLayout& L, uint32_t n, uint32_t slot, uint32_t p, float f0, float f1, float* x, float* y) {
+    int r = static_cast<int>(sqrtf(static_cast<float>(n)));
+    float strata = 1.0f / r;
+    float sub = strata / static_cast<int>(L.root);
+    int ux = static_cast<int>(slot) % r, uy = static_cast<int>(slot) / r;
+    int px = static_cast<int>(p % L.root), py = static_cast<int>(p / L.root);
+    float xo = px + f0, yo = py + f1;
+    *x = ux * strata + xo * sub;
+    *y = uy * strata + yo * sub;
+}
+
+// Sampler::requestSamples for the pixel (cx, cy): fills c.recs.  Called by the whole workgroup.
+__device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const StreamLayout& L, int cx, int cy) {
+    const uint32_t S = L.S;
+    stream_emit(c, c.raw, L.NF + L.NU);
+    // ---- shuffle<T>(buffer, S, dim, rng): for n in [0, S): swap(element n, element rng.randomUInt() % S)
+    // (GoblinSampler.h:149-157), tracked as the position permutation of each column
+    const uint32_t B = min(64u, c.lperm_words / S);
+    for (uint32_t c0 = 0; c0 < L.ncols; c0 += B) {
+        const uint32_t b = threadIdx.x, col = c0 + b;
+        if (b < B && col < L.ncols) {
+            for (uint32_t k = 0; k < S; ++k) c.lperm[k * B + b] = k;
+            const uint32_t* u = c.raw + L.NF + col * S;
+            for (uint32_t n0 = 0; n0 < S; n0 += 8) {
+                uint32_t o[8];
+                for (uint32_t i = 0; i < 8; ++i) o[i] = n0 + i < S ? u[n0 + i] % S : 0u;
+                for (uint32_t i = 0; i < 8 && n0 + i < S; ++i) {
+                    const uint32_t ia = (n0 + i) * B + b, ib = o[i] * B + b;
+                    const uint32_t va = c.lperm[ia], vb = c.lperm[ib];
+                    c.lperm[ia] = vb;
+                    c.lperm[ib] = va;
+                }
+            }
+            for (uint32_t k = 0; k < S; ++k) c.perm[col * S + k] = c.lperm[k * B + b];
+        }
+    }
+    __syncthreads();
+    // ---- records: sample k takes, in every column, the element its position's permutation points at
+    const uint32_t n1_single = 3u * L.D, n2_single = 2u * L.D;
+    const uint32_t* uper = c.raw + L.NF + L.ncols * S;   // in-pattern shuffle draws, F1 + F2 per sample
+    for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
+        float* rec = c.recs + static_cast<size_t>(k) * L.dims;
+        {
+            float x, y;
+            stream_strat2(L, 1u, 0u, k, stream_u01(c.raw[2 * k]), stream_u01(c.raw[2 * k + 1]), &x, &y);
+            rec[0] = cx + x;
+            rec[1] = cy + y;
+            const uint32_t p = c.perm[k];
+            stream_strat2(L, 1u, 0u, p, stream_u01(c.raw[2 * S + 2 * p]), stream_u01(c.raw[2 * S + 2 * p + 1]), &x, &y);
+            rec[2] = x;
+            rec[3] = y;
+        }
+        uint32_t col1 = 0;   // running 1D slot
+        for (uint32_t i = 0; i < n1_single + 4u; ++i) {
+            const uint32_t n = i < n1_single ? 1u : L.nb;
+            const float strata = 1.0f / static_cast<float>(n);
+            const float sub = strata / static_cast<int>(S);
+            for (uint32_t j = 0; j < n; ++j, ++col1) {
+                const uint32_t p = c.perm[(1u + col1) * S + k];
+                const float off = static_cast<int>(p) + stream_u01(c.raw[4 * S + col1 * S + p]);
+                rec[4 + col1] = j * strata + off * sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
+            }
+        }
+        uint32_t col2 = 0;   // running 2D slot
+        for (uint32_t i = 0; i < n2_single + 2u; ++i) {
+            const uint32_t n = i < n2_single ? 1u : L.nb2;
+            for (uint32_t j = 0; j < n; ++j, ++col2) {
+                const uint32_t p = c.perm[(1u + L.F1 + col2) * S + k];
+                const uint32_t e = 4 * S + L.F1 * S + 2 * (col2 * S + p);
+                float x, y;
+                stream_strat2(L, n, j, p, stream_u01(c.raw[e]), stream_u01(c.raw[e + 1]), &x, &y);
+                rec[4 + L.F1 + 2 * col2] = x;
+                rec[4 + L.F1 + 2 * col2 + 1] = y;
+            }
+        }
+        // per-sample shuffles inside each pattern (:185-196); a one-slot pattern swaps its slot with itself
+        const uint32_t* us = uper + static_cast<size_t>(k) * (L.F1 + L.F2);
+        if (L.nb > 1u) {
+            for (uint32_t i = 0; i < 4u; ++i) {
+                float* pat = rec + 4 + n1_single + i * L.nb;
+                const uint32_t* up = us + n1_single + i * L.nb;
+                for (uint32_t m = 0; m < L.nb; ++m) {
+                    const uint32_t other = up[m] % L.nb;
+                    const float tmp = pat[m];
+                    pat[m] = pat[other];
+                    pat[other] = tmp;
+                }
+            }
+        }
+        if (L.nb2 > 1u) {
+            for (uint32_t i = 0; i < 2u; ++i) {
+                float* pat = rec + 4 + L.F1 + 2 * (n2_single + i * L.nb2);
+                const uint32_t* up = us + L.F1 + n2_single + i * L.nb2;
+                for (uint32_t m = 0; m < L.nb2; ++m) {
+                    const uint32_t other = up[m] % L.nb2;
+                    const float t0 = pat[2 * m], t1 = pat[2 * m + 1];
+                    pat[2 * m] = pat[2 * other];
+                    pat[2 * m + 1] = pat[2 * other + 1];
+                    pat[2 * other] = t0;
+                    pat[2 * other + 1] = t1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+#endif

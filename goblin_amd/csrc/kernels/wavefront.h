@@ -724,7 +724,11 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
             for (int kk = wave; kk < wa.pass_spp; kk += GBL_BLOCK / 64) {
                 const uint32_t k = static_cast<uint32_t>(wa.pass_k0 + kk);
                 float image_x, image_y;
-                if (REPLAY) {
+                if (REPLAY && ra.image_xy) {   // GBL_SAMPLES_STREAM: the records were transient, their image positions were kept
+                    const float* xy = ra.image_xy + 2 * (static_cast<size_t>(local_pixel) * ra.spp + k);
+                    image_x = xy[0];
+                    image_y = xy[1];
+                } else if (REPLAY) {
                     const float* rec = ra.replay + (static_cast<size_t>(local_pixel) * ra.spp + k) * ra.dims;
                     image_x = rec[0];
                     image_y = rec[1];

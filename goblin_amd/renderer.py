@@ -99,7 +99,7 @@ class HipPathTracer:
         return Film(self.info.xres, self.info.yres, self.device)
 
     def _params(self, setting=None, window=None, seed=0, replay=None, li_out=None, stats=False, rr=False, shard=None,
-                schedule=0):
+                schedule=0, sampler="native"):
         s = setting or self.scene.desc.setting
         p = _abi.gbl_render_params()
         p.integrator = s.integrator
@@ -112,7 +112,8 @@ class HipPathTracer:
             p.window[i] = int(w[i])
         if shard is not None:
             p.tile_shard_index, p.tile_shard_count = int(shard[0]), int(shard[1])
-        p.sample_mode = _abi.GBL_SAMPLES_REPLAY if replay is not None else _abi.GBL_SAMPLES_NATIVE
+        p.sample_mode = _abi.GBL_SAMPLES_REPLAY if replay is not None else (
+            _abi.GBL_SAMPLES_STREAM if sampler == "stream" else _abi.GBL_SAMPLES_NATIVE)
         p.seed = int(seed)
         p.replay_samples = replay.data_ptr() if replay is not None else None
         p.li_out = li_out.data_ptr() if li_out is not None else None
@@ -124,11 +125,12 @@ class HipPathTracer:
         return p
 
     def render(self, film=None, setting=None, window=None, seed=0, replay_samples=None, want_li=False, stats=False,
-               timed=False, rr=False, shard=None, schedule="auto"):
+               timed=False, rr=False, shard=None, schedule="auto", sampler="native"):
         """Accumulate one pass into ``film`` (created if None).
 
         replay_samples: (n, dims) float32 tensor/array of Sample records for the
         window, pixel-major (GBL_SAMPLES_REPLAY); otherwise the native sampler.
+        sampler: "native" (counter-based law) or "stream" (the reference's own mt19937 stream, GBL_SAMPLES_STREAM).
         shard: (index, count) renders only every count-th 8x8 sample tile (multi-GPU).
         Returns dict(film=..., li=..., stats=...).
         """
@@ -148,7 +150,7 @@ class HipPathTracer:
             if tuple(replay.shape) != (npaths, dims):
                 raise ValueError("replay_samples must have shape (%d, %d), got %s" % (npaths, dims, tuple(replay.shape)))
         li = torch.zeros((npaths, 4), dtype=torch.float32, device=self.device) if want_li else None
-        p = self._params(s, window, seed, replay, li, stats, rr, shard, schedule)
+        p = self._params(s, window, seed, replay, li, stats, rr, shard, schedule, sampler)
         st_out = _abi.gbl_stats() if (stats or timed) else None
         st = self.lib.gbl_render(self.handle, C.byref(p), film.accum.data_ptr(), C.byref(st_out) if st_out else None)
         if st != _abi.GBL_OK:

@@ -309,7 +309,20 @@ typedef enum gbl_sample_mode {
      * lensU2, u1D[0][..], u1D[1][..], ..., u2D[0][..], ...} exactly as
      * Sampler::requestSamples fills them; pixel-major, S samples per pixel,
      * pixels in row-major order over the sample window given in params. */
-    GBL_SAMPLES_REPLAY = 1
+    GBL_SAMPLES_REPLAY = 1,
+    /* The reference's own stream, generated on the device: one mt19937 per 8x8
+     * sample tile (RNGImp, GoblinUtils.cpp:13-56) seeded with the tile's value
+     * of the never-seeded libc rand() in row-major tile order (RenderTask,
+     * GoblinRenderer.cpp:29-52, 99-126), Sampler::requestSamples per pixel
+     * (GoblinSampler.cpp:108-197) and the three discarded floats of every
+     * BSDFSample(rng) in PathTracer::Li (GoblinPathtracer.cpp:103,150,159).
+     * The Film accumulators then equal the reference binary's (glibc /
+     * libstdc++ build) up to float summation order, with nothing uploaded.
+     * A tile is sequential by construction -- this is the bit-faithful mode,
+     * NATIVE the fast one.  Path tracer on the megakernel schedule only;
+     * the window must be whole tiles of the full sample window; scenes with
+     * subsurface materials are not covered (GBL_ERR_UNSUPPORTED). */
+    GBL_SAMPLES_STREAM = 2
 } gbl_sample_mode;
 
 /* How the device schedules the same arithmetic (identical per-sample radiance):

@@ -129,6 +129,50 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     assert rel <= FILM_RELL2_TOL
 
 
+@pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_vn_box", "cornell_triangle_crop",
+                                  "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt"])
+def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
+    """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
+    Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators
+    are the reference binary's up to float summation order."""
+    meta, data = golden(case)
+    scene = gs.load_scene(meta["scene"], meta["overrides"])
+    from goblin_amd.renderer import HipPathTracer
+    r = HipPathTracer(scene, 0)
+    out = r.render(sampler="stream", want_li=True)
+    film, ref = out["film"].numpy(), data["film"]
+    np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
+    rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
+    o = ob.Oracle(scene)
+    res = o.render(threads=1, want_samples=True)
+    idx = helpers.tile_order_index(o.window(), meta["spp"])
+    flips = helpers.li_mismatch_fraction(out["li"].cpu().numpy(), res["li"][idx])
+    print(case, "stream film relL2", rel, "li flips", flips)
+    assert flips <= LI_FLIP_TOL
+    assert rel <= 1e-5
+
+
+def test_stream_mode_shards_and_windows(torch):
+    """Tiles are independent streams: interleaved tile shards and tile-aligned windows give the whole render's film."""
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(40, 32), spp=4, depth=4))
+    from goblin_amd.renderer import HipPathTracer
+    r = HipPathTracer(scene, 0)
+    whole = r.render(sampler="stream", want_li=True)
+    parts = r.new_film()
+    for i in range(3):
+        r.render(film=parts, sampler="stream", shard=(i, 3))
+    np.testing.assert_allclose(parts.accum.cpu().numpy(), whole["film"].accum.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    x0, x1, y0, y1 = r.window
+    halves = r.new_film()
+    r.render(film=halves, sampler="stream", window=(x0, x0 + 16, y0, y1))
+    r.render(film=halves, sampler="stream", window=(x0 + 16, x1, y0, y1))
+    np.testing.assert_allclose(halves.accum.cpu().numpy(), whole["film"].accum.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(_abi.GoblinError):   # not whole tiles of the full window
+        r.render(sampler="stream", window=(x0 + 3, x1, y0, y1))
+    with pytest.raises(_abi.GoblinError):
+        r.render(sampler="stream", schedule="wavefront")
+
+
 @pytest.mark.parametrize("name,ov", [
     ("bunny", gs.config_overrides(resolution=(48, 40), spp=16, depth=5)),
     ("cornell", gs.config_overrides(resolution=(32, 32), spp=9, depth=6)),
