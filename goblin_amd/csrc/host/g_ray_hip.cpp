@@ -1,4 +1,7 @@
-// g_ray_hip <scene.json> [--device N] [--seed S] [--out file.{exr,ppm,pfm}]
+// g_ray_hip <scene.json> [--device N] [--seed S] [--sampler native|stream] [--out file.{exr,ppm,pfm}]
+//
+// --sampler stream renders with the reference's own sample stream (GBL_SAMPLES_STREAM): the image is the one the
+// reference binary writes for this scene file, up to float summation order; native (default) is the fast sampler.
 //
 // Stand-alone host with the call shape of the reference's g_ray
 // (/root/reference/src/g_ray.cpp:7-27): load the scene, render it, and run
@@ -7,6 +10,7 @@
 // ABI of include/goblin_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,16 +22,18 @@
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: g_ray_hip scene_file.json [--device N] [--seed S] [--out image.{exr,ppm,pfm}]\n");
+        fprintf(stderr, "Usage: g_ray_hip scene_file.json [--device N] [--seed S] [--sampler native|stream] [--out image.{exr,ppm,pfm}]\n");
         return 0;
     }
     std::string scene_path = argv[1], out_path;
     int device = 0;
     unsigned long long seed = 0;
+    bool stream_sampler = false;
     for (int i = 2; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], nullptr, 10);
         else if (!strcmp(argv[i], "--out")) out_path = argv[i + 1];
+        else if (!strcmp(argv[i], "--sampler")) stream_sampler = !strcmp(argv[i + 1], "stream");
     }
     gbl_host_scene* hs = nullptr;
     if (gbl_host_load_file(scene_path.c_str(), &hs) != GBL_OK) {
@@ -62,7 +68,28 @@ int main(int argc, char** argv) {
     p.seed = seed;
     gbl_stats st;
     auto t0 = std::chrono::steady_clock::now();
-    if (gbl_render(ctx, &p, accum, &st) != GBL_OK) {
+    if (stream_sampler) {
+        // bands of whole tile rows, sized so a band's per-sample buffers stay near 1 GiB
+        p.sample_mode = GBL_SAMPLES_STREAM;
+        const int spp = gbl_host_round_to_square(p.sample_per_pixel);
+        const long long row_samples = static_cast<long long>(info.window[1] - info.window[0]) * spp;
+        int band = static_cast<int>(std::max<long long>(8, ((1ll << 26) / std::max<long long>(1, row_samples)) / 8 * 8));
+        gbl_stats total;
+        memset(&total, 0, sizeof(total));
+        for (int y = info.window[2]; y < info.window[3]; y += band) {
+            p.window[0] = info.window[0];
+            p.window[1] = info.window[1];
+            p.window[2] = y;
+            p.window[3] = std::min(y + band, info.window[3]);
+            if (gbl_render(ctx, &p, accum, &st) != GBL_OK) {
+                fprintf(stderr, "gbl_render failed: %s\n", gbl_last_error(ctx));
+                return 1;
+            }
+            total.paths += st.paths;
+            total.kernel_ms += st.kernel_ms;
+        }
+        st = total;
+    } else if (gbl_render(ctx, &p, accum, &st) != GBL_OK) {
         fprintf(stderr, "gbl_render failed: %s\n", gbl_last_error(ctx));
         return 1;
     }

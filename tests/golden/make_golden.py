@@ -45,6 +45,8 @@ VN_GEOMS = [{"name": "bunny", "type": "mesh", "file": "models/bunny_vn.obj"},
 # name -> (scene, overrides, number of (Sample -> Li) records to keep, with_kat)
 CASES = {
     "bunny_pt": ("bunny", ov((64, 64), 16, 4), 2048, True),
+    # BASELINE configs[0] at its full size (1 081 600 paths), Film only
+    "bunny_config1": ("bunny", ov((256, 256), 16, 4), 0, False),
     "bunny_pt_d8": ("bunny", ov((32, 32), 4, 8), 1024, False),
     "cornell_pt": ("cornell", ov((48, 48), 16, 6), 2048, True),
     "grid_pt": ("grid", ov((48, 48), 4, 5), 1024, True),

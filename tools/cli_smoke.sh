@@ -12,3 +12,5 @@ json.dump(doc,open("gpurun_out/cli/t.json","w"))
 PY
 ./goblin_amd/lib/g_ray_hip gpurun_out/cli/t.json
 ls -la gpurun_out/cli
+./goblin_amd/lib/g_ray_hip gpurun_out/cli/t.json --sampler stream --out gpurun_out/cli/textured_stream.ppm
+ls -la gpurun_out/cli
