@@ -837,10 +837,6 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ctx->error = "GBL_SAMPLES_STREAM covers the path tracer on the megakernel schedule";
             return GBL_ERR_UNSUPPORTED;
         }
-        if (sc.has_bssrdf != 0) {
-            ctx->error = "GBL_SAMPLES_STREAM does not cover scenes with subsurface materials";
-            return GBL_ERR_UNSUPPORTED;
-        }
         // the tiles rendered must be tiles of the reference's own tiling of the full sample window
         if ((ra.window[0] - full[0]) % GBL_TILE != 0 || (ra.window[2] - full[2]) % GBL_TILE != 0 ||
             (ra.window[1] != full[1] && (ra.window[1] - full[0]) % GBL_TILE != 0) ||
@@ -883,7 +879,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     for (int k = 0; k < 3; ++k)
         if (!tev[k]) HIP_TRY(ctx, hipEventCreate(&tev[k]));
     HIP_TRY(ctx, hipEventRecord(tev[0], stream));
-    if (sc.has_bssrdf != 0 && p->integrator == GBL_INTEGRATOR_PATH) {
+    if (sc.has_bssrdf != 0 && p->integrator == GBL_INTEGRATOR_PATH && !stream_mode) {
         // Lsubsurface of every camera sample, ahead of the path kernels that add it at the first hit (kernels/subsurface.h)
         const uint64_t entries = npix * ra.spp;
         if (entries * 16 > li_budget_bytes(ctx)) {

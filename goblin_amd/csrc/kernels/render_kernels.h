@@ -19,6 +19,7 @@
 #include "sampler.h"
 #include "shade.h"
 #include "stream.h"
+#include "bssrdf.h"
 #include "trace.h"
 #include "vecmath.h"
 
@@ -426,9 +427,23 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     } else {
                         F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
                         ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
-                        if (EXT && sc.has_bssrdf != 0) {   // Li += Lsubsurface (kernels/subsurface.h), GoblinPathtracer.cpp:69
-                            const float4 ss = reinterpret_cast<const float4*>(ra.sss)[out_index];
-                            ps.Li = f3(ps.Li.x + ss.x, ps.Li.y + ss.y, ps.Li.z + ss.z);
+                        if (EXT && sc.has_bssrdf != 0) {   // Li += Lsubsurface, GoblinPathtracer.cpp:69
+                            if constexpr (STREAM) {
+                                // the records only exist while the tile walk is on this pixel: evaluate in place (bssrdf.h)
+                                const int material = sc.instances[hit.inst].material;
+                                if (sc.materials[material].type == GBL_MAT_SUBSURFACE) {
+                                    TexFrag ts = tf;   // zero differentials for these lookups; the bounce keeps its own
+                                    DevMaterial mo;
+                                    sss_resolve(sc, material, fr, ts, mo);
+                                    const F3 single = l_bssrdf_single<true, STATS>(sc, ra, src, fr, mo, material, -ps.d, stk, cnt);
+                                    const F3 multi = l_bssrdf_diffusion<true, STATS>(sc, ra, src, fr, ts, mo, material, -ps.d, stk, cnt);
+                                    const F3 ss = single + multi;
+                                    ps.Li = f3(ps.Li.x + ss.x, ps.Li.y + ss.y, ps.Li.z + ss.z);
+                                }
+                            } else {   // computed ahead by sss_kernel (subsurface.h)
+                                const float4 ss = reinterpret_cast<const float4*>(ra.sss)[out_index];
+                                ps.Li = f3(ps.Li.x + ss.x, ps.Li.y + ss.y, ps.Li.z + ss.z);
+                            }
                         }
                         ps.bounce = 0;
                     }

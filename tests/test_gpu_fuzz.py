@@ -1,4 +1,5 @@
-"""Randomised scenes: the device against the oracle, sample by sample (counter-based sampler on both sides).
+"""Randomised scenes: the device against the oracle, sample by sample (counter-based sampler on both sides), and the
+device-generated reference stream against the oracle's whole-render Film.
 
 Every seed draws a scene from the supported feature set -- meshes, spheres and disks under random (also non-uniform)
 transforms, the five material types incl. masks, procedural textures, point / spot / directional / area lights over
@@ -44,3 +45,11 @@ def test_random_scene_matches_oracle(seed):
             rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
             print("seed", seed, bvh, schedule, "flips %.5f relL2 %.2e" % (flips, rel), "mask" if masks_in_use else "")
             assert flips <= 3e-3 and rel <= 2e-2, (seed, bvh, schedule, flips, rel)
+    # the reference's own sample stream, generated on the device: the oracle's whole-render Film (bit-exact with the
+    # compiled reference on these scenes, tests/test_oracle_fuzz.py) is the reference's Film
+    ref = o.render(threads=1)["film"]
+    film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
+    print("seed", seed, "stream film relL2 %.2e" % rel)
+    np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
+    assert rel <= 1e-5, (seed, rel)
