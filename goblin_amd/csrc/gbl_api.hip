@@ -833,8 +833,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     }
     const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY || stream_mode;
     if (stream_mode) {
-        if (p->integrator != GBL_INTEGRATOR_PATH || p->schedule == GBL_SCHEDULE_WAVEFRONT) {
-            ctx->error = "GBL_SAMPLES_STREAM covers the path tracer on the megakernel schedule";
+        if (p->schedule == GBL_SCHEDULE_WAVEFRONT) {
+            ctx->error = "GBL_SAMPLES_STREAM runs on the megakernel schedule";
             return GBL_ERR_UNSUPPORTED;
         }
         // the tiles rendered must be tiles of the reference's own tiling of the full sample window
@@ -844,7 +844,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ctx->error = "GBL_SAMPLES_STREAM: the window must consist of whole 8x8 tiles of the full sample window";
             return GBL_ERR_INVALID;
         }
-        const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
+        const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
+                                             p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
         if (static_cast<uint64_t>(sc.stack_entries) * GBL_BLOCK < L.S) {
             ctx->error = "GBL_SAMPLES_STREAM: sample_per_pixel too large for the shuffle scratch";
             return GBL_ERR_UNSUPPORTED;
@@ -920,9 +921,13 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
         if (stream_mode) {
-            kernel = want_stats ? path_trace_kernel<true, true, true, true>
-                                : (ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>);
-            const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
+            if (p->integrator == GBL_INTEGRATOR_AO)
+                kernel = want_stats ? ao_kernel<true, true, true, true> : (ext ? ao_kernel<true, false, true, true> : ao_kernel<true, false, false, true>);
+            else
+                kernel = want_stats ? path_trace_kernel<true, true, true, true>
+                                    : (ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>);
+            const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
+                                                 p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
             ra.stream_stride = stream_scratch_words(L);
             const uint64_t need = ra.stream_stride * sizeof(uint32_t) * grid64;
             if (need > ctx->stream_scratch_bytes) {

@@ -633,16 +633,28 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
 // Ambient occlusion (AORenderer::Li): one closest hit, N uniform-hemisphere
 // any-hit rays, unoccluded fraction as grey radiance.
 // ---------------------------------------------------------------------------
-template <bool REPLAY, bool STATS, bool EXT>
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false>
 __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
-    uint32_t* stack = ctrl + 4;
+    uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
     const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+    StreamCtx scx = {};
+    StreamLayout slay = {};
+    if constexpr (STREAM) {   // see path_trace_kernel; AORenderer::Li draws nothing from the tile's generator itself
+        slay = stream_layout(ra.spp, ra.root, 0, 0, 0, ra.ao_n);
+        scx.mt = ctrl + 4;
+        scx.pos = ctrl + 4 + GBL_MT_N;
+        scx.lperm = stack;
+        scx.lperm_words = static_cast<uint32_t>(sc.stack_entries) * GBL_BLOCK;
+        scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
+        scx.perm = scx.raw + slay.NF + slay.NU;
+        scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+    }
 
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
@@ -661,8 +673,24 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
         __syncthreads();
         const uint32_t item = ctrl[0];
         if (item >= n_items) break;
-        const ItemInfo it = decode_item(ra, item);
-        const int tx0 = it.px0 - sc.film.halo, ty0 = it.py0 - sc.film.halo;
+        const ItemInfo tile_item = decode_item(ra, item);
+        const int tx0 = tile_item.px0 - sc.film.halo, ty0 = tile_item.py0 - sc.film.halo;
+        if constexpr (STREAM) {
+            const int ftx = (tile_item.px0 - sc.film.window[0]) / GBL_TILE, fty = (tile_item.py0 - sc.film.window[2]) / GBL_TILE;
+            mt_seed(scx, ra.tile_seeds[fty * ra.full_tiles_x + ftx]);
+        }
+        const int n_sub = STREAM ? tile_item.tw * tile_item.th : 1;
+        for (int sub = 0; sub < n_sub; ++sub) {
+        ItemInfo it = tile_item;
+        if constexpr (STREAM) {
+            it.px0 = tile_item.px0 + sub % tile_item.tw;
+            it.py0 = tile_item.py0 + sub / tile_item.tw;
+            it.tw = it.th = 1;
+            it.paths = ra.spp;
+            stream_generate_pixel(scx, slay, it.px0, it.py0);
+            if (threadIdx.x == 0) ctrl[1] = 0u;
+            __syncthreads();
+        }
 
         for (;;) {
             int fetched = wave_fetch(true, ctrl + 1);
@@ -680,9 +708,13 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             uint32_t out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
             float image_x, image_y;
             if (REPLAY) {
-                src.rec = ra.replay + static_cast<size_t>(out_index) * ra.dims;
+                src.rec = STREAM ? scx.recs + static_cast<size_t>(src.k) * ra.dims : ra.replay + static_cast<size_t>(out_index) * ra.dims;
                 image_x = src.rec[0];
                 image_y = src.rec[1];
+                if (STREAM) {
+                    ra.image_xy[2 * static_cast<size_t>(out_index)] = image_x;
+                    ra.image_xy[2 * static_cast<size_t>(out_index) + 1] = image_y;
+                }
             } else {
                 uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
                 src.pixel_key = nat_mix(ra.seed_key, pixel);
@@ -741,6 +773,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             paths_done += 1;
             }   // valid
         }
+        if constexpr (STREAM) __syncthreads();   // every record of this pixel has been read before the next overwrites them
+        }   // sub
         __syncthreads();
         if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }

@@ -29,21 +29,35 @@
 #define GBL_MT_M 397
 
 struct StreamLayout {
-    uint32_t S, root, D, nb, nb2;   // samples per pixel and its root; bounces; BSSRDF slots (1D / 2D)
+    uint32_t S, root;               // samples per pixel and its root
+    // the quota as runs of patterns: s1 one-slot 1D patterns then g1 1D patterns of nb slots; likewise 2D
+    uint32_t s1, g1, nb, s2, g2, nb2;
     uint32_t F1, F2;                // total 1D / 2D slots
     uint32_t NF, NU;                // float / uint draws per pixel
     uint32_t ncols;                 // shuffled columns: lens, then every 1D slot, then every 2D slot
     uint32_t dims;
 };
-__host__ __device__ inline StreamLayout stream_layout(int spp, int root, int max_depth, int nb, int nb2) {
+// path tracer: D x {light 1D, bsdf 1D, pick 1D; light 2D, bsdf 2D} + the BSSRDF block (4 1D and 2 2D patterns of nb / nb2
+// slots); AO (ao != 0): one 2D pattern of `ao` directions (AORenderer::querySampleQuota, GoblinAO.cpp:39-42)
+__host__ __device__ inline StreamLayout stream_layout(int spp, int root, int max_depth, int nb, int nb2, int ao = 0) {
     StreamLayout L;
     L.S = static_cast<uint32_t>(spp);
     L.root = static_cast<uint32_t>(root);
-    L.D = static_cast<uint32_t>(max_depth);
-    L.nb = static_cast<uint32_t>(nb);
-    L.nb2 = static_cast<uint32_t>(nb2);
-    L.F1 = 3u * L.D + 4u * L.nb;
-    L.F2 = 2u * L.D + 2u * L.nb2;
+    if (ao != 0) {
+        L.s1 = L.g1 = L.nb = 0u;
+        L.s2 = 0u;
+        L.g2 = 1u;
+        L.nb2 = static_cast<uint32_t>(ao);
+    } else {
+        L.s1 = 3u * static_cast<uint32_t>(max_depth);
+        L.g1 = 4u;
+        L.nb = static_cast<uint32_t>(nb);
+        L.s2 = 2u * static_cast<uint32_t>(max_depth);
+        L.g2 = 2u;
+        L.nb2 = static_cast<uint32_t>(nb2);
+    }
+    L.F1 = L.s1 + L.g1 * L.nb;
+    L.F2 = L.s2 + L.g2 * L.nb2;
     L.NF = L.S * (4u + L.F1 + 2u * L.F2);
     L.NU = L.S * (1u + 2u * L.F1 + 2u * L.F2);
     L.ncols = 1u + L.F1 + L.F2;
@@ -177,7 +191,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
     }
     __syncthreads();
     // ---- records: sample k takes, in every column, the element its position's permutation points at
-    const uint32_t n1_single = 3u * L.D, n2_single = 2u * L.D;
+    const uint32_t n1_single = L.s1, n2_single = L.s2;
     const uint32_t* uper = c.raw + L.NF + L.ncols * S;   // in-pattern shuffle draws, F1 + F2 per sample
     for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
         float* rec = c.recs + static_cast<size_t>(k) * L.dims;
@@ -192,7 +206,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
             rec[3] = y;
         }
         uint32_t col1 = 0;   // running 1D slot
-        for (uint32_t i = 0; i < n1_single + 4u; ++i) {
+        for (uint32_t i = 0; i < n1_single + L.g1; ++i) {
             const uint32_t n = i < n1_single ? 1u : L.nb;
             const float strata = 1.0f / static_cast<float>(n);
             const float sub = strata / static_cast<int>(S);
@@ -203,7 +217,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
             }
         }
         uint32_t col2 = 0;   // running 2D slot
-        for (uint32_t i = 0; i < n2_single + 2u; ++i) {
+        for (uint32_t i = 0; i < n2_single + L.g2; ++i) {
             const uint32_t n = i < n2_single ? 1u : L.nb2;
             for (uint32_t j = 0; j < n; ++j, ++col2) {
                 const uint32_t p = c.perm[(1u + L.F1 + col2) * S + k];
@@ -217,7 +231,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         // per-sample shuffles inside each pattern (:185-196); a one-slot pattern swaps its slot with itself
         const uint32_t* us = uper + static_cast<size_t>(k) * (L.F1 + L.F2);
         if (L.nb > 1u) {
-            for (uint32_t i = 0; i < 4u; ++i) {
+            for (uint32_t i = 0; i < L.g1; ++i) {
                 float* pat = rec + 4 + n1_single + i * L.nb;
                 const uint32_t* up = us + n1_single + i * L.nb;
                 for (uint32_t m = 0; m < L.nb; ++m) {
@@ -229,7 +243,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
             }
         }
         if (L.nb2 > 1u) {
-            for (uint32_t i = 0; i < 2u; ++i) {
+            for (uint32_t i = 0; i < L.g2; ++i) {
                 float* pat = rec + 4 + L.F1 + 2 * (n2_single + i * L.nb2);
                 const uint32_t* up = us + L.F1 + n2_single + i * L.nb2;
                 for (uint32_t m = 0; m < L.nb2; ++m) {

@@ -129,7 +129,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     assert rel <= FILM_RELL2_TOL
 
 
-@pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_vn_box", "cornell_triangle_crop",
+@pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
                                   "subsurface_pt", "subsurface_n9"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
