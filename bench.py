@@ -73,13 +73,18 @@ def cpu_baseline(workload_overrides, spp_sample, cores):
                     g["file"] = os.path.join(os.path.dirname(src), g["file"])
             with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as tf:
                 json.dump(doc, tf)
+            prefix = tf.name[:-5]
             try:
-                res = json.loads(subprocess.check_output([harness, "time", tf.name, str(cores)], timeout=600).decode())
+                res = json.loads(subprocess.check_output([harness, "film", tf.name, prefix, str(cores)], timeout=600).decode())
+                import numpy as np
+                ref_film = np.fromfile(prefix + ".film.f32", np.float32).reshape(res["yres"], res["xres"], 4)
             finally:
                 os.unlink(tf.name)
+                if os.path.exists(prefix + ".film.f32"):
+                    os.unlink(prefix + ".film.f32")
             out = {"value": round(res["mpaths_per_s"], 4), "unit": "Mpaths/s", "cores": cores, "kind": "reference",
                    "sample": sample + ", %d paths in %.2f s (oracle/_ref/ref_harness = /root/reference/src compiled as-is)"
-                   % (res["paths"], res["seconds"])}
+                   % (res["paths"], res["seconds"]), "_film": ref_film}
         except Exception as e:  # the prebuilt binary may be absent or unusable on this box
             print("cpu_baseline: reference harness failed (%s); using the oracle port" % e, file=sys.stderr)
     try:
@@ -97,6 +102,25 @@ def cpu_baseline(workload_overrides, spp_sample, cores):
     except Exception as e:
         print("cpu_baseline: oracle port failed: %s" % e, file=sys.stderr)
     return out
+
+
+def l2_vs_reference(tracer, ref_film, spp_sample):
+    """Per-pixel L2 of the normalised film against the Film the compiled reference itself rendered for the
+    cpu_baseline leg: the device regenerates the reference's own sample stream (GBL_SAMPLES_STREAM), so the two
+    films hold the same samples and differ by float summation order only."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_binding as ob
+    from goblin_amd import _abi
+    s = _abi.gbl_render_setting.from_buffer_copy(tracer.scene.desc.setting)
+    s.sample_per_pixel = spp_sample
+    gpu = tracer.render(setting=s, sampler="stream", schedule="megakernel")["film"].numpy()
+    a, b = ob.normalize_film(gpu).astype(np.float64), ob.normalize_film(ref_film).astype(np.float64)
+    return {"rel_l2": float(np.linalg.norm(a - b) / np.linalg.norm(b)),
+            "rmse": float(np.sqrt(np.mean((a - b) ** 2))),
+            "max_weight_diff": float(np.abs(gpu[..., 3] - ref_film[..., 3]).max()),
+            "sample": "512x512 film, %d spp: oracle/_ref/ref_harness's Film vs the device rendering the reference's own "
+                      "mt19937 sample stream" % spp_sample}
 
 
 def l2_vs_cpu(tracer, workload_overrides, spp_sample, cores, seed):
@@ -263,9 +287,33 @@ def main():
                 "l2_hit_rate": pmc.get("l2_hit_rate"),
             },
         }
+        if world == 1:
+            # the same frame with the reference's own mt19937 sample stream generated on the device (GBL_SAMPLES_STREAM):
+            # its Film is the reference binary's; reported beside the headline, never as `value`
+            try:
+                sfilm = tracer.new_film()
+                tracer.render(film=sfilm, sampler="stream", schedule="megakernel")
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                sfilm.zero_()
+                tracer.render(film=sfilm, sampler="stream", schedule="megakernel")
+                torch.cuda.synchronize()
+                sms = (time.perf_counter() - ts) * 1e3
+                line["reference_stream_sampler"] = {"value": round(my_paths / sms * 1e-3, 2), "unit": "Mpaths/s",
+                                                    "ms_per_step": round(sms, 2),
+                                                    "note": "bit-faithful sampler: per-tile mt19937 + Sampler::requestSamples on the device"}
+                del sfilm
+            except Exception as e:
+                print("reference_stream_sampler leg failed: %s" % e, file=sys.stderr)
         if world == 1 and not args.no_cpu:
             cores = max(1, min(16, len(os.sched_getaffinity(0))))
             line["cpu_baseline"] = cpu_baseline(overrides, 16, cores)
+            ref_film = line["cpu_baseline"].pop("_film", None) if line["cpu_baseline"] else None
+            if ref_film is not None:
+                try:
+                    line["l2_vs_reference"] = l2_vs_reference(tracer, ref_film, 16)
+                except Exception as e:
+                    print("l2_vs_reference failed: %s" % e, file=sys.stderr)
             try:
                 line["l2_vs_cpu"] = l2_vs_cpu(tracer, overrides, 16, cores, base_seed)
             except Exception as e:

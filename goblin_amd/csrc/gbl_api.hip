@@ -669,6 +669,23 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
     return GBL_OK;
 }
 
+__global__ void selftest_sincos_kernel(const float* in, float* s, float* c, uint64_t n) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i] = gbl_sinf(in[i]);
+    c[i] = gbl_cosf(in[i]);
+}
+
+gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
+    if (!ctx || !in || !sin_out || !cos_out) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    hipLaunchKernelGGL(selftest_sincos_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, in, sin_out, cos_out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+
 void gbl_destroy(gbl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

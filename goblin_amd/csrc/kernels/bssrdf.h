@@ -222,7 +222,7 @@ __device__ __forceinline__ F3 l_bssrdf_diffusion(const DevScene& sc, const Rende
         // BSSRDF::sampleProbeRay (GoblinMaterial.cpp:129-164): a gaussian disc sample, probed along N, U or V (2 : 1 : 1)
         const float r = sqrtf(logf(1.0f - bs.disc0 * (1.0f - expf(-sigma_tr * rmax * rmax))) / -sigma_tr);
         const float theta = GBL_TWO_PI * bs.disc1;
-        const float sx = r * cosf(theta), sy = r * sinf(theta);
+        const float sx = r * gbl_cosf(theta), sy = r * gbl_sinf(theta);
         const float half_len = sqrtf(rmax * rmax - (sx * sx + sy * sy));
         F3 po, pd;
         int axis;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, 
                 tf->v = theta * GBL_INV_PI;
                 float inv_r = 1.0f / sqrtf(pos.x * pos.x + pos.y * pos.y);
                 float cos_phi = pos.x * inv_r, sin_phi = pos.y * inv_r;
-                dpdv = GBL_PI * f3(pos.z * cos_phi, pos.z * sin_phi, -ip->radius * sinf(theta));
+                dpdv = GBL_PI * f3(pos.z * cos_phi, pos.z * sin_phi, -ip->radius * gbl_sinf(theta));
             } else {
                 float r = sqrtf(pos.x * pos.x + pos.y * pos.y);
                 tf->v = r / ip->radius;
@@ -256,12 +256,12 @@ __device__ __forceinline__ F3 cosine_sample_hemisphere(float u1, float u2) {
     float sin_t = sqrtf(u1);
     float cos_t = sqrtf(fmaxf(0.0f, 1.0f - u1));
     float phi = GBL_TWO_PI * u2;
-    return f3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+    return f3(sin_t * gbl_cosf(phi), sin_t * gbl_sinf(phi), cos_t);
 }
 __device__ __forceinline__ F3 uniform_sample_hemisphere(float u1, float u2) {
     float sin_t = sqrtf(fmaxf(0.0f, 1.0f - u1 * u1));
     float phi = GBL_TWO_PI * u2;
-    return f3(sin_t * cosf(phi), sin_t * sinf(phi), u1);
+    return f3(sin_t * gbl_cosf(phi), sin_t * gbl_sinf(phi), u1);
 }
 __device__ __forceinline__ float power_heuristic(float pa, float pb) {
     float A = 1.0f * pa, B = 1.0f * pb;
@@ -350,7 +350,7 @@ __device__ __forceinline__ F3 mat_sample(const DevMaterial& m, const Frag& fr, F
         float cos_t = powf(u1, 1.0f / (e + 1.0f));
         float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
         float phi = u2 * GBL_TWO_PI;
-        F3 wh_local = f3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+        F3 wh_local = f3(sin_t * gbl_cosf(phi), sin_t * gbl_sinf(phi), cos_t);
         if (dot(wo, n) < 0.0f) wh_local = wh_local * -1.0f;
         F3 wh = shade_to_world(fr, wh_local);
         *wi = -wo + 2.0f * dot(wo, wh) * wh;
@@ -545,8 +545,8 @@ __device__ __forceinline__ void uniform_sample_disk(float u1, float u2, float* o
             theta = y != 0.0f ? 0.25f * GBL_PI * (6.0f - x / y) : 0.0f;
         }
     }
-    *ox = r * cosf(theta);
-    *oy = r * sinf(theta);
+    *ox = r * gbl_cosf(theta);
+    *oy = r * gbl_sinf(theta);
 }
 // Geometry::pdf for an analytic emitter, light-local space (GoblinGeometry.cpp:44-62)
 __device__ __forceinline__ float light_shape_area_pdf(const DevLight& l, F3 p, F3 wi) {
@@ -588,7 +588,7 @@ __device__ __forceinline__ F3 light_shape_sample(const DevLight& l, F3 p, float 
         float z = 1.0f - 2.0f * u1;
         float sin_t = sqrtf(fmaxf(0.0f, 1.0f - z * z));
         float phi = GBL_TWO_PI * u2;
-        *normal = f3(sin_t * cosf(phi), sin_t * sinf(phi), z);
+        *normal = f3(sin_t * gbl_cosf(phi), sin_t * gbl_sinf(phi), z);
         return l.radius * (*normal);
     }
     F3 z_axis = normalize(-p), x_axis, y_axis;
@@ -598,7 +598,7 @@ __device__ __forceinline__ F3 light_shape_sample(const DevLight& l, F3 p, float 
     float cos_t = 1.0f - u1 + u1 * cos_max;
     float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
     float phi = GBL_TWO_PI * u2;
-    F3 d = x_axis * sin_t * cosf(phi) + y_axis * sin_t * sinf(phi) + z_axis * cos_t;
+    F3 d = x_axis * sin_t * gbl_cosf(phi) + y_axis * sin_t * gbl_sinf(phi) + z_axis * cos_t;
     float t;
     F3 p_hit;
     if (sphere_test(l.radius, p, d, 1e-3f, INFINITY, &t)) p_hit = p + t * d;

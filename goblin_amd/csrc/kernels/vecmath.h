@@ -60,3 +60,5 @@ __device__ __forceinline__ F3 xf_normal(const float* inv, F3 n) {
 #define GBL_INV_TWOPI 0.15915494309189533577f
 #define GBL_INV_PI 0.31830988618379067154f
 #define GBL_INV_TWOPI 0.15915494309189533577f
+
+#include "refmath.h"

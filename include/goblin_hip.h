@@ -433,6 +433,9 @@ gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out);
  * the scene bound), are GBL_ERR_UNSUPPORTED: re-create the context for those. */
 gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world);
 
+/* Self-test hook: the device's sinf / cosf (glibc's algorithm restated, kernels/refmath.h) on n device floats. */
+gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n);
+
 void gbl_destroy(gbl_ctx* ctx);
 /* Message for the last failing call on ctx (or on creation when ctx == NULL). */
 const char* gbl_last_error(const gbl_ctx* ctx);
