@@ -272,7 +272,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "kernel": "path_trace_kernel<false,false,false>" if resolved != "wavefront" else "wf_trace/wf_shade (all wavefront kernels of a step)",
+                "kernel": "path_trace_kernel<false,false,false,false>" if resolved != "wavefront" else "wf_trace/wf_shade (all wavefront kernels of a step)",
                 "kernel_ms_avg": round(avg_kernel_ms, 3),
                 "call_ms_avg": round(sum(call_ms) / len(call_ms), 3),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
