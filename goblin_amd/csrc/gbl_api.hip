@@ -1041,6 +1041,11 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             if (getenv("GBL_PROBE"))
                 fprintf(stderr, "probe: interior lane-steps %llu wave-steps %llu (util %.3f) | leaf/other lane %llu wave %llu (util %.3f)\n", h[7], h[8],
                         h[8] ? h[7] / (64.0 * h[8]) : 0.0, h[9], h[10], h[10] ? h[9] / (64.0 * h[10]) : 0.0);
+            if (getenv("GBL_PROBE") && h[25] + h[26] + h[27] + h[28] + h[29]) {
+                const double tot = static_cast<double>(h[25] + h[26] + h[27] + h[28] + h[29]);
+                fprintf(stderr, "probe: stream sampler phases (share of the workgroups' time): emit %.1f%% permute %.1f%% assemble %.1f%% paths %.1f%% skip %.1f%%\n",
+                        100.0 * h[25] / tot, 100.0 * h[26] / tot, 100.0 * h[27] / tot, 100.0 * h[28] / tot, 100.0 * h[29] / tot);
+            }
             if (getenv("GBL_PROBE") && h[11] + h[12] + h[13] + h[14] + h[15] + h[16] + h[17]) {
                 const char* names[7] = {"<=3", "4-7", "8-15", "16-31", "32-63", "64-127", ">=128"};
                 unsigned long long rays = 0, steps = 0;

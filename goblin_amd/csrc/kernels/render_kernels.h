@@ -287,6 +287,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];
     const int full_w = sc.film.window[1] - sc.film.window[0];
+    unsigned long long stream_tm[5] = {0ull, 0ull, 0ull, 0ull, 0ull};   // instrumented STREAM builds: phase ticks (emit, permute, assemble, paths, skip)
 
     for (;;) {
         __syncthreads();
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             mt_seed(scx, ra.tile_seeds[fty * ra.full_tiles_x + ftx]);
         }
         uint32_t stream_draws = 0;   // STREAM: BSDFSample(rng) floats this lane's paths discarded
+        unsigned long long stream_t0 = 0ull;
         const int n_sub = STREAM ? tile_item.tw * tile_item.th : 1;
         for (int sub = 0; sub < n_sub; ++sub) {
         ItemInfo it = tile_item;
@@ -315,10 +317,11 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             it.py0 = tile_item.py0 + sub / tile_item.tw;
             it.tw = it.th = 1;
             it.paths = ra.spp;
-            stream_generate_pixel(scx, slay, it.px0, it.py0);
+            stream_generate_pixel(scx, slay, it.px0, it.py0, STATS ? stream_tm : nullptr);
             if (threadIdx.x == 0) ctrl[1] = ctrl[2] = 0u;
             stream_draws = 0;
             __syncthreads();
+            if (STATS) stream_t0 = wall_clock64();
         }
 
         PathState ps;
@@ -620,13 +623,21 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             __syncthreads();
             const uint32_t drawn = ctrl[2];
             __syncthreads();
+            if (STATS) {
+                const unsigned long long t1 = wall_clock64();
+                stream_tm[3] += t1 - stream_t0;
+                stream_t0 = t1;
+            }
             stream_emit(scx, nullptr, drawn);
+            if (STATS) stream_tm[4] += wall_clock64() - stream_t0;
         }
         }   // sub
         __syncthreads();
         if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
+    if (STATS && STREAM && threadIdx.x == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(ra.stats + 25 + i, stream_tm[i]);
 }
 
 // ---------------------------------------------------------------------------

@@ -165,9 +165,17 @@ __device__ __forceinline__ void stream_strat2(const StreamLayout& L, uint32_t n,
 }
 
 // Sampler::requestSamples for the pixel (cx, cy): fills c.recs.  Called by the whole workgroup.
-__device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const StreamLayout& L, int cx, int cy) {
+// tm (instrumented builds): wall_clock64 ticks spent emitting / permuting / assembling, accumulated by thread 0
+__device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const StreamLayout& L, int cx, int cy,
+                                                      unsigned long long* tm = nullptr) {
     const uint32_t S = L.S;
+    unsigned long long t0 = tm ? wall_clock64() : 0ull;
     stream_emit(c, c.raw, L.NF + L.NU);
+    if (tm) {
+        const unsigned long long t1 = wall_clock64();
+        tm[0] += t1 - t0;
+        t0 = t1;
+    }
     // ---- shuffle<T>(buffer, S, dim, rng): for n in [0, S): swap(element n, element rng.randomUInt() % S)
     // (GoblinSampler.h:149-157), tracked as the position permutation of each column
     const uint32_t B = min(64u, c.lperm_words / S);
@@ -190,6 +198,11 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         }
     }
     __syncthreads();
+    if (tm) {
+        const unsigned long long t1 = wall_clock64();
+        tm[1] += t1 - t0;
+        t0 = t1;
+    }
     // ---- records: sample k takes, in every column, the element its position's permutation points at
     const uint32_t n1_single = L.s1, n2_single = L.s2;
     const uint32_t* uper = c.raw + L.NF + L.ncols * S;   // in-pattern shuffle draws, F1 + F2 per sample
@@ -258,5 +271,6 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         }
     }
     __syncthreads();
+    if (tm) tm[2] += wall_clock64() - t0;
 }
 #endif
