@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 6
+GBL_ABI_VERSION = 7
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM = range(6)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM"}
@@ -20,7 +20,7 @@ GBL_LIGHT_POINT, GBL_LIGHT_DIRECTIONAL, GBL_LIGHT_SPOT, GBL_LIGHT_AREA = 0, 1, 2
 GBL_SHAPE_MESH, GBL_SHAPE_SPHERE, GBL_SHAPE_DISK = 0, 1, 2
 GBL_CAMERA_PERSPECTIVE, GBL_CAMERA_ORTHOGRAPHIC = 0, 1
 GBL_FILTER_BOX, GBL_FILTER_TRIANGLE, GBL_FILTER_GAUSSIAN, GBL_FILTER_MITCHELL = range(4)
-GBL_INTEGRATOR_PATH, GBL_INTEGRATOR_AO = 0, 1
+GBL_INTEGRATOR_PATH, GBL_INTEGRATOR_AO, GBL_INTEGRATOR_WHITTED = 0, 1, 2
 GBL_SAMPLES_NATIVE, GBL_SAMPLES_REPLAY, GBL_SAMPLES_STREAM = 0, 1, 2
 GBL_SCHEDULE_AUTO, GBL_SCHEDULE_MEGAKERNEL, GBL_SCHEDULE_WAVEFRONT = 0, 1, 2
 
@@ -66,7 +66,7 @@ class gbl_instance(C.Structure):
 class gbl_light(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", C.c_float * 3), ("position", C.c_float * 3),
                 ("direction", C.c_float * 3), ("cos_theta_max", C.c_float), ("cos_falloff_start", C.c_float),
-                ("mesh", C.c_uint32), ("to_world", gbl_trs)]
+                ("mesh", C.c_uint32), ("to_world", gbl_trs), ("sample_num", C.c_uint32)]
 
 
 class gbl_camera(C.Structure):
@@ -131,7 +131,7 @@ class gbl_info(C.Structure):
 
 HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "gbl_host_free",
                 "gbl_host_last_error", "gbl_host_sample_window", "gbl_host_round_to_square",
-                "gbl_host_sample_dimension", "gbl_host_film_normalize", "gbl_host_write_pfm", "gbl_host_output_path",
+                "gbl_host_sample_dimension", "gbl_host_sample_dimension_scene", "gbl_host_film_normalize", "gbl_host_write_pfm", "gbl_host_output_path",
                 "gbl_host_bloom", "gbl_host_tone_map", "gbl_host_write_ppm", "gbl_host_write_exr", "gbl_host_write_image"]
 GBL_CREATE_DEVICE_BVH = 1
 HIP_SYMBOLS = ["gbl_create", "gbl_create_ex", "gbl_update_instances", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
@@ -161,6 +161,7 @@ def host_lib():
         lib.gbl_host_sample_window.restype = None
         lib.gbl_host_round_to_square.argtypes = [C.c_int32]
         lib.gbl_host_sample_dimension.argtypes = [C.POINTER(gbl_render_setting)]
+        lib.gbl_host_sample_dimension_scene.argtypes = [C.POINTER(gbl_scene_desc), C.POINTER(gbl_render_setting)]
         lib.gbl_host_film_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         lib.gbl_host_film_normalize.restype = None
         lib.gbl_host_write_pfm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]

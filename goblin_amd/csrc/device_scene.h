@@ -123,7 +123,9 @@ struct DevLight {
     float sum_area;
     uint32_t shape;         // area: gbl_shape of the emitting geometry
     float radius;           // area: sphere / disk radius
-    float pad[3];
+    uint32_t wh_n;          // Whitted quota: roundToSquare(Light::getSamplesNum()) slots of this light's patterns ...
+    uint32_t wh_prefix;     // ... and the slots of the lights before it
+    float pad;
 };
 
 struct DevCamera {
@@ -165,7 +167,7 @@ struct DevScene {
     int32_t extended;             // scene uses analytic shapes, a directional light or a non-pinhole camera: EXT kernels
     int32_t has_masks;            // some instance carries a mask material: filtered queries + attenuation walks (megakernel only)
     int32_t has_bssrdf;           // some material is a subsurface material: sss_kernel runs ahead of the path kernels
-    int32_t pad_scene;
+    int32_t wh_slots;             // Whitted quota: sum of the lights' wh_n
     DevCamera camera;
     DevFilm film;
 };

@@ -21,6 +21,7 @@
 #include "kernels/render_kernels.h"
 #include "kernels/wavefront.h"
 #include "kernels/subsurface.h"
+#include "kernels/whitted.h"
 #include "kernels/lbvh.h"
 #include <hipcub/hipcub.hpp>
 #include "scene_prep.h"
@@ -573,6 +574,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     sc.extended = packed.extended;
     sc.has_masks = packed.has_masks;
     sc.has_bssrdf = packed.has_bssrdf;
+    sc.wh_slots = packed.wh_slots;
     sc.camera = packed.camera;
     sc.film = packed.film;
     void* p = nullptr;
@@ -752,7 +754,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     const DevScene& sc = ctx->scene;
     RenderArgs ra;
     memset(&ra, 0, sizeof(ra));
-    if (p->integrator != GBL_INTEGRATOR_PATH && p->integrator != GBL_INTEGRATOR_AO) {
+    if (p->integrator != GBL_INTEGRATOR_PATH && p->integrator != GBL_INTEGRATOR_AO && p->integrator != GBL_INTEGRATOR_WHITTED) {
         ctx->error = "unknown integrator";
         return GBL_ERR_INVALID;
     }
@@ -778,6 +780,10 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ra.off2_base = 4 + 3 * ra.max_depth + 4 * n1;
         ra.bssrdf_n = n1;
         ra.bssrdf_n2 = n2;
+        if (p->integrator == GBL_INTEGRATOR_WHITTED) {   // per-light patterns instead of per-bounce ones (kernels/whitted.h)
+            ra.dims = 4 + 6 * sc.wh_slots + 1 + 4 * n1 + 4 * n2;
+            ra.off2_base = 4 + 2 * sc.wh_slots + 1 + 4 * n1;
+        }
     }
     const int32_t* full = sc.film.window;
     bool whole = p->window[0] == 0 && p->window[1] == 0 && p->window[2] == 0 && p->window[3] == 0;
@@ -897,6 +903,85 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     for (int k = 0; k < 3; ++k)
         if (!tev[k]) HIP_TRY(ctx, hipEventCreate(&tev[k]));
     HIP_TRY(ctx, hipEventRecord(tev[0], stream));
+    if (p->integrator == GBL_INTEGRATOR_WHITTED) {
+        // WhittedRenderer: one lane per camera sample with the recursion's frames in scratch (kernels/whitted.h), then the
+        // shared splat kernel
+        if (stream_mode || p->schedule == GBL_SCHEDULE_WAVEFRONT) {
+            ctx->error = "the Whitted integrator runs with the native or replay sampler on the megakernel schedule";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        if (sc.has_masks != 0 || sc.has_bssrdf != 0) {
+            ctx->error = "the Whitted integrator's device path does not cover mask or subsurface materials";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        if (ra.max_depth > GBL_WHITTED_MAX_DEPTH) {
+            ctx->error = "max_ray_depth above " + std::to_string(GBL_WHITTED_MAX_DEPTH) + " is outside the Whitted kernel's frame stack";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        const uint64_t entries = npix * ra.spp;
+        float4* li = reinterpret_cast<float4*>(ra.li_out);
+        if (!li) {
+            if (entries * 16 > li_budget_bytes(ctx)) {
+                ctx->error = "the Whitted integrator keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
+                return GBL_ERR_UNSUPPORTED;
+            }
+            gbl_status lst = ensure_li(ctx, entries);
+            if (lst != GBL_OK) return lst;
+            li = ctx->wf_li;
+        }
+        if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
+        hipEvent_t* wev = ctx->t_ev[ctx->t_calls % gbl_ctx::kTimingRing];
+        for (int k = 0; k < 3; ++k)
+            if (!wev[k]) HIP_TRY(ctx, hipEventCreate(&wev[k]));
+        HIP_TRY(ctx, hipEventRecord(wev[0], stream));
+        auto k_wh = replay ? (want_stats ? whitted_kernel<true, true> : whitted_kernel<true, false>)
+                           : (want_stats ? whitted_kernel<false, true> : whitted_kernel<false, false>);
+        const size_t lds_wh = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+        if (lds_wh > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_wh), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds_wh)));
+        const uint64_t total = static_cast<uint64_t>(ra.local_tiles) * 64 * ra.spp;
+        const uint64_t blocks = std::min<uint64_t>((total + GBL_BLOCK - 1) / GBL_BLOCK, static_cast<uint64_t>(ctx->num_cus) * 8);
+        hipLaunchKernelGGL(k_wh, dim3(static_cast<unsigned>(blocks)), dim3(GBL_BLOCK), lds_wh, stream, sc, ra, li);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(wev[1], stream));
+        {
+            WfArgs wa;
+            memset(&wa, 0, sizeof(wa));
+            wa.li_buf = li;
+            wa.pass_k0 = 0;
+            wa.pass_spp = ra.spp;
+            // replay records of another quota: the splat only reads their image positions, at the Whitted record stride
+            auto k_splat = replay ? (want_stats ? wf_splat<true, true> : wf_splat<true, false>)
+                                  : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
+            const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
+            hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), dim3(GBL_BLOCK), lds_tile, stream, sc, ra, wa);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        HIP_TRY(ctx, hipEventRecord(wev[2], stream));
+        ctx->t_calls += 1;
+        if (stats) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev1, stream));
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+            float ms = 0.0f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            memset(stats, 0, sizeof(*stats));
+            stats->kernel_ms = ms;
+            stats->paths = npix * ra.spp;
+            if (want_stats) {
+                unsigned long long h[32];
+                HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));
+                stats->paths = h[0];
+                stats->extension_rays = h[1];
+                stats->shadow_rays = h[2];
+                stats->nodes = h[3];
+                stats->tris = h[4];
+                stats->splats = h[5];
+                stats->dims = h[6];
+            }
+        }
+        return GBL_OK;
+    }
     if (sc.has_bssrdf != 0 && p->integrator == GBL_INTEGRATOR_PATH && !stream_mode) {
         // Lsubsurface of every camera sample, ahead of the path kernels that add it at the first hit (kernels/subsurface.h)
         const uint64_t entries = npix * ra.spp;

@@ -460,8 +460,10 @@ private:
         gbl_render_setting& rs = s_->desc.setting;
         if (method == "ao") {
             rs.integrator = GBL_INTEGRATOR_AO;
-        } else if (method == "whitted" || method == "light_tracing" || method == "bdpt" || method == "sppm") {
-            return fail(GBL_ERR_UNSUPPORTED, "render_method \"" + method + "\" is outside the device path (path_tracing and ao only)");
+        } else if (method == "whitted") {
+            rs.integrator = GBL_INTEGRATOR_WHITTED;
+        } else if (method == "light_tracing" || method == "bdpt" || method == "sppm") {
+            return fail(GBL_ERR_UNSUPPORTED, "render_method \"" + method + "\" is outside the device path (path_tracing, whitted and ao only)");
         } else {
             rs.integrator = GBL_INTEGRATOR_PATH;  // "path_tracing" and the unknown-string fallback
         }
@@ -912,6 +914,7 @@ private:
             std::string name = p.get_string("name");
             gbl_light lt;
             memset(&lt, 0, sizeof(lt));
+            lt.sample_num = 1;   // Light::getSamplesNum (GoblinLight.h:124); area lights read "sample_num"
             lt.to_world.orientation[0] = 1.0f;
             lt.to_world.scale[0] = lt.to_world.scale[1] = lt.to_world.scale[2] = 1.0f;
             if (type == "ibl") {
@@ -954,6 +957,7 @@ private:
                 if (st != GBL_OK) return st;
                 lt.mesh = mesh;
                 read_trs(p, &lt.to_world);
+                lt.sample_num = static_cast<uint32_t>(std::max(0, p.get_int("sample_num", 1)));   // createAreaLight, GoblinLight.cpp:675
             } else {  // "point" and the unknown-type fallback
                 lt.type = GBL_LIGHT_POINT;
                 Vec I = p.get_vec(p.vec3s, "intensity", vec(0, 0, 0));
@@ -1095,6 +1099,19 @@ int32_t gbl_host_sample_dimension(const gbl_render_setting* rs) {
     int n1 = round_to_square(rs->bssrdf_sample_num);
     int n2 = round_to_square(n1);
     return 4 + 7 * depth + 4 * n1 + 2 * 2 * n2;
+}
+
+int32_t gbl_host_sample_dimension_scene(const gbl_scene_desc* desc, const gbl_render_setting* rs) {
+    if (rs->integrator != GBL_INTEGRATOR_WHITTED) return gbl_host_sample_dimension(rs);
+    // per light: LightSampleIndex + BSDFSampleIndex of getSamplesNum() points (1D + 2D each); one pick 1D; the BSSRDF block
+    int dims = 4;
+    for (uint32_t i = 0; i < desc->num_lights; ++i) {
+        const int n1 = round_to_square(static_cast<int>(desc->lights[i].sample_num));
+        const int n2 = round_to_square(n1);
+        dims += 2 * n1 + 2 * 2 * n2;
+    }
+    const int b1 = round_to_square(rs->bssrdf_sample_num), b2 = round_to_square(b1);
+    return dims + 1 + 4 * b1 + 2 * 2 * b2;
 }
 
 void gbl_host_film_normalize(const float* accum, int32_t xres, int32_t yres, float* rgb_out) {

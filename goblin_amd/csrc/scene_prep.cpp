@@ -931,6 +931,13 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             return GBL_ERR_INVALID;
         }
         power[i] = 0.212671f * pr + 0.715160f * pg + 0.072169f * pb;
+        // WhittedRenderer::querySampleQuota: LightSampleIndex(quota, getSamplesNum()) -> roundToSquare slots
+        {
+            const int root = static_cast<int>(std::ceil(std::sqrt(static_cast<float>(gl.sample_num))));
+            dl.wh_n = static_cast<uint32_t>(root * root);
+            dl.wh_prefix = static_cast<uint32_t>(out->wh_slots);
+            out->wh_slots += static_cast<int32_t>(dl.wh_n);
+        }
     }
     out->light_cdf.assign(d->num_lights + 1, 0.0f);
     out->light_pick_pdf.assign(std::max<uint32_t>(1, d->num_lights), 0.0f);

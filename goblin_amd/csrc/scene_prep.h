@@ -23,6 +23,7 @@ struct PackedScene {
     int32_t extended = 0;   // DevScene::extended
     int32_t has_masks = 0;  // DevScene::has_masks
     int32_t has_bssrdf = 0; // DevScene::has_bssrdf
+    int32_t wh_slots = 0;   // DevScene::wh_slots
     uint64_t blas_nodes = 0, tlas_nodes = 0;
     int blas_max_depth = 0, tlas_depth = 0;
     std::vector<float> mesh_lo, mesh_hi;   // 3 per mesh: object bounds

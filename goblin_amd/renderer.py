@@ -146,7 +146,7 @@ class HipPathTracer:
         spp = _abi.host_lib().gbl_host_round_to_square(s.sample_per_pixel)
         npaths = (w[1] - w[0]) * (w[3] - w[2]) * spp
         if replay is not None:
-            dims = _abi.host_lib().gbl_host_sample_dimension(C.byref(s))
+            dims = _abi.host_lib().gbl_host_sample_dimension_scene(C.byref(self.scene.desc), C.byref(s))
             if tuple(replay.shape) != (npaths, dims):
                 raise ValueError("replay_samples must have shape (%d, %d), got %s" % (npaths, dims, tuple(replay.shape)))
         li = torch.zeros((npaths, 4), dtype=torch.float32, device=self.device) if want_li else None

@@ -67,7 +67,7 @@ class Scene:
         return _abi.host_lib().gbl_host_round_to_square(self.desc.setting.sample_per_pixel)
 
     def sample_dimension(self):
-        return _abi.host_lib().gbl_host_sample_dimension(C.byref(self.desc.setting))
+        return _abi.host_lib().gbl_host_sample_dimension_scene(C.byref(self.desc), C.byref(self.desc.setting))
 
     def num_paths(self):
         x0, x1, y0, y1 = self.sample_window()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 6
+#define GBL_ABI_VERSION 7
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -161,6 +161,8 @@ typedef struct gbl_light {
     float cos_falloff_start; /* spot                                           */
     uint32_t mesh;           /* area: emitting geometry                        */
     gbl_trs to_world;        /* area                                           */
+    uint32_t sample_num;     /* area: "sample_num" (default 1) = Light::getSamplesNum, read by the Whitted
+                              * renderer's per-light quota (GoblinLight.cpp:675, GoblinWhitted.cpp:60-66); 1 for the rest */
 } gbl_light;
 
 typedef enum gbl_camera_type {
@@ -204,7 +206,11 @@ typedef struct gbl_film {
 
 typedef enum gbl_integrator {
     GBL_INTEGRATOR_PATH = 0, /* PathTracer  (GoblinPathtracer.cpp) */
-    GBL_INTEGRATOR_AO = 1    /* AORenderer  (GoblinAO.cpp)         */
+    GBL_INTEGRATOR_AO = 1,   /* AORenderer  (GoblinAO.cpp)         */
+    /* WhittedRenderer (GoblinWhitted.cpp:13-44): emission + multiSampleLd over every light (GoblinRenderer.cpp:474-596)
+     * + the specular reflection / refraction tree (:598-648).  Mask and subsurface materials are outside this
+     * integrator's device path (GBL_ERR_UNSUPPORTED). */
+    GBL_INTEGRATOR_WHITTED = 2
 } gbl_integrator;
 
 /* render_setting block (GoblinPathtracer.cpp:210-217, GoblinAO.cpp:44-49). */
@@ -267,6 +273,9 @@ const char* gbl_host_last_error(void);
 void gbl_host_sample_window(const gbl_film* film, int32_t out[4]);
 /* roundToSquare (GoblinUtils.h:124-130): the spp the sampler really takes. */
 int32_t gbl_host_round_to_square(int32_t n);
+/* Floats per Sample record when the quota depends on the scene (the Whitted renderer's per-light patterns,
+ * WhittedRenderer::querySampleQuota, GoblinWhitted.cpp:46-70); equals gbl_host_sample_dimension otherwise. */
+int32_t gbl_host_sample_dimension_scene(const gbl_scene_desc* desc, const gbl_render_setting* rs);
 /* Floats per Sample for an integrator: 4 + quota (GoblinPathtracer.cpp:181-208,
  * GoblinAO.cpp:39-42, GoblinSampler.h:27-31). */
 int32_t gbl_host_sample_dimension(const gbl_render_setting* setting);

@@ -474,6 +474,7 @@ struct orc_scene {
     std::vector<gbl_texture> textures;
     std::vector<Xform> tex_xf;   // SphericalMapping::mToTex per texture
     bool has_masks = false;
+    std::vector<uint32_t> light_samples;   // Light::getSamplesNum per light (the Whitted renderer's quota)
     std::vector<Light> lights;
     std::vector<Cdf> light_geo_cdf;   // per light (area only)
     Cdf light_power;
@@ -711,6 +712,8 @@ void prepare(orc_scene* s) {
     s->tlas.build(iboxes);
     // lights
     s->lights.resize(d.num_lights);
+    s->light_samples.resize(d.num_lights);
+    for (uint32_t i = 0; i < d.num_lights; ++i) s->light_samples[i] = d.lights[i].sample_num;
     std::vector<float> powers;
     s->light_power_rgb.clear();
     for (uint32_t i = 0; i < d.num_lights; ++i) {
@@ -1819,6 +1822,38 @@ Quota pt_quota(const gbl_render_setting& rs, PtIndices* ix) {
     return q;
 }
 
+// WhittedRenderer::querySampleQuota, GoblinWhitted.cpp:46-70: per light a LightSampleIndex and a BSDFSampleIndex of
+// getSamplesNum() points, one pick-light 1D (requested, never read by Li), the BSSRDF block
+Quota whitted_quota(const orc_scene* s, const gbl_render_setting& rs, PtIndices* ix) {
+    Quota q;
+    for (size_t i = 0; i < s->lights.size(); ++i) {
+        uint32_t n = s->light_samples[i];
+        uint32_t l1 = q.one_d(n), l2 = q.two_d(n);
+        uint32_t b1 = q.one_d(n), b2 = q.two_d(n);
+        if (ix) {
+            ix->light1.push_back(l1); ix->light2.push_back(l2);
+            ix->bsdf1.push_back(b1); ix->bsdf2.push_back(b2);
+        }
+    }
+    uint32_t pk = q.one_d(1);
+    if (ix) ix->pick.push_back(pk);
+    q.perm1_from = 0;
+    q.perm2_from = 0;
+    int n = rs.bssrdf_sample_num;
+    uint32_t s_ls1 = q.one_d(n), s_ls2 = q.two_d(n);
+    uint32_t s_pick = q.one_d(n);
+    uint32_t s_axis = q.one_d(n);
+    uint32_t s_disc = q.two_d(n);
+    uint32_t s_single = q.one_d(n);
+    if (ix) {
+        ix->sss_ls1 = s_ls1; ix->sss_ls2 = s_ls2; ix->sss_pick = s_pick; ix->sss_axis = s_axis; ix->sss_disc = s_disc;
+        ix->sss_single = s_single;
+        ix->sss_n = std::min(q.n1[s_ls1], q.n2[s_ls2]);
+    }
+    q.finish();
+    return q;
+}
+
 Quota ao_quota(const gbl_render_setting& rs) {   // AORenderer::querySampleQuota, GoblinAO.cpp:39-42
     Quota q;
     q.two_d(rs.ao_sample_num);
@@ -2444,10 +2479,148 @@ Col ao_li(LiCtx* c, const Ray& primary, const float* rec) {
     return Li;
 }
 
+// ---------------------------------------------------------------------------
+// WhittedRenderer (GoblinWhitted.cpp:13-44) over Renderer::multiSampleLd / estimateLd / specularReflect /
+// specularRefract (GoblinRenderer.cpp:474-648).  Mask and subsurface materials are not restated for this integrator.
+// ---------------------------------------------------------------------------
+inline bool mat_is_specular(const gbl_material& m) { return m.type == GBL_MAT_TRANSPARENT || m.type == GBL_MAT_MIRROR; }
+
+// Renderer::estimateLd with type = BSDFAll & ~BSDFSpecular (:502-567)
+Col estimate_ld(LiCtx* c, V3 wo, float epsilon, const Hit& hit, const ResolvedMat& mat, int light, float ls_comp, const float* ls_geo,
+                float bs_comp, const float* bs_dir) {
+    const orc_scene* s = c->s;
+    Col Ld(BLACK);
+    const Frag& frag = hit.frag;
+    V3 wi;
+    V3 p = frag.p, n = frag.n;
+    float light_pdf_v, bsdf_pdf;
+    Ray shadow;
+    Col L = light_sample(s, light, p, epsilon, ls_comp, ls_geo[0], ls_geo[1], &wi, &light_pdf_v, &shadow);
+    if (L != BLACK && light_pdf_v > 0.0f) {
+        Col f = rmat_bsdf(mat, n, wo, wi);
+        if (f != BLACK && !scene_occluded(s, shadow, &c->cnt)) {
+            if (light_is_delta(s->lights[light])) return f * L * absdot(n, wi) / light_pdf_v;
+            bsdf_pdf = rmat_pdf(mat, n, wo, wi);
+            float lw = power_heuristic(1, light_pdf_v, 1, bsdf_pdf);
+            Ld += f * L * absdot(n, wi) * lw / light_pdf_v;
+        }
+    }
+    // sampleBSDF(..., BSDFAll & ~BSDFSpecular): the specular materials do not match the request (pdf 0, Black);
+    // Lambert and Blinn sample exactly as under BSDFAll
+    if (mat_is_specular(mat.m)) return Ld;
+    int sampled = 0;
+    Col f = rmat_sample(mat, frag, wo, bs_comp, bs_dir[0], bs_dir[1], &wi, &bsdf_pdf, &sampled);
+    if (f != BLACK && bsdf_pdf > 0.0f) {
+        float fw = 1.0f;
+        if (!(sampled & BSDF_SPECULAR)) {
+            light_pdf_v = light_pdf(s, light, p, wi);
+            if (light_pdf_v == 0.0f) return Ld;
+            fw = power_heuristic(1, bsdf_pdf, 1, light_pdf_v);
+        }
+        Ray r;
+        r.o = p; r.d = wi; r.mint = epsilon; r.maxt = INF;
+        Hit lh;
+        lh.frag = hit.frag;
+        if (scene_intersect(s, r, &lh, &c->cnt)) {
+            if (s->instances[lh.instance].area_light == light) {
+                Col Le = hit_Le(s, lh, -wi);
+                if (Le != BLACK) Ld += f * Le * absdot(wi, n) * fw / bsdf_pdf;
+            }
+        }   // else: light->Le(r) is Black for every light on this path (IBL only)
+    }
+    return Ld;
+}
+
+// Renderer::multiSampleLd (:474-500)
+Col multi_sample_ld(LiCtx* c, const Ray& ray, float epsilon, const Hit& hit, const ResolvedMat& mat, const float* rec) {
+    const orc_scene* s = c->s;
+    Col total(BLACK);
+    for (size_t i = 0; i < s->lights.size(); ++i) {
+        Col Ld(BLACK);
+        uint32_t n_samples = std::min(c->q->n1[c->ix->light1[i]], c->q->n2[c->ix->light2[i]]);   // LightSampleIndex::samplesNum
+        for (uint32_t n = 0; n < n_samples; ++n) {
+            // LightSample ls(rng); BSDFSample bs(rng); -- six draws, then both are replaced by the Sample's values
+            draw_bsdf_sample(c);
+            draw_bsdf_sample(c);
+            float ls_comp = rec[c->q->off1[c->ix->light1[i]] + n];
+            const float* ls_geo = rec + c->q->off2[c->ix->light2[i]] + 2 * n;
+            float bs_comp = rec[c->q->off1[c->ix->bsdf1[i]] + n];
+            const float* bs_dir = rec + c->q->off2[c->ix->bsdf2[i]] + 2 * n;
+            c->dims_used += 6;
+            Ld += estimate_ld(c, -ray.d, epsilon, hit, mat, static_cast<int>(i), ls_comp, ls_geo, bs_comp, bs_dir);
+        }
+        Ld = Ld / static_cast<float>(n_samples);
+        total += Ld;
+    }
+    return total;
+}
+
+Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* diff, int depth) {
+    const orc_scene* s = c->s;
+    Col Li(BLACK);
+    Ray ray = ray_in;
+    Hit hit;
+    hit.frag.n = V3(0, 0, 0);
+    hit.frag.dpdv = V3(0, 0, 0);
+    if (!scene_intersect(s, ray, &hit, &c->cnt)) return Li;   // evalEnvironmentLight = 0 on this path
+    compute_uv_differential(&hit.frag, diff);
+    Li += hit_Le(s, hit, -ray.d);
+    // Lsubsurface: 0 (no BSSRDF under this integrator's device path)
+    const ResolvedMat mat = resolve_hit_material(s, s->instances[hit.instance].material, hit.frag);
+    Li += multi_sample_ld(c, ray, hit.epsilon, hit, mat, rec);
+    if (depth < c->rs->max_ray_depth) {
+        const Frag& frag = hit.frag;
+        V3 n = frag.n, p = frag.p, wo = -ray.d;
+        // specularReflect (:598-622): sampleBSDF(..., BSDFSample(rng), BSDFSpecular | BSDFReflection)
+        {
+            Col L(BLACK);
+            draw_bsdf_sample(c);
+            V3 wi(0, 0, 0);
+            float pdf = 0.0f;
+            Col f(BLACK);
+            if (mat.m.type == GBL_MAT_MIRROR) {
+                f = mat_color(mat.m) * specular_reflect_conductor(n, wo, &wi, mat.m.index, mat.m.k);
+                pdf = 1.0f;
+            } else if (mat.m.type == GBL_MAT_TRANSPARENT) {   // nMatch == 1, the reflection lobe (:660-667)
+                f = mat_color(mat.m) * specular_reflect_dielectric(n, wo, &wi, 1.0f, mat.m.index);
+                pdf = 1.0f;
+            }
+            if (f != BLACK && absdot(wi, n) != 0.0f) {
+                Ray child;
+                child.o = p; child.d = wi; child.mint = hit.epsilon; child.maxt = INF;
+                Col Lr = whitted_li(c, child, rec, nullptr, depth + 1);
+                L += f * Lr * absdot(wi, n) / pdf;
+            }
+            Li += L;
+        }
+        // specularRefract (:624-648): BSDFSpecular | BSDFTransmission
+        {
+            Col L(BLACK);
+            draw_bsdf_sample(c);
+            V3 wi(0, 0, 0);
+            float pdf = 0.0f;
+            Col f(BLACK);
+            if (mat.m.type == GBL_MAT_TRANSPARENT) {
+                f = mat_color2(mat.m) * specular_refract(n, wo, &wi, 1.0f, mat.m.index);
+                pdf = 1.0f;
+            }
+            if (f != BLACK && absdot(wi, n) != 0.0f) {
+                Ray child;
+                child.o = p; child.d = wi; child.mint = hit.epsilon; child.maxt = INF;
+                Col Lr = whitted_li(c, child, rec, nullptr, depth + 1);
+                L += f * Lr * absdot(wi, n) / pdf;
+            }
+            Li += L;
+        }
+    }
+    return Li;
+}
+
 inline Col eval_li(LiCtx* c, const float* rec) {
     RayDiff rd;
     Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3], &rd);
     c->dims_used += 2;
+    if (c->rs->integrator == GBL_INTEGRATOR_WHITTED) return whitted_li(c, ray, rec, &rd, 0);
     return c->rs->integrator == GBL_INTEGRATOR_AO ? ao_li(c, ray, rec) : path_li(c, ray, rec, &rd);
 }
 
@@ -2553,7 +2726,8 @@ struct NativeSampler {
     }
 };
 
-Quota make_quota(const gbl_render_setting& rs, PtIndices* ix) {
+Quota make_quota(const gbl_render_setting& rs, PtIndices* ix, const orc_scene* s = nullptr) {
+    if (rs.integrator == GBL_INTEGRATOR_WHITTED && s) return whitted_quota(s, rs, ix);
     return rs.integrator == GBL_INTEGRATOR_AO ? ao_quota(rs) : pt_quota(rs, ix);
 }
 
@@ -2581,6 +2755,9 @@ void orc_destroy(orc_scene* s) { delete s; }
 void orc_sample_window(const orc_scene* s, int32_t out[4]) { memcpy(out, s->window, sizeof(s->window)); }
 
 int32_t orc_sample_dimension(const gbl_render_setting* rs) { return static_cast<int32_t>(make_quota(*rs, nullptr).dims()); }
+int32_t orc_sample_dimension_scene(const orc_scene* s, const gbl_render_setting* rs) {
+    return static_cast<int32_t>(make_quota(*rs, nullptr, s).dims());
+}
 
 // Float offsets of the path tracer's per-bounce sample slots inside a record:
 // out[5*b + {0..4}] = {light component, light geometry(2), bsdf component, bsdf direction(2), pick light}
@@ -2646,7 +2823,7 @@ int32_t orc_occluded(const orc_scene* s, const float o[3], const float d[3], flo
 int32_t orc_li_replay(const orc_scene* s, const gbl_render_setting* rs, const float* samples, int64_t n, float* li_out,
                       int32_t threads, orc_counters* counters) {
     PtIndices ix;
-    Quota q = make_quota(*rs, &ix);
+    Quota q = make_quota(*rs, &ix, s);
     uint32_t dims = q.dims();
     int nt = std::max(1, threads);
     std::vector<Counters> cnts(nt);
@@ -2689,7 +2866,7 @@ int32_t orc_splat(const orc_scene* s, const float* samples, int32_t dims, const 
 
 // Native (counter-based) sample records for a sub-window, pixel-major.
 int32_t orc_native_samples(const orc_scene* s, const gbl_render_setting* rs, uint64_t seed, const int32_t window[4], float* out) {
-    Quota q = make_quota(*rs, nullptr);
+    Quota q = make_quota(*rs, nullptr, s);
     NativeSampler ns(seed, rs->sample_per_pixel);
     int fw = s->window[1] - s->window[0];
     uint32_t dims = q.dims();
@@ -2715,7 +2892,7 @@ int32_t orc_render(const orc_scene* s, const gbl_render_setting* rs, int32_t thr
                    uint64_t seed, float* film_accum, float* samples_out, float* li_out, double* seconds,
                    orc_counters* counters) {
     PtIndices ix;
-    Quota q = make_quota(*rs, &ix);
+    Quota q = make_quota(*rs, &ix, s);
     uint32_t dims = q.dims();
     int root;
     int spp = round_to_square(rs->sample_per_pixel, &root);

@@ -44,6 +44,7 @@
 #include "GoblinScene.h"
 #include "GoblinThreadLocalStorage.h"
 #include "GoblinThreadPool.h"
+#include "GoblinWhitted.h"
 
 using namespace Goblin;
 
@@ -92,6 +93,18 @@ struct ProbeAO : public AORenderer {
              RenderingTLS* tls) const {
         Color c = AORenderer::Li(scene, ray, sample, rng, tls);
         g_rec.record(sample, c);
+        return c;
+    }
+};
+
+// The Whitted renderer calls Li recursively (specularReflect / specularRefract, GoblinRenderer.cpp:598-648): only the
+// camera ray's call (depth 0) is a record.
+struct ProbeWhitted : public WhittedRenderer {
+    ProbeWhitted(int spp, int threads, int depth, int bssrdf) : WhittedRenderer(spp, threads, depth, bssrdf) {}
+    Color Li(const ScenePtr& scene, const RayDifferential& ray, const Sample& sample, const RNG& rng,
+             RenderingTLS* tls) const {
+        Color c = WhittedRenderer::Li(scene, ray, sample, rng, tls);
+        if (ray.depth == 0) g_rec.record(sample, c);
         return c;
     }
 };
@@ -228,7 +241,8 @@ int main(int argc, char** argv) {
     int spp = base->mSamplePerPixel;
     bool is_ao = dynamic_cast<AORenderer*>(base) != nullptr;
     bool is_pt = dynamic_cast<PathTracer*>(base) != nullptr;
-    if (!is_ao && !is_pt) {
+    bool is_wh = dynamic_cast<WhittedRenderer*>(base) != nullptr;
+    if (!is_ao && !is_pt && !is_wh) {
         fprintf(stderr, "scene selects a renderer outside the hot path\n");
         return 1;
     }
@@ -261,6 +275,9 @@ int main(int argc, char** argv) {
         if (is_pt) {
             PathTracer* pt = static_cast<PathTracer*>(base);
             probe = new ProbePT(spp, 1, pt->mMaxRayDepth, pt->mBssrdfSampleNum);
+        } else if (is_wh) {
+            WhittedRenderer* wh = static_cast<WhittedRenderer*>(base);
+            probe = new ProbeWhitted(spp, 1, wh->mMaxRayDepth, wh->mBssrdfSampleNum);
         } else {
             AORenderer* ao = static_cast<AORenderer*>(base);
             probe = new ProbeAO(spp, 1, ao->mAOSampleNum);

@@ -67,6 +67,9 @@ CASES = {
     "masked_pt": ("masked", ov((64, 64), 9, 6), 2048, False),
     # subsurface materials -- Lsubsurface at the camera hit (single scattering + dipole diffusion), the
     # Fresnel mirror lobe of SubsurfaceMaterial, and its BSDFAll type under the isOpaque / notOpaque filters
+    # the Whitted renderer: multiSampleLd over every light (per-light sample counts 4, 1, 2 -> 4, 1, 4 slots), specular tree
+    "whitted": ("whitted", ov((64, 64), 9, 5), 2048, False),
+    "whitted_d2": ("whitted", ov((48, 48), 4, 2), 1024, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }

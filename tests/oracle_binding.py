@@ -46,6 +46,7 @@ def lib():
         L.orc_sample_window.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.orc_sample_window.restype = None
         L.orc_sample_dimension.argtypes = [C.POINTER(_abi.gbl_render_setting)]
+        L.orc_sample_dimension_scene.argtypes = [C.c_void_p, C.POINTER(_abi.gbl_render_setting)]
         L.orc_pt_offsets.argtypes = [C.POINTER(_abi.gbl_render_setting), C.POINTER(C.c_int32)]
         L.orc_pt_offsets.restype = None
         L.orc_glibc_rand.argtypes = [C.POINTER(C.c_int32), C.c_int32]
@@ -95,7 +96,7 @@ class Oracle:
         return tuple(w)
 
     def dims(self, setting=None):
-        return lib().orc_sample_dimension(C.byref(setting or self.scene.desc.setting))
+        return lib().orc_sample_dimension_scene(self.h, C.byref(setting or self.scene.desc.setting))
 
     def pt_offsets(self, setting=None):
         s = setting or self.scene.desc.setting

@@ -44,7 +44,7 @@ def schedule(request):
 
 
 class _Scheduled:
-    """HipPathTracer whose render() defaults to one schedule (AO always runs the persistent megakernel)."""
+    """HipPathTracer whose render() defaults to one schedule (AO and Whitted have a single kernel each)."""
 
     def __init__(self, tracer, schedule):
         self._t, self._schedule = tracer, schedule
@@ -54,7 +54,7 @@ class _Scheduled:
 
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
-        kw.setdefault("schedule", "auto" if s.integrator == _abi.GBL_INTEGRATOR_AO else self._schedule)
+        kw.setdefault("schedule", "auto" if s.integrator != _abi.GBL_INTEGRATOR_PATH else self._schedule)
         return self._t.render(**kw)
 
 
@@ -75,7 +75,7 @@ def fake_window(full, n_pixels):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt", "subsurface_n9"])
+                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -104,7 +104,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt"])
+                                  "subsurface_pt", "whitted"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -181,6 +181,7 @@ def test_stream_mode_shards_and_windows(torch):
     ("shapes", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("textured", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("masked", gs.config_overrides(resolution=(40, 40), spp=9, depth=6)),
+    ("whitted", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("subsurface", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("subsurface", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
                         render_setting=dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4)["render_setting"], bssrdf_sample_num=7))),

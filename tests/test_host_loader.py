@@ -61,7 +61,9 @@ def test_render_methods():
     assert s.desc.setting.integrator == _abi.GBL_INTEGRATOR_AO
     s = load(minimal(render_setting={"render_method": "no such thing"}))
     assert s.desc.setting.integrator == _abi.GBL_INTEGRATOR_PATH
-    for m in ("sppm", "bdpt", "whitted", "light_tracing"):
+    s = load(minimal(render_setting={"render_method": "whitted"}))
+    assert s.desc.setting.integrator == _abi.GBL_INTEGRATOR_WHITTED
+    for m in ("sppm", "bdpt", "light_tracing"):
         with pytest.raises(_abi.GoblinError) as e:
             load(minimal(render_setting={"render_method": m}))
         assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
@@ -203,6 +205,17 @@ def test_subsurface_material():
     with pytest.raises(_abi.GoblinError) as e:                          # a mask around a subsurface material
         load(minimal(materials=[{"name": "inner", "type": "subsurface"}, {"name": "m", "type": "mask", "material": "inner"}]))
     assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+
+
+def test_whitted_quota_follows_the_lights():
+    """WhittedRenderer::querySampleQuota (GoblinWhitted.cpp:46-70): a LightSampleIndex and a BSDFSampleIndex of
+    roundToSquare(getSamplesNum()) slots per light, one pick 1D, the BSSRDF block; "sample_num" is read by area lights only."""
+    lights = [{"name": "a", "type": "area", "geometry": "q", "radiance": [1, 1, 1], "sample_num": 3},
+              {"name": "p", "type": "point", "intensity": [1, 1, 1], "sample_num": 7}]
+    s = load(minimal(render_setting={"render_method": "whitted", "bssrdf_sample_num": 4}, lights=lights))
+    assert [s.desc.lights[i].sample_num for i in range(2)] == [3, 1]
+    # light a: 4 slots -> 2 * (4 + 2 * 4); light p: 1 slot -> 2 * (1 + 2); pick 1; BSSRDF 4 * 4 + 2 * 2 * 4
+    assert s.sample_dimension() == 4 + 24 + 6 + 1 + 32
 
 
 def test_unused_out_of_scope_declarations_are_ignored():
