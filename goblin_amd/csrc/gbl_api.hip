@@ -678,6 +678,70 @@ __global__ void selftest_sincos_kernel(const float* in, float* s, float* c, uint
     c[i] = gbl_cosf(in[i]);
 }
 
+// rays: n x {kind (0 closest, 1 any), o(3), d(3), mint, maxt}; out: n x {t of the closest hit or -1 | 1 occluded or 0, instance, shading normal(3), tangent(3)}
+__global__ void selftest_trace_kernel(DevScene sc, const float* rays, float* out, uint32_t n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LdsStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x)};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 9 * i;
+    LaneCounters cnt = {};
+    Hit hit;
+    hit.inst = -1;
+    hit.t = -1.0f;
+    const F3 o = f3(r[1], r[2], r[3]), d = f3(r[4], r[5], r[6]);
+    float* q = out + 8 * i;
+    for (int k = 0; k < 8; ++k) q[k] = 0.0f;
+    if (r[0] != 0.0f) {
+        q[0] = trace<true, false, true>(sc, o, d, r[7], r[8], stk, hit, cnt) ? 1.0f : 0.0f;
+        q[1] = -1.0f;
+    } else {
+        const bool got = trace<false, false, true>(sc, o, d, r[7], r[8], stk, hit, cnt);
+        q[0] = got ? hit.t : -1.0f;
+        q[1] = got ? static_cast<float>(hit.inst) : -1.0f;
+        if (got) {
+            Frag fr;
+            make_fragment<true>(sc, hit, o, d, fr);
+            q[2] = fr.n.x; q[3] = fr.n.y; q[4] = fr.n.z;
+            q[5] = fr.t.x; q[6] = fr.t.y; q[7] = fr.t.z;
+        }
+    }
+}
+
+gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n) {
+    if (!ctx || !rays || !out) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    const size_t lds = static_cast<size_t>(ctx->scene.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(selftest_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds)));
+    hipLaunchKernelGGL(selftest_trace_kernel, dim3((n + GBL_BLOCK - 1) / GBL_BLOCK), dim3(GBL_BLOCK), lds, nullptr, ctx->scene, rays, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+
+// out[4 i ..] = {sqrtf(a), a / b, 1 / a, expected to be IEEE correctly rounded like the host's}
+__global__ void selftest_arith_kernel(const float* a, const float* b, float* out, uint64_t n) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[4 * i] = sqrtf(a[i]);
+    out[4 * i + 1] = a[i] / b[i];
+    out[4 * i + 2] = 1.0f / a[i];
+    const F3 v = normalize(f3(a[i], b[i], 0.5f));
+    out[4 * i + 3] = v.x;
+}
+gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n) {
+    if (!ctx || !a || !b || !out) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    hipLaunchKernelGGL(selftest_arith_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, a, b, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+
 gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
     if (!ctx || !in || !sin_out || !cos_out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

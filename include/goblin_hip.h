@@ -444,6 +444,12 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
 
 /* Self-test hook: the device's sinf / cosf (glibc's algorithm restated, kernels/refmath.h) on n device floats. */
 gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n);
+/* Self-test hook: out[4 i ..] = {sqrtf(a), a / b, 1 / a, normalize(a, b, 0.5).x} on n device floats -- the basic
+ * operations must round like the host's for per-sample radiance to be bit-identical with the reference. */
+gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n);
+/* Self-test hook: scene queries for n device rays {kind (0 Scene::intersect, 1 Scene::occluded), o(3), d(3), mint, maxt}
+ * -> out n x 8 floats {hit t or -1 | 1 occluded or 0, hit instance or -1, shading normal(3), tangent(3)}. */
+gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n);
 
 void gbl_destroy(gbl_ctx* ctx);
 /* Message for the last failing call on ctx (or on creation when ctx == NULL). */

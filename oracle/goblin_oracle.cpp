@@ -352,6 +352,9 @@ inline bool slab_test(const Box& b, const Ray& ray, V3 inv, const uint32_t neg[3
 
 struct Counters {
     uint64_t closest = 0, anyhit = 0, filtered = 0, nodes = 0, tris = 0;
+    // debugging aid (orc_debug_rays): every scene query of a sample, 16 floats each --
+    // {0 closest / 1 any, o(3), d(3), mint, maxt, result: hit t or -1 / 1 occluded or 0, shading normal(3), tangent(3)}
+    std::vector<float>* log = nullptr;
     void add(const Counters& o) {
         closest += o.closest; anyhit += o.anyhit; filtered += o.filtered; nodes += o.nodes; tris += o.tris;
     }
@@ -1064,7 +1067,23 @@ struct Hit {
 // Triangle::intersect (GoblinScene.cpp:75-83, GoblinPrimitive.cpp:103-112,
 // GoblinModel.cpp:39-55).  ray.maxt shrinks in place.  Frag state persists
 // across candidate hits exactly as the reference's single Intersection does.
+bool scene_intersect_impl(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt, int filter);
 bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt, int filter = FILTER_NONE) {
+    const Ray in = ray;
+    const bool any = scene_intersect_impl(s, ray, hit, cnt, filter);
+    if (cnt->log) {
+        V3 fn(0, 0, 0), ft(0, 0, 0);
+        if (any) {   // Fragment::getWorldToShade's n and t rows
+            fn = hit->frag.n;
+            ft = normalize(hit->frag.dpdu - fn * dot(hit->frag.dpdu, fn));
+        }
+        const float rec[16] = {0.0f, in.o.x, in.o.y, in.o.z, in.d.x, in.d.y, in.d.z, in.mint, in.maxt, any ? ray.maxt : -1.0f,
+                               fn.x, fn.y, fn.z, ft.x, ft.y, ft.z};
+        cnt->log->insert(cnt->log->end(), rec, rec + 16);
+    }
+    return any;
+}
+bool scene_intersect_impl(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt, int filter) {
     ++cnt->closest;
     bool any = false;
     traverse(s->tlas, ray, cnt, [&](uint32_t inst_id) {
@@ -1145,6 +1164,11 @@ bool scene_occluded(const orc_scene* s, const Ray& ray, Counters* cnt, int filte
         });
         return occ;
     });
+    if (cnt->log) {
+        const float rec[16] = {1.0f, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.mint, ray.maxt, occ ? 1.0f : 0.0f,
+                               0, 0, 0, 0, 0, 0};
+        cnt->log->insert(cnt->log->end(), rec, rec + 16);
+    }
     return occ;
 }
 
@@ -2852,6 +2876,20 @@ int32_t orc_li_replay(const orc_scene* s, const gbl_render_setting* rs, const fl
         }
     }
     return 0;
+}
+
+// Debugging aid: every scene query the Li evaluation of ONE record issues (see Counters::log); returns the count.
+int32_t orc_debug_rays(const orc_scene* s, const gbl_render_setting* rs, const float* rec, float* out, int32_t max_rays) {
+    PtIndices ix;
+    Quota q = make_quota(*rs, &ix, s);
+    std::vector<float> log;
+    LiCtx c;
+    c.s = s; c.rs = rs; c.q = &q; c.ix = &ix; c.rng = nullptr; c.ref_faithful = 0;
+    c.cnt.log = &log;
+    eval_li(&c, rec);
+    int32_t n = static_cast<int32_t>(log.size() / 16);
+    memcpy(out, log.data(), sizeof(float) * 16 * std::min(n, max_rays));
+    return n;
 }
 
 // Splat (sample, Li) pairs into a film in order: ImageTile::addSample.
