@@ -57,6 +57,17 @@ struct DevTriShade {
     uint32_t flags;   // bit0 has_normal, bit1 has_uv
 };
 
+// Where a triangle sits in the REFERENCE's own BLAS over its mesh (BVH::buildLinearBVH, GoblinBVH.cpp:81-151: median
+// split by std::nth_element along the longest axis of the centroid bounds, one triangle per leaf).  The device does not
+// traverse that tree, but its visiting order -- near child first by the ray's sign on the split axis -- decides which of
+// two triangles wins when a ray meets their shared edge at exactly the same t (`t <= maxt`, the later test wins).
+struct DevTriOrder {
+    uint32_t path;       // bit l: the triangle is in the second child at depth l (bit 0 = the root's split)
+    uint32_t axes_lo;    // 2 bits per depth: the split axis there (depths 0-15)
+    uint32_t axes_hi;    // depths 16-31
+    uint32_t depth_rank; // depth of its leaf | position inside a multi-triangle leaf << 8
+};
+
 struct DevInstance {
     float m[12];      // toWorld rows 0..2 (3x4)
     float inv[12];    // inverse rows 0..2 (3x4)
@@ -150,6 +161,7 @@ struct DevScene {
     const DevNode* nodes;
     const DevTri* tris;
     const DevTriShade* tri_shade;
+    const DevTriOrder* tri_order;   // per original triangle id (DevTri::shade); null: ties fall to the device's own order
     const float* normals;    // 3 per vertex
     const float* uvs;        // 2 per vertex
     const DevInstance* instances;

@@ -271,6 +271,22 @@ __device__ __forceinline__ bool disk_test(float radius, F3 o, F3 d, float mint, 
     return true;
 }
 
+// Two triangles of one instance accepted at EXACTLY the same t (a ray through their shared edge): the reference keeps
+// whichever its own BLAS visits later (DevTriOrder).  true: `cand` replaces the current hit `cur`.
+__device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, uint32_t cand, F3 d) {
+    const DevTriOrder a = sc.tri_order[sc.tris[cur].shade], b = sc.tri_order[sc.tris[cand].shade];
+    const uint32_t da = a.depth_rank & 0xffu, db = b.depth_rank & 0xffu;
+    const uint32_t common = min(da, db);
+    const uint32_t x = (a.path ^ b.path) & (common >= 32u ? 0xffffffffu : ((1u << common) - 1u));
+    if (x == 0u) return (b.depth_rank >> 8) > (a.depth_rank >> 8);   // one leaf: its triangles are tested in order
+    const uint32_t l = static_cast<uint32_t>(__ffs(static_cast<int>(x))) - 1u;
+    const uint32_t axis = l < 16u ? (a.axes_lo >> (2u * l)) & 3u : (a.axes_hi >> (2u * (l - 16u))) & 3u;
+    const float dc = axis == 0u ? d.x : (axis == 1u ? d.y : d.z);
+    const bool near_is_second = dc < 0.0f;                 // dirIsNeg[axis]: the second child is entered first
+    const bool cand_in_second = ((b.path >> l) & 1u) != 0u;
+    return cand_in_second != near_is_second;               // the far child is visited later
+}
+
 // EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
 // `filter` (EXT builds): GBL_FILTER_* -- instances whose material is / is not a mask are skipped whole, which is
 // what Model::intersect does with the isOpaque / notOpaque IntersectFilter (GoblinModel.cpp:30-32, 44-46).
@@ -328,6 +344,8 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, co
                 *occluded = true;
                 return true;
             }
+            if (t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr && !tie_goes_to(sc, st.hit.tri, first + i, st.r.d))
+                continue;
             st.maxt = t;
             st.hit.t = t;
             st.hit.inst = st.inst;

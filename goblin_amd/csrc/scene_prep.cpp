@@ -531,6 +531,62 @@ int floor_i(float f) { return static_cast<int>(std::floor(f)); }
 
 }  // namespace
 
+// BVH::buildLinearBVH (GoblinBVH.cpp:81-151) with the EqualCount split, followed only as far as the SHAPE of the tree:
+// per triangle the root-to-leaf path, the split axes along it and its place in a multi-triangle leaf.
+namespace {
+struct RefItem {   // BVHPrimitiveInfo (:8-14)
+    float lo[3], hi[3], c[3];
+    uint32_t id;
+};
+void reference_order_rec(std::vector<RefItem>& it, uint32_t start, uint32_t end, uint32_t depth, uint32_t path, uint64_t axes,
+                         DevTriOrder* out) {
+    auto leaf = [&]() {
+        for (uint32_t i = start; i < end; ++i) {
+            DevTriOrder& o = out[it[i].id];
+            o.path = path;
+            o.axes_lo = static_cast<uint32_t>(axes);
+            o.axes_hi = static_cast<uint32_t>(axes >> 32);
+            o.depth_rank = depth | ((i - start) << 8);
+        }
+    };
+    if (end - start == 1 || depth >= 32) return leaf();
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = start; i < end; ++i)
+        for (int k = 0; k < 3; ++k) {
+            clo[k] = std::min(clo[k], it[i].c[k]);
+            chi[k] = std::max(chi[k], it[i].c[k]);
+        }
+    const float dx = chi[0] - clo[0], dy = chi[1] - clo[1], dz = chi[2] - clo[2];
+    const int dim = (dx > dy && dx > dz) ? 0 : (dy > dz ? 1 : 2);   // BBox::longestAxis, GoblinBBox.cpp:79-88
+    if (clo[dim] == chi[dim]) return leaf();
+    const uint32_t mid = (start + end) / 2;
+    std::nth_element(&it[start], &it[mid], &it[end - 1] + 1, [dim](const RefItem& a, const RefItem& b) { return a.c[dim] < b.c[dim]; });
+    axes |= static_cast<uint64_t>(dim) << (2 * depth);
+    reference_order_rec(it, start, mid, depth + 1, path, axes, out);
+    reference_order_rec(it, mid, end, depth + 1, path | (1u << depth), axes, out);
+}
+void reference_order(const float* P, const uint32_t* I, uint32_t n, DevTriOrder* out) {
+    std::vector<RefItem> it(n);
+    for (uint32_t t = 0; t < n; ++t) {
+        RefItem& r = it[t];
+        for (int k = 0; k < 3; ++k) {
+            r.lo[k] = INFINITY;
+            r.hi[k] = -INFINITY;
+        }
+        for (int v = 0; v < 3; ++v) {   // Triangle::getObjectBound: the three vertices' bound
+            const float* p = P + 3 * I[3 * t + v];
+            for (int k = 0; k < 3; ++k) {
+                r.lo[k] = std::min(r.lo[k], p[k]);
+                r.hi[k] = std::max(r.hi[k], p[k]);
+            }
+        }
+        for (int k = 0; k < 3; ++k) r.c[k] = 0.5f * (r.lo[k] + r.hi[k]);
+        r.id = t;
+    }
+    reference_order_rec(it, 0, n, 0, 0u, 0ull, out);
+}
+}   // namespace
+
 gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* err, bool device_blas) {
     if (!d || d->abi_version != GBL_ABI_VERSION) {
         *err = "scene description has the wrong abi_version";
@@ -590,6 +646,15 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     // ---- vertex attributes used at shading time
     out->normals.assign(d->normals, d->normals + 3 * static_cast<size_t>(d->num_vertices));
     out->uvs.assign(d->uvs, d->uvs + 2 * static_cast<size_t>(d->num_vertices));
+
+    // ---- the reference's visiting order of every mesh's triangles (DevTriOrder)
+    out->tri_order.assign(d->num_triangles, DevTriOrder());
+    for (uint32_t mi = 0; mi < d->num_meshes; ++mi) {
+        const gbl_mesh& gm = d->meshes[mi];
+        if (gm.shape != GBL_SHAPE_MESH || gm.tri_count == 0) continue;
+        reference_order(d->positions + 3 * static_cast<size_t>(gm.vertex_offset), d->indices + 3 * static_cast<size_t>(gm.tri_offset),
+                        gm.tri_count, out->tri_order.data() + gm.tri_offset);
+    }
 
     // ---- one BLAS per mesh
     const int kBlasCap = 40;
