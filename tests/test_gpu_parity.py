@@ -227,6 +227,22 @@ def test_native_sampler_matches_oracle_restatement(torch, schedule, name, ov):
     np.testing.assert_allclose(out2["li"].cpu().numpy(), li, rtol=1e-6, atol=1e-7)
 
 
+def test_headline_scene_radiance_is_bit_identical(torch, schedule):
+    """bunny.json (Lambert floor, glass bunny, spot light): every float operation on its paths rounds as on the host --
+    IEEE sqrt / divide, glibc's sinf / cosf restated (refmath.h), the reference's visiting order for exact-t ties -- so
+    the device's per-sample radiance EQUALS the oracle's, not merely approximates it."""
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(160, 160), spp=16, depth=8))
+    o = ob.Oracle(scene)
+    r = make_renderer(scene, schedule)
+    seed = 77
+    samples = o.native_samples(seed)
+    li_ref, _ = o.li_replay(samples, threads=4)
+    li = r.render(seed=seed, want_li=True)["li"].cpu().numpy()
+    same = (li == li_ref).all(axis=1)
+    print("bit-identical samples", int(same.sum()), "of", same.size)
+    assert same.mean() >= 0.99999
+
+
 def test_window_sharding_equals_whole_render(torch, schedule):
     """Tile-sharding property the multi-GPU path relies on: rendering the sample
     window in pieces and summing the films equals rendering it whole."""
