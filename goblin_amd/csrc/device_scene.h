@@ -162,6 +162,7 @@ struct DevScene {
     const DevTri* tris;
     const DevTriShade* tri_shade;
     const DevTriOrder* tri_order;   // per original triangle id (DevTri::shade); null: ties fall to the device's own order
+    const float* positions;         // 3 per vertex, as given: the reference's leaf boxes in a tie (trace.h tie_goes_to)
     const float* normals;    // 3 per vertex
     const float* uvs;        // 2 per vertex
     const DevInstance* instances;

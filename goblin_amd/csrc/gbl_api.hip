@@ -558,6 +558,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if ((st = upload(ctx, packed.tri_shade, &sc.tri_shade)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.tri_order, &sc.tri_order)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.positions, &sc.positions)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.normals, &sc.normals)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.uvs, &sc.uvs)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.instances, &sc.instances)) != GBL_OK) return bail(st);

@@ -271,9 +271,33 @@ __device__ __forceinline__ bool disk_test(float radius, F3 o, F3 d, float mint, 
     return true;
 }
 
-// Two triangles of one instance accepted at EXACTLY the same t (a ray through their shared edge): the reference keeps
-// whichever its own BLAS visits later (DevTriOrder).  true: `cand` replaces the current hit `cur`.
-__device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, uint32_t cand, F3 d) {
+// Two triangles of one instance accepted at EXACTLY the same t (a ray through their shared edge or vertex): the
+// reference keeps whichever its own BLAS tests later (DevTriOrder) -- if it gets to test it at all: by then maxt is t,
+// and the box test in front of the later leaf is strict (tMin < maxt, GoblinBVH.cpp:156-187), so a leaf whose box the
+// ray enters exactly AT the hit point (the hit is a corner or an edge of the triangle's bound) is skipped and the
+// earlier triangle stays.
+__device__ __forceinline__ bool ref_leaf_reached(const DevScene& sc, uint32_t tri, F3 o, F3 d, float mint, float maxt) {
+    const DevTriShade sh = sc.tri_shade[sc.tris[tri].shade];
+    const F3 a = load3(sc.positions + 3 * sh.v[0]), b = load3(sc.positions + 3 * sh.v[1]), c = load3(sc.positions + 3 * sh.v[2]);
+    const F3 lo = f3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
+    const F3 hi = f3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+    const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float tmin = ((d.x < 0.0f ? hi.x : lo.x) - o.x) * inv.x;
+    float tmax = ((d.x < 0.0f ? lo.x : hi.x) - o.x) * inv.x;
+    const float tymin = ((d.y < 0.0f ? hi.y : lo.y) - o.y) * inv.y;
+    const float tymax = ((d.y < 0.0f ? lo.y : hi.y) - o.y) * inv.y;
+    if (tymax < tmin || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    const float tzmin = ((d.z < 0.0f ? hi.z : lo.z) - o.z) * inv.z;
+    const float tzmax = ((d.z < 0.0f ? lo.z : hi.z) - o.z) * inv.z;
+    if (tzmax < tmin || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return tmin < maxt && tmax > mint;
+}
+// true: `cand` replaces the current hit `cur` (both accepted at t)
+__device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, uint32_t cand, F3 o, F3 d, float mint, float t) {
     const DevTriOrder a = sc.tri_order[sc.tris[cur].shade], b = sc.tri_order[sc.tris[cand].shade];
     const uint32_t da = a.depth_rank & 0xffu, db = b.depth_rank & 0xffu;
     const uint32_t common = min(da, db);
@@ -284,7 +308,10 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
     const float dc = axis == 0u ? d.x : (axis == 1u ? d.y : d.z);
     const bool near_is_second = dc < 0.0f;                 // dirIsNeg[axis]: the second child is entered first
     const bool cand_in_second = ((b.path >> l) & 1u) != 0u;
-    return cand_in_second != near_is_second;               // the far child is visited later
+    const bool cand_is_later = cand_in_second != near_is_second;   // the far child is visited later
+    // the later one wins if its leaf is reached with maxt == t; its single-triangle leaf's box is the triangle's bound
+    if (cand_is_later) return ref_leaf_reached(sc, cand, o, d, mint, t);
+    return !ref_leaf_reached(sc, cur, o, d, mint, t);
 }
 
 // EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
@@ -344,7 +371,7 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, co
                 *occluded = true;
                 return true;
             }
-            if (t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr && !tie_goes_to(sc, st.hit.tri, first + i, st.r.d))
+            if (t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr && !tie_goes_to(sc, st.hit.tri, first + i, st.r.o, st.r.d, st.mint, t))
                 continue;
             st.maxt = t;
             st.hit.t = t;

@@ -644,6 +644,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     }
 
     // ---- vertex attributes used at shading time
+    out->positions.assign(d->positions, d->positions + 3 * static_cast<size_t>(d->num_vertices));
     out->normals.assign(d->normals, d->normals + 3 * static_cast<size_t>(d->num_vertices));
     out->uvs.assign(d->uvs, d->uvs + 2 * static_cast<size_t>(d->num_vertices));
 

@@ -10,7 +10,8 @@ struct PackedScene {
     std::vector<DevNode> nodes;
     std::vector<DevTri> tris;
     std::vector<DevTriShade> tri_shade;
-    std::vector<DevTriOrder> tri_order;   // empty when no mesh was small enough to get one
+    std::vector<DevTriOrder> tri_order;
+    std::vector<float> positions;         // 3 per vertex
     std::vector<float> normals, uvs;
     std::vector<DevInstance> instances;
     std::vector<DevMaterial> materials;
