@@ -62,6 +62,7 @@ struct gbl_ctx {
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;
+    std::vector<uint32_t> h_light_slots;   // DevLight::wh_n per light (the Whitted quota, host copy for the stream sampler's layout)
     std::vector<gbl_mesh> h_meshes;
     std::vector<gbl_material> h_materials;
     std::vector<float> mesh_lo, mesh_hi;
@@ -228,6 +229,38 @@ gbl_status ensure_li(gbl_ctx* ctx, size_t entries) {
         return GBL_ERR_OOM;
     }
     ctx->wf_li_entries = entries;
+    return GBL_OK;
+}
+
+// GBL_SAMPLES_STREAM: per-workgroup sample-generation scratch and the per-sample image positions the splat reads
+gbl_status ensure_stream_buffers(gbl_ctx* ctx, uint64_t words_per_wg, uint64_t workgroups, uint64_t samples, RenderArgs* ra) {
+    ra->stream_stride = words_per_wg;
+    const uint64_t need = words_per_wg * sizeof(uint32_t) * workgroups;
+    if (need > ctx->stream_scratch_bytes) {
+        if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
+        ctx->stream_scratch = nullptr;
+        ctx->stream_scratch_bytes = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_scratch), need);
+        if (e != hipSuccess) {
+            ctx->error = std::string("hipMalloc(stream scratch): ") + hipGetErrorString(e);
+            return GBL_ERR_OOM;
+        }
+        ctx->stream_scratch_bytes = need;
+    }
+    ra->stream_scratch = ctx->stream_scratch;
+    const uint64_t xy_bytes = samples * 2 * sizeof(float);
+    if (xy_bytes > ctx->stream_xy_bytes) {
+        if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
+        ctx->stream_xy = nullptr;
+        ctx->stream_xy_bytes = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_xy), xy_bytes);
+        if (e != hipSuccess) {
+            ctx->error = std::string("hipMalloc(stream image positions): ") + hipGetErrorString(e);
+            return GBL_ERR_OOM;
+        }
+        ctx->stream_xy_bytes = xy_bytes;
+    }
+    ra->image_xy = ctx->stream_xy;
     return GBL_OK;
 }
 
@@ -572,6 +605,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     sc.tlas_root = packed.tlas_root;
     sc.num_instances = static_cast<int32_t>(packed.instances.size());
     sc.num_lights = static_cast<int32_t>(packed.lights.size());
+    for (const DevLight& l : packed.lights) ctx->h_light_slots.push_back(l.wh_n);
     sc.stack_entries = packed.stack_entries;
     sc.extended = packed.extended;
     sc.has_masks = packed.has_masks;
@@ -933,8 +967,13 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ctx->error = "GBL_SAMPLES_STREAM: the window must consist of whole 8x8 tiles of the full sample window";
             return GBL_ERR_INVALID;
         }
-        const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
-                                             p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
+        StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
+                                       p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
+        if (p->integrator == GBL_INTEGRATOR_WHITTED &&
+            !stream_layout_whitted(L, ra.spp, ra.root, ra.bssrdf_n, ra.bssrdf_n2, sc.num_lights, [&](int i) { return ctx->h_light_slots[i]; })) {
+            ctx->error = "GBL_SAMPLES_STREAM under the Whitted integrator covers up to " + std::to_string(GBL_STREAM_MAX_RUNS - 2) + " lights";
+            return GBL_ERR_UNSUPPORTED;
+        }
         if (static_cast<uint64_t>(sc.stack_entries) * GBL_BLOCK < L.S) {
             ctx->error = "GBL_SAMPLES_STREAM: sample_per_pixel too large for the shuffle scratch";
             return GBL_ERR_UNSUPPORTED;
@@ -972,8 +1011,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     if (p->integrator == GBL_INTEGRATOR_WHITTED) {
         // WhittedRenderer: one lane per camera sample with the recursion's frames in scratch (kernels/whitted.h), then the
         // shared splat kernel
-        if (stream_mode || p->schedule == GBL_SCHEDULE_WAVEFRONT) {
-            ctx->error = "the Whitted integrator runs with the native or replay sampler on the megakernel schedule";
+        if (p->schedule == GBL_SCHEDULE_WAVEFRONT) {
+            ctx->error = "the Whitted integrator has one kernel of its own: there is no wavefront schedule for it";
             return GBL_ERR_UNSUPPORTED;
         }
         if (sc.has_masks != 0 || sc.has_bssrdf != 0) {
@@ -1000,14 +1039,23 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         for (int k = 0; k < 3; ++k)
             if (!wev[k]) HIP_TRY(ctx, hipEventCreate(&wev[k]));
         HIP_TRY(ctx, hipEventRecord(wev[0], stream));
-        auto k_wh = replay ? (want_stats ? whitted_kernel<true, true> : whitted_kernel<true, false>)
-                           : (want_stats ? whitted_kernel<false, true> : whitted_kernel<false, false>);
-        const size_t lds_wh = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+        auto k_wh = stream_mode ? (want_stats ? whitted_stream_kernel<true> : whitted_stream_kernel<false>)
+                    : replay    ? (want_stats ? whitted_kernel<true, true> : whitted_kernel<true, false>)
+                                : (want_stats ? whitted_kernel<false, true> : whitted_kernel<false, false>);
+        size_t lds_wh = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+        if (stream_mode) lds_wh += (4 + GBL_STREAM_LDS_WORDS) * sizeof(uint32_t);
         if (lds_wh > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_wh), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds_wh)));
         const uint64_t total = static_cast<uint64_t>(ra.local_tiles) * 64 * ra.spp;
-        const uint64_t blocks = std::min<uint64_t>((total + GBL_BLOCK - 1) / GBL_BLOCK, static_cast<uint64_t>(ctx->num_cus) * 8);
+        uint64_t blocks = std::min<uint64_t>((total + GBL_BLOCK - 1) / GBL_BLOCK, static_cast<uint64_t>(ctx->num_cus) * 8);
+        if (stream_mode) {   // one workgroup per tile in flight, each with its sample-generation scratch
+            blocks = std::min<uint64_t>(static_cast<uint64_t>(ra.local_tiles), static_cast<uint64_t>(ctx->num_cus) * 4);
+            StreamLayout L;
+            stream_layout_whitted(L, ra.spp, ra.root, ra.bssrdf_n, ra.bssrdf_n2, sc.num_lights, [&](int i) { return ctx->h_light_slots[i]; });
+            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L), blocks, entries, &ra);
+            if (sst != GBL_OK) return sst;
+        }
         hipLaunchKernelGGL(k_wh, dim3(static_cast<unsigned>(blocks)), dim3(GBL_BLOCK), lds_wh, stream, sc, ra, li);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(wev[1], stream));
@@ -1096,33 +1144,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                                     : (ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>);
             const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
                                                  p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
-            ra.stream_stride = stream_scratch_words(L);
-            const uint64_t need = ra.stream_stride * sizeof(uint32_t) * grid64;
-            if (need > ctx->stream_scratch_bytes) {
-                if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
-                ctx->stream_scratch = nullptr;
-                ctx->stream_scratch_bytes = 0;
-                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_scratch), need);
-                if (e != hipSuccess) {
-                    ctx->error = std::string("hipMalloc(stream scratch): ") + hipGetErrorString(e);
-                    return GBL_ERR_OOM;
-                }
-                ctx->stream_scratch_bytes = need;
-            }
-            ra.stream_scratch = ctx->stream_scratch;
-            const uint64_t xy_bytes = npix * ra.spp * 2 * sizeof(float);
-            if (xy_bytes > ctx->stream_xy_bytes) {
-                if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
-                ctx->stream_xy = nullptr;
-                ctx->stream_xy_bytes = 0;
-                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->stream_xy), xy_bytes);
-                if (e != hipSuccess) {
-                    ctx->error = std::string("hipMalloc(stream image positions): ") + hipGetErrorString(e);
-                    return GBL_ERR_OOM;
-                }
-                ctx->stream_xy_bytes = xy_bytes;
-            }
-            ra.image_xy = ctx->stream_xy;
+            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L), grid64, npix * ra.spp, &ra);
+            if (sst != GBL_OK) return sst;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = replay ? (want_stats ? path_trace_kernel<true, true, true> : (ext ? path_trace_kernel<true, false, true> : path_trace_kernel<true, false, false>))
                             : (want_stats ? path_trace_kernel<false, true, true> : (ext ? path_trace_kernel<false, false, true> : path_trace_kernel<false, false, false>));

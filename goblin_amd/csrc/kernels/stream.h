@@ -28,15 +28,26 @@
 #define GBL_MT_N 624
 #define GBL_MT_M 397
 
+#define GBL_STREAM_MAX_RUNS 16
 struct StreamLayout {
     uint32_t S, root;               // samples per pixel and its root
-    // the quota as runs of patterns: s1 one-slot 1D patterns then g1 1D patterns of nb slots; likewise 2D
-    uint32_t s1, g1, nb, s2, g2, nb2;
+    // the quota as runs of equally sized patterns, in request order: count r?c[i] patterns of r?n[i] slots each
+    uint32_t nr1, nr2;
+    uint32_t r1c[GBL_STREAM_MAX_RUNS], r1n[GBL_STREAM_MAX_RUNS], r2c[GBL_STREAM_MAX_RUNS], r2n[GBL_STREAM_MAX_RUNS];
     uint32_t F1, F2;                // total 1D / 2D slots
     uint32_t NF, NU;                // float / uint draws per pixel
     uint32_t ncols;                 // shuffled columns: lens, then every 1D slot, then every 2D slot
     uint32_t dims;
 };
+__host__ __device__ inline void stream_layout_finish(StreamLayout& L) {
+    L.F1 = L.F2 = 0u;
+    for (uint32_t i = 0; i < L.nr1; ++i) L.F1 += L.r1c[i] * L.r1n[i];
+    for (uint32_t i = 0; i < L.nr2; ++i) L.F2 += L.r2c[i] * L.r2n[i];
+    L.NF = L.S * (4u + L.F1 + 2u * L.F2);
+    L.NU = L.S * (1u + 2u * L.F1 + 2u * L.F2);
+    L.ncols = 1u + L.F1 + L.F2;
+    L.dims = 4u + L.F1 + 2u * L.F2;
+}
 // path tracer: D x {light 1D, bsdf 1D, pick 1D; light 2D, bsdf 2D} + the BSSRDF block (4 1D and 2 2D patterns of nb / nb2
 // slots); AO (ao != 0): one 2D pattern of `ao` directions (AORenderer::querySampleQuota, GoblinAO.cpp:39-42)
 __host__ __device__ inline StreamLayout stream_layout(int spp, int root, int max_depth, int nb, int nb2, int ao = 0) {
@@ -44,25 +55,39 @@ __host__ __device__ inline StreamLayout stream_layout(int spp, int root, int max
     L.S = static_cast<uint32_t>(spp);
     L.root = static_cast<uint32_t>(root);
     if (ao != 0) {
-        L.s1 = L.g1 = L.nb = 0u;
-        L.s2 = 0u;
-        L.g2 = 1u;
-        L.nb2 = static_cast<uint32_t>(ao);
+        L.nr1 = 0u;
+        L.nr2 = 1u;
+        L.r2c[0] = 1u;
+        L.r2n[0] = static_cast<uint32_t>(ao);
     } else {
-        L.s1 = 3u * static_cast<uint32_t>(max_depth);
-        L.g1 = 4u;
-        L.nb = static_cast<uint32_t>(nb);
-        L.s2 = 2u * static_cast<uint32_t>(max_depth);
-        L.g2 = 2u;
-        L.nb2 = static_cast<uint32_t>(nb2);
+        L.nr1 = 2u;
+        L.r1c[0] = 3u * static_cast<uint32_t>(max_depth); L.r1n[0] = 1u;
+        L.r1c[1] = 4u; L.r1n[1] = static_cast<uint32_t>(nb);
+        L.nr2 = 2u;
+        L.r2c[0] = 2u * static_cast<uint32_t>(max_depth); L.r2n[0] = 1u;
+        L.r2c[1] = 2u; L.r2n[1] = static_cast<uint32_t>(nb2);
     }
-    L.F1 = L.s1 + L.g1 * L.nb;
-    L.F2 = L.s2 + L.g2 * L.nb2;
-    L.NF = L.S * (4u + L.F1 + 2u * L.F2);
-    L.NU = L.S * (1u + 2u * L.F1 + 2u * L.F2);
-    L.ncols = 1u + L.F1 + L.F2;
-    L.dims = 4u + L.F1 + 2u * L.F2;
+    stream_layout_finish(L);
     return L;
+}
+// Whitted renderer (WhittedRenderer::querySampleQuota, GoblinWhitted.cpp:46-70): per light {light 1D, bsdf 1D} and
+// {light 2D, bsdf 2D} of that light's n slots, the pick 1D, the BSSRDF block.  light_n[i] = DevLight::wh_n.
+// Returns false when the lights do not fit GBL_STREAM_MAX_RUNS.
+template <class GetN>
+__host__ __device__ inline bool stream_layout_whitted(StreamLayout& L, int spp, int root, int nb, int nb2, int num_lights, GetN light_n) {
+    L.S = static_cast<uint32_t>(spp);
+    L.root = static_cast<uint32_t>(root);
+    if (num_lights + 2 > GBL_STREAM_MAX_RUNS) return false;
+    L.nr1 = L.nr2 = 0u;
+    for (int i = 0; i < num_lights; ++i) {
+        L.r1c[L.nr1] = 2u; L.r1n[L.nr1++] = light_n(i);
+        L.r2c[L.nr2] = 2u; L.r2n[L.nr2++] = light_n(i);
+    }
+    L.r1c[L.nr1] = 1u; L.r1n[L.nr1++] = 1u;
+    L.r1c[L.nr1] = 4u; L.r1n[L.nr1++] = static_cast<uint32_t>(nb);
+    L.r2c[L.nr2] = 2u; L.r2n[L.nr2++] = static_cast<uint32_t>(nb2);
+    stream_layout_finish(L);
+    return true;
 }
 // words of global scratch one workgroup needs: raw draws, column permutations, records
 __host__ __device__ inline uint64_t stream_scratch_words(const StreamLayout& L) {
@@ -204,7 +229,6 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         t0 = t1;
     }
     // ---- records: sample k takes, in every column, the element its position's permutation points at
-    const uint32_t n1_single = L.s1, n2_single = L.s2;
     const uint32_t* uper = c.raw + L.NF + L.ncols * S;   // in-pattern shuffle draws, F1 + F2 per sample
     for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
         float* rec = c.recs + static_cast<size_t>(k) * L.dims;
@@ -219,53 +243,61 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
             rec[3] = y;
         }
         uint32_t col1 = 0;   // running 1D slot
-        for (uint32_t i = 0; i < n1_single + L.g1; ++i) {
-            const uint32_t n = i < n1_single ? 1u : L.nb;
+        for (uint32_t r = 0; r < L.nr1; ++r) {
+            const uint32_t n = L.r1n[r];
             const float strata = 1.0f / static_cast<float>(n);
             const float sub = strata / static_cast<int>(S);
-            for (uint32_t j = 0; j < n; ++j, ++col1) {
-                const uint32_t p = c.perm[(1u + col1) * S + k];
-                const float off = static_cast<int>(p) + stream_u01(c.raw[4 * S + col1 * S + p]);
-                rec[4 + col1] = j * strata + off * sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
-            }
+            for (uint32_t i = 0; i < L.r1c[r]; ++i)
+                for (uint32_t j = 0; j < n; ++j, ++col1) {
+                    const uint32_t p = c.perm[(1u + col1) * S + k];
+                    const float off = static_cast<int>(p) + stream_u01(c.raw[4 * S + col1 * S + p]);
+                    rec[4 + col1] = j * strata + off * sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
+                }
         }
         uint32_t col2 = 0;   // running 2D slot
-        for (uint32_t i = 0; i < n2_single + L.g2; ++i) {
-            const uint32_t n = i < n2_single ? 1u : L.nb2;
-            for (uint32_t j = 0; j < n; ++j, ++col2) {
-                const uint32_t p = c.perm[(1u + L.F1 + col2) * S + k];
-                const uint32_t e = 4 * S + L.F1 * S + 2 * (col2 * S + p);
-                float x, y;
-                stream_strat2(L, n, j, p, stream_u01(c.raw[e]), stream_u01(c.raw[e + 1]), &x, &y);
-                rec[4 + L.F1 + 2 * col2] = x;
-                rec[4 + L.F1 + 2 * col2 + 1] = y;
-            }
+        for (uint32_t r = 0; r < L.nr2; ++r) {
+            const uint32_t n = L.r2n[r];
+            for (uint32_t i = 0; i < L.r2c[r]; ++i)
+                for (uint32_t j = 0; j < n; ++j, ++col2) {
+                    const uint32_t p = c.perm[(1u + L.F1 + col2) * S + k];
+                    const uint32_t e = 4 * S + L.F1 * S + 2 * (col2 * S + p);
+                    float x, y;
+                    stream_strat2(L, n, j, p, stream_u01(c.raw[e]), stream_u01(c.raw[e + 1]), &x, &y);
+                    rec[4 + L.F1 + 2 * col2] = x;
+                    rec[4 + L.F1 + 2 * col2 + 1] = y;
+                }
         }
         // per-sample shuffles inside each pattern (:185-196); a one-slot pattern swaps its slot with itself
         const uint32_t* us = uper + static_cast<size_t>(k) * (L.F1 + L.F2);
-        if (L.nb > 1u) {
-            for (uint32_t i = 0; i < L.g1; ++i) {
-                float* pat = rec + 4 + n1_single + i * L.nb;
-                const uint32_t* up = us + n1_single + i * L.nb;
-                for (uint32_t m = 0; m < L.nb; ++m) {
-                    const uint32_t other = up[m] % L.nb;
+        uint32_t off1 = 0;
+        for (uint32_t r = 0; r < L.nr1; ++r) {
+            const uint32_t n = L.r1n[r];
+            for (uint32_t i = 0; i < L.r1c[r]; ++i, off1 += n) {
+                if (n <= 1u) continue;
+                float* pat = rec + 4 + off1;
+                const uint32_t* up = us + off1;
+                for (uint32_t m = 0; m < n; ++m) {
+                    const uint32_t other = up[m] % n;
                     const float tmp = pat[m];
                     pat[m] = pat[other];
                     pat[other] = tmp;
                 }
             }
         }
-        if (L.nb2 > 1u) {
-            for (uint32_t i = 0; i < L.g2; ++i) {
-                float* pat = rec + 4 + L.F1 + 2 * (n2_single + i * L.nb2);
-                const uint32_t* up = us + L.F1 + n2_single + i * L.nb2;
-                for (uint32_t m = 0; m < L.nb2; ++m) {
-                    const uint32_t other = up[m] % L.nb2;
-                    const float t0 = pat[2 * m], t1 = pat[2 * m + 1];
+        uint32_t off2 = 0;
+        for (uint32_t r = 0; r < L.nr2; ++r) {
+            const uint32_t n = L.r2n[r];
+            for (uint32_t i = 0; i < L.r2c[r]; ++i, off2 += n) {
+                if (n <= 1u) continue;
+                float* pat = rec + 4 + L.F1 + 2 * off2;
+                const uint32_t* up = us + L.F1 + off2;
+                for (uint32_t m = 0; m < n; ++m) {
+                    const uint32_t other = up[m] % n;
+                    const float t0_ = pat[2 * m], t1_ = pat[2 * m + 1];
                     pat[2 * m] = pat[2 * other];
                     pat[2 * m + 1] = pat[2 * other + 1];
-                    pat[2 * other] = t0;
-                    pat[2 * other + 1] = t1;
+                    pat[2 * other] = t0_;
+                    pat[2 * other + 1] = t1_;
                 }
             }
         }

@@ -117,7 +117,7 @@ __device__ __forceinline__ F3 wh_fold(F3 acc, F3 f, F3 Lr, F3 wi, F3 n) {
 
 template <bool REPLAY, bool STATS, class STK>
 __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleSource& src, F3 o, F3 d, float mint, float image_x, float image_y,
-                         const STK& stk, LaneCounters& cnt) {
+                         const STK& stk, LaneCounters& cnt, uint32_t* draws = nullptr) {
     WhFrame frames[GBL_WHITTED_MAX_DEPTH + 1];
     int depth = 0;
     F3 ret = f3(0, 0, 0);
@@ -146,6 +146,7 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
                 for (uint32_t s = 0; s < n; ++s) {
                     const WhSlots w = wh_slots<REPLAY>(sc, ra, src, li, s);
                     if (STATS) cnt.dims += 6;
+                    if (draws) *draws += 6;   // LightSample ls(rng); BSDFSample bs(rng); before the Sample's values replace them (:487-488)
                     const F3 e = wh_estimate_ld<STATS>(sc, fr, rmat, wo, li, w, stk, cnt);
                     Ld = f3(Ld.x + e.x, Ld.y + e.y, Ld.z + e.z);
                 }
@@ -155,6 +156,7 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
             Li = f3(Li.x + total.x, Li.y + total.y, Li.z + total.z);
             ret = Li;
             if (depth < ra.max_depth) {
+                if (draws) *draws += 6;   // BSDFSample(rng) in specularReflect and in specularRefract (:612, :638)
                 // the two specular requests: Mirror answers the reflection one, Transparent each with the matching lobe at pdf 1
                 WhFrame& F = frames[depth];
                 F.flags = 0u;
@@ -282,6 +284,73 @@ __global__ __launch_bounds__(GBL_BLOCK) void whitted_kernel(DevScene sc, RenderA
         const F3 L = whitted_li<REPLAY, STATS>(sc, ra, src, o, d, mint, image_x, image_y, stk, cnt);
         out[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
         paths_done += 1;
+    }
+    if (STATS) accumulate_stats(ra, cnt, paths_done);
+}
+
+// The Whitted renderer under GBL_SAMPLES_STREAM: the tile walk of path_trace_kernel<.., STREAM> (kernels/stream.h) around
+// whitted_li -- one workgroup per tile, per pixel the reference's records generated from the tile's mt19937, the S
+// samples traced, and the stream moved past the 6 floats per (light, slot) and 6 per specular level they discarded.
+template <bool STATS>
+__global__ __launch_bounds__(GBL_BLOCK) void whitted_stream_kernel(DevScene sc, RenderArgs ra, float4* out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* stack = ctrl + 4 + GBL_STREAM_LDS_WORDS;
+    const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
+    StreamLayout slay;
+    stream_layout_whitted(slay, ra.spp, ra.root, ra.bssrdf_n, ra.bssrdf_n2, sc.num_lights, [&](int i) { return sc.lights[i].wh_n; });
+    StreamCtx scx;
+    scx.mt = ctrl + 4;
+    scx.pos = ctrl + 4 + GBL_MT_N;
+    scx.lperm = stack;
+    scx.lperm_words = static_cast<uint32_t>(sc.stack_entries) * GBL_BLOCK;
+    scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
+    scx.perm = scx.raw + slay.NF + slay.NU;
+    scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+    LaneCounters cnt = {};
+    uint32_t paths_done = 0;
+    const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles);
+    const int sub_w = ra.window[1] - ra.window[0];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) ctrl[0] = atomicAdd(ra.work_counter, 1u);
+        __syncthreads();
+        const uint32_t item = ctrl[0];
+        if (item >= n_items) break;
+        const ItemInfo tile_item = decode_item(ra, item);
+        const int ftx = (tile_item.px0 - sc.film.window[0]) / GBL_TILE, fty = (tile_item.py0 - sc.film.window[2]) / GBL_TILE;
+        mt_seed(scx, ra.tile_seeds[fty * ra.full_tiles_x + ftx]);
+        for (int sub = 0; sub < tile_item.tw * tile_item.th; ++sub) {
+            const int px = tile_item.px0 + sub % tile_item.tw, py = tile_item.py0 + sub / tile_item.tw;
+            stream_generate_pixel(scx, slay, px, py);
+            if (threadIdx.x == 0) ctrl[2] = 0u;
+            __syncthreads();
+            uint32_t draws = 0;
+            for (uint32_t k = threadIdx.x; k < static_cast<uint32_t>(ra.spp); k += GBL_BLOCK) {
+                SampleSource src;
+                src.spp = ra.spp;
+                src.root = ra.root;
+                src.pixel_key = 0;
+                src.k = k;
+                src.rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+                const uint32_t out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + k;
+                const float image_x = src.rec[0], image_y = src.rec[1];
+                ra.image_xy[2 * static_cast<size_t>(out_index)] = image_x;
+                ra.image_xy[2 * static_cast<size_t>(out_index) + 1] = image_y;
+                if (STATS) cnt.dims += 2;
+                F3 o, d;
+                float mint;
+                camera_ray<true>(sc.camera, image_x, image_y, src.rec[2], src.rec[3], &o, &d, &mint);
+                const F3 L = whitted_li<true, STATS>(sc, ra, src, o, d, mint, image_x, image_y, stk, cnt, &draws);
+                out[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+                paths_done += 1;
+            }
+            if (draws) atomicAdd(ctrl + 2, draws);
+            __syncthreads();
+            const uint32_t drawn = ctrl[2];
+            __syncthreads();
+            stream_emit(scx, nullptr, drawn);
+        }
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
 }

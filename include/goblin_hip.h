@@ -328,7 +328,7 @@ typedef enum gbl_sample_mode {
      * The Film accumulators then equal the reference binary's (glibc /
      * libstdc++ build) up to float summation order, with nothing uploaded.
      * A tile is sequential by construction -- this is the bit-faithful mode,
-     * NATIVE the fast one.  Megakernel schedule only;
+     * NATIVE the fast one.  All three integrators, megakernel schedule only;
      * the window must be whole tiles of the full sample window. */
     GBL_SAMPLES_STREAM = 2
 } gbl_sample_mode;

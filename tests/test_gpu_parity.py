@@ -131,7 +131,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
-                                  "subsurface_pt", "subsurface_n9"])
+                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
     """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
     Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators
