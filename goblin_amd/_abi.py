@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 7
+GBL_ABI_VERSION = 8
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM = range(6)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM"}
@@ -87,6 +87,15 @@ class gbl_render_setting(C.Structure):
                 ("bssrdf_sample_num", C.c_int32), ("ao_sample_num", C.c_int32), ("thread_num", C.c_int32)]
 
 
+class gbl_volume(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("attenuation", C.c_float * 3), ("albedo", C.c_float * 3), ("emission", C.c_float * 3),
+                ("g", C.c_float), ("sample_num", C.c_int32), ("box_min", C.c_float * 3), ("box_max", C.c_float * 3),
+                ("to_world", gbl_trs)]
+
+
+GBL_VOLUME_NONE, GBL_VOLUME_HOMOGENEOUS = 0, 1
+
+
 class gbl_scene_desc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32),
                 ("num_vertices", C.c_uint32), ("positions", C.POINTER(C.c_float)),
@@ -97,7 +106,7 @@ class gbl_scene_desc(C.Structure):
                 ("num_textures", C.c_uint32), ("textures", C.POINTER(gbl_texture)),
                 ("num_instances", C.c_uint32), ("instances", C.POINTER(gbl_instance)),
                 ("num_lights", C.c_uint32), ("lights", C.POINTER(gbl_light)),
-                ("camera", gbl_camera), ("film", gbl_film), ("setting", gbl_render_setting)]
+                ("camera", gbl_camera), ("film", gbl_film), ("setting", gbl_render_setting), ("volume", gbl_volume)]
 
 
 class gbl_render_params(C.Structure):

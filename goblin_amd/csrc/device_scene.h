@@ -80,6 +80,11 @@ struct DevInstance {
     uint32_t is_mask;   // the material is a MaskMaterial (its type carries BSDFnullptr): what isOpaque / notOpaque filter on
     int32_t pad;
 };
+// InstancedPrimitive's world bound (Transform::onBBox of the mesh bound): the reference's TLAS leaf box.  Kept apart
+// from DevInstance (128 B, one cache line per traversal step); only the medium's self-occlusion rule reads it.
+struct DevInstanceBound {
+    float lo[3], hi[3];
+};
 // IntersectFilter of a scene query (GoblinPathtracer.cpp:5-11): none, isOpaque (skip masks), notOpaque (masks only)
 #define GBL_FILTER_NONE 0
 #define GBL_FILTER_OPAQUE 1
@@ -139,6 +144,21 @@ struct DevLight {
     float pad;
 };
 
+// HomogeneousVolumeRegion (GoblinVolume.h:72-112) + what Light::samplePosition needs of the scene (its bounding sphere)
+struct DevVolume {
+    uint32_t on;
+    float attenuation[3];
+    float scatter[3];       // attenuation * albedo
+    float emission[3];
+    float g;
+    int32_t sample_num;
+    float lo[3], hi[3];
+    float m[12], inv[12];
+    float bound_center[3];  // Scene::getBoundingSphere: centre of the scene bound ...
+    float bound_radius;     // ... and its full diagonal (GoblinBBox.h:51-54)
+    float pad[2];
+};
+
 struct DevCamera {
     float pos[3];
     float proj00;
@@ -166,6 +186,7 @@ struct DevScene {
     const float* normals;    // 3 per vertex
     const float* uvs;        // 2 per vertex
     const DevInstance* instances;
+    const DevInstanceBound* instance_bounds;
     const DevMaterial* materials;
     const DevTexture* textures;
     const DevLight* lights;
@@ -183,6 +204,7 @@ struct DevScene {
     int32_t wh_slots;             // Whitted quota: sum of the lights' wh_n
     DevCamera camera;
     DevFilm film;
+    DevVolume volume;
 };
 
 struct RenderArgs {
@@ -203,6 +225,7 @@ struct RenderArgs {
     int32_t bssrdf_n;           // BSSRDFSampleIndex::samplesNum: roundToSquare(bssrdf_sample_num)
     int32_t bssrdf_n2;          // size of its 2D patterns (rounded to a square once more)
     const float* sss;           // per-sample Lsubsurface of this render (float4, pixel-major like li_out), or null
+    float* vol;                 // per camera sample {transmittance.rgb, -, Lv.rgb, -} of the medium (2 float4), or null
     // GBL_SAMPLES_STREAM (kernels/stream.h)
     const uint32_t* tile_seeds; // the reference's per-tile mt19937 seeds, row-major over the FULL sample window's tiles
     uint32_t* stream_scratch;   // stream_stride words per workgroup

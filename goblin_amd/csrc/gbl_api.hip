@@ -22,6 +22,7 @@
 #include "kernels/wavefront.h"
 #include "kernels/subsurface.h"
 #include "kernels/whitted.h"
+#include "kernels/volume.h"
 #include "kernels/lbvh.h"
 #include <hipcub/hipcub.hpp>
 #include "scene_prep.h"
@@ -57,6 +58,8 @@ struct gbl_ctx {
     uint64_t stream_scratch_bytes = 0;
     float* stream_xy = nullptr;           // ... and the image position of every camera sample of the call (for the splat)
     uint64_t stream_xy_bytes = 0;
+    float* vol_buf = nullptr;    // per-sample {transmittance, Lv} of the render in flight (scenes with a participating medium)
+    uint64_t vol_entries = 0;
     float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
     uint64_t sss_entries = 0;
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
@@ -591,6 +594,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if ((st = upload(ctx, packed.tri_shade, &sc.tri_shade)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.tri_order, &sc.tri_order)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.instance_bounds, &sc.instance_bounds)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.positions, &sc.positions)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.normals, &sc.normals)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.uvs, &sc.uvs)) != GBL_OK) return bail(st);
@@ -611,6 +615,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     sc.has_masks = packed.has_masks;
     sc.has_bssrdf = packed.has_bssrdf;
     sc.wh_slots = packed.wh_slots;
+    sc.volume = packed.volume;
     sc.camera = packed.camera;
     sc.film = packed.film;
     void* p = nullptr;
@@ -682,8 +687,9 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
     int depth = 0;
     float lo[3], hi[3];
     std::string err;
+    std::vector<DevInstanceBound> bounds;
     gbl_status st = build_tlas(edited.data(), static_cast<uint32_t>(edited.size()), ctx->h_meshes.data(), ctx->h_materials.data(), ctx->mesh_lo.data(),
-                               ctx->mesh_hi.data(), ctx->mesh_root.data(), ctx->tlas_base, &inst, &tlas, &root, &depth, lo, hi, &err);
+                               ctx->mesh_hi.data(), ctx->mesh_root.data(), ctx->tlas_base, &inst, &tlas, &root, &depth, lo, hi, &err, &bounds);
     if (st != GBL_OK) {
         ctx->error = err;
         return st;
@@ -697,6 +703,8 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
     DevScene& sc = ctx->scene;
     if (!inst.empty())
         HIP_TRY(ctx, hipMemcpy(const_cast<DevInstance*>(sc.instances), inst.data(), inst.size() * sizeof(DevInstance), hipMemcpyHostToDevice));
+    if (!bounds.empty())
+        HIP_TRY(ctx, hipMemcpy(const_cast<DevInstanceBound*>(sc.instance_bounds), bounds.data(), bounds.size() * sizeof(DevInstanceBound), hipMemcpyHostToDevice));
     if (!tlas.empty())
         HIP_TRY(ctx, hipMemcpy(const_cast<DevNode*>(sc.nodes) + ctx->tlas_base, tlas.data(), tlas.size() * sizeof(DevNode), hipMemcpyHostToDevice));
     sc.tlas_root = root;
@@ -794,6 +802,7 @@ void gbl_destroy(gbl_ctx* ctx) {
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
     if (ctx->sss_buf) (void)hipFree(ctx->sss_buf);
+    if (ctx->vol_buf) (void)hipFree(ctx->vol_buf);
     if (ctx->stream_seeds) (void)hipFree(ctx->stream_seeds);
     if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
     if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
@@ -1008,6 +1017,40 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     for (int k = 0; k < 3; ++k)
         if (!tev[k]) HIP_TRY(ctx, hipEventCreate(&tev[k]));
     HIP_TRY(ctx, hipEventRecord(tev[0], stream));
+    if (sc.volume.on != 0u) {
+        // the participating medium's {tr, Lv} of every camera sample (kernels/volume.h); the splat applies them
+        if (stream_mode) {
+            ctx->error = "GBL_SAMPLES_STREAM does not cover scenes with a participating medium (its draws follow each sample's Li in the tile's stream)";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        const uint64_t entries = npix * ra.spp;
+        if (entries * 32 > li_budget_bytes(ctx)) {
+            ctx->error = "a scene with a participating medium keeps 32 bytes per camera sample: render this window in smaller pieces";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        if (entries > ctx->vol_entries) {
+            if (ctx->vol_buf) (void)hipFree(ctx->vol_buf);
+            ctx->vol_buf = nullptr;
+            ctx->vol_entries = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->vol_buf), entries * 2 * sizeof(float4));
+            if (e != hipSuccess) {
+                ctx->error = std::string("hipMalloc(medium terms): ") + hipGetErrorString(e);
+                return GBL_ERR_OOM;
+            }
+            ctx->vol_entries = entries;
+        }
+        ra.vol = ctx->vol_buf;
+        auto k_vol = replay ? (want_stats ? vol_kernel<true, true> : vol_kernel<true, false>)
+                            : (want_stats ? vol_kernel<false, true> : vol_kernel<false, false>);
+        const size_t lds_vol = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+        if (lds_vol > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vol), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds_vol)));
+        const uint64_t total = static_cast<uint64_t>(ra.local_tiles) * 64 * ra.spp;
+        const uint64_t blocks = std::min<uint64_t>((total + GBL_BLOCK - 1) / GBL_BLOCK, static_cast<uint64_t>(ctx->num_cus) * 8);
+        hipLaunchKernelGGL(k_vol, dim3(static_cast<unsigned>(blocks)), dim3(GBL_BLOCK), lds_vol, stream, sc, ra);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (p->integrator == GBL_INTEGRATOR_WHITTED) {
         // WhittedRenderer: one lane per camera sample with the recursion's frames in scratch (kernels/whitted.h), then the
         // shared splat kernel
@@ -1070,6 +1113,11 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                                   : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
             const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
             hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), dim3(GBL_BLOCK), lds_tile, stream, sc, ra, wa);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        if (ra.vol && ra.li_out) {   // the caller's per-sample output carries what the tile received: tr * Li + Lv
+            hipLaunchKernelGGL(vol_combine_kernel, dim3(static_cast<unsigned>((entries + 255) / 256)), dim3(256), 0, stream,
+                               reinterpret_cast<float4*>(ra.li_out), reinterpret_cast<const float4*>(ra.vol), entries);
             HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipEventRecord(wev[2], stream));
@@ -1172,6 +1220,10 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                 defer = true;
             }
         }
+        if (sc.volume.on != 0u && !defer) {
+            ctx->error = "a scene with a participating medium needs the per-sample radiance buffer: render this window in smaller pieces";
+            return GBL_ERR_UNSUPPORTED;
+        }
         if (stream_mode && !defer) {
             ctx->error = "GBL_SAMPLES_STREAM keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
@@ -1191,6 +1243,12 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), block, lds_tile, stream, sc, ra, wa);
             HIP_TRY(ctx, hipGetLastError());
         }
+    }
+    if (ra.vol && ra.li_out) {   // the caller's per-sample output carries what the tile received: tr * Li + Lv
+        const uint64_t n_li = npix * ra.spp;
+        hipLaunchKernelGGL(vol_combine_kernel, dim3(static_cast<unsigned>((n_li + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<float4*>(ra.li_out), reinterpret_cast<const float4*>(ra.vol), n_li);
+        HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(tev[2], stream));
     ctx->t_calls += 1;

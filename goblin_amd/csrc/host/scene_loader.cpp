@@ -423,7 +423,7 @@ public:
         if ((st = read_setting()) != GBL_OK) return st;
         if ((st = read_camera()) != GBL_OK) return st;
         if ((st = add_lens()) != GBL_OK) return st;
-        if (root_.find("volume")) return fail(GBL_ERR_UNSUPPORTED, "participating media (\"volume\") are outside the device path");
+        if ((st = read_volume()) != GBL_OK) return st;
         read_geometries();
         read_textures();
         if ((st = read_primitives()) != GBL_OK) return st;
@@ -451,6 +451,32 @@ private:
     const gbl_json::Value* list(const char* key) const {
         const gbl_json::Value* v = root_.find(key);
         return (v && v->kind == gbl_json::Value::Array) ? v : nullptr;
+    }
+
+    // createVolume (GoblinContextLoader.cpp:189-207) + createHomogeneousVolume (GoblinVolume.cpp:343-360)
+    gbl_status read_volume() {
+        gbl_volume& v = s_->desc.volume;
+        memset(&v, 0, sizeof(v));
+        const gbl_json::Value* node = root_.find("volume");
+        if (!node) return GBL_OK;
+        Params p(node);
+        if (p.get_string("type") == "heterogeneous")
+            return fail(GBL_ERR_UNSUPPORTED, "heterogeneous volumes (density grid files) are outside the device path");
+        v.type = GBL_VOLUME_HOMOGENEOUS;   // "homogeneous" and the unknown-type fallback
+        const Vec att = p.get_vec(p.vec3s, "attenuation", vec(0, 0, 0)), alb = p.get_vec(p.vec3s, "albedo", vec(0, 0, 0)),
+                  emi = p.get_vec(p.vec3s, "emission", vec(0, 0, 0)), lo = p.get_vec(p.vec3s, "box_min", vec(0, 0, 0)),
+                  hi = p.get_vec(p.vec3s, "box_max", vec(0, 0, 0));
+        for (int i = 0; i < 3; ++i) {
+            v.attenuation[i] = att.v[i];
+            v.albedo[i] = alb.v[i];
+            v.emission[i] = emi.v[i];
+            v.box_min[i] = lo.v[i];
+            v.box_max[i] = hi.v[i];
+        }
+        v.g = p.get_float("g", 0.0f);
+        v.sample_num = p.get_int("sample_num", 5);
+        read_trs(p, &v.to_world);
+        return GBL_OK;
     }
 
     // createRenderer (GoblinContextLoader.cpp:67-92) + createPathTracer / createAO

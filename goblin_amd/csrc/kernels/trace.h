@@ -276,11 +276,16 @@ __device__ __forceinline__ bool disk_test(float radius, F3 o, F3 d, float mint, 
 // and the box test in front of the later leaf is strict (tMin < maxt, GoblinBVH.cpp:156-187), so a leaf whose box the
 // ray enters exactly AT the hit point (the hit is a corner or an edge of the triangle's bound) is skipped and the
 // earlier triangle stays.
+// static intersect(bbox, ray, invDir, dirIsNeg), GoblinBVH.cpp:156-187: the reference's node test
+__device__ __forceinline__ bool ref_box_reached(F3 lo, F3 hi, F3 o, F3 d, float mint, float maxt);
 __device__ __forceinline__ bool ref_leaf_reached(const DevScene& sc, uint32_t tri, F3 o, F3 d, float mint, float maxt) {
     const DevTriShade sh = sc.tri_shade[sc.tris[tri].shade];
     const F3 a = load3(sc.positions + 3 * sh.v[0]), b = load3(sc.positions + 3 * sh.v[1]), c = load3(sc.positions + 3 * sh.v[2]);
     const F3 lo = f3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
     const F3 hi = f3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+    return ref_box_reached(lo, hi, o, d, mint, maxt);
+}
+__device__ __forceinline__ bool ref_box_reached(F3 lo, F3 hi, F3 o, F3 d, float mint, float maxt) {
     const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float tmin = ((d.x < 0.0f ? hi.x : lo.x) - o.x) * inv.x;
     float tmax = ((d.x < 0.0f ? lo.x : hi.x) - o.x) * inv.x;

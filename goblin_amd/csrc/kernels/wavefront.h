@@ -636,6 +636,14 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
 // wf_splat: one workgroup per owned tile, one lane per PIXEL of the tile (64 lanes of a
 // wave splat 64 different footprints: no same-address LDS atomic storms); the four waves
 // split the samples.  ImageTile::addSample (GoblinFilm.cpp:61-90).
+// RenderTask::run: what the tile receives is w * (tr * L + Lv), w = 1 -- the medium's two terms come from vol_kernel
+// (kernels/volume.h), per camera sample of the call
+__device__ __forceinline__ float4 wf_apply_medium(const RenderArgs& ra, float4 L, size_t sample) {
+    if (ra.vol == nullptr) return L;
+    const float4 tr = reinterpret_cast<const float4*>(ra.vol)[2 * sample], lv = reinterpret_cast<const float4*>(ra.vol)[2 * sample + 1];
+    return make_float4(1.0f * (tr.x * L.x + lv.x), 1.0f * (tr.y * L.y + lv.y), 1.0f * (tr.z * L.z + lv.z), L.w);
+}
+
 // ---------------------------------------------------------------------------
 template <bool REPLAY, bool STATS>
 __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra, WfArgs wa) {
@@ -679,7 +687,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
                 float u, v;
                 src.native_2d(0u, 1u, 0u, false, &u, &v);
                 const float image_x = px + u, image_y = py + v;
-                const float4 L = wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk];
+                const float4 L = wf_apply_medium(ra, wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk],
+                                                 static_cast<size_t>(local_pixel) * ra.spp + src.k);
                 if (L.x != L.x || L.y != L.y || L.z != L.z) continue;   // NaN sample: dropped
                 const float dx = image_x - 0.5f, dy = image_y - 0.5f;
                 const int x0 = max(static_cast<int>(ceilf(dx - sc.film.wx)), xlo), x1 = min(static_cast<int>(floorf(dx + sc.film.wx)), xhi);
@@ -739,7 +748,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
                     image_x = px + u;
                     image_y = py + v;
                 }
-                float4 L = wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk];
+                float4 L = wf_apply_medium(ra, wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk],
+                                           static_cast<size_t>(local_pixel) * ra.spp + k);
                 splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, f3(L.x, L.y, L.z), cnt);
             }
         }

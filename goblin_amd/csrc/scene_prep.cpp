@@ -466,8 +466,10 @@ int ceil_i(float f) { return static_cast<int>(std::ceil(f)); }
 // TLAS node k gets device index tlas_base + k; sb_lo/hi return the union of the instance boxes.
 gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* meshes, const gbl_material* materials, const float* mesh_lo,
                       const float* mesh_hi, const int32_t* mesh_root, int32_t tlas_base, std::vector<DevInstance>* out_inst,
-                      std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err) {
+                      std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err,
+                      std::vector<DevInstanceBound>* bounds_out) {
     const int kTlasCap = 22;
+    if (bounds_out) bounds_out->clear();
     out_inst->resize(n);
     out_nodes->clear();
     std::vector<Prim> iprims(n);
@@ -503,6 +505,14 @@ gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* mesh
         }
         for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
         p.id = i;
+        if (bounds_out) {
+            DevInstanceBound wb;
+            for (int k = 0; k < 3; ++k) {
+                wb.lo[k] = p.box.lo[k];
+                wb.hi[k] = p.box.hi[k];
+            }
+            bounds_out->push_back(wb);
+        }
     }
     Aabb scene_bound;
     for (const Prim& p : iprims) {
@@ -739,7 +749,8 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     float sb_lo[3], sb_hi[3];
     {
         gbl_status ts = build_tlas(d->instances, d->num_instances, d->meshes, d->materials, out->mesh_lo.data(), out->mesh_hi.data(),
-                                   mesh_root.data(), out->tlas_base, &out->instances, &tlas, &out->tlas_root, &out->tlas_depth, sb_lo, sb_hi, err);
+                                   mesh_root.data(), out->tlas_base, &out->instances, &tlas, &out->tlas_root, &out->tlas_depth, sb_lo, sb_hi, err,
+                                   &out->instance_bounds);
         if (ts != GBL_OK) return ts;
     }
     for (const DevInstance& di : out->instances)
@@ -1013,6 +1024,32 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         float integral = out->light_cdf[d->num_lights];
         for (uint32_t i = 1; i <= d->num_lights; ++i) out->light_cdf[i] /= integral;
         for (uint32_t i = 0; i < d->num_lights; ++i) out->light_pick_pdf[i] = (power[i] / integral) * dx;
+    }
+
+    // ---- participating medium
+    memset(&out->volume, 0, sizeof(out->volume));
+    if (d->volume.type == GBL_VOLUME_HOMOGENEOUS) {
+        DevVolume& v = out->volume;
+        v.on = 1u;
+        for (int k = 0; k < 3; ++k) {
+            v.attenuation[k] = d->volume.attenuation[k];
+            v.scatter[k] = d->volume.attenuation[k] * d->volume.albedo[k];
+            v.emission[k] = d->volume.emission[k];
+            v.lo[k] = std::min(d->volume.box_min[k], d->volume.box_max[k]);   // BBox(p1, p2), GoblinBBox.h:20-23
+            v.hi[k] = std::max(d->volume.box_min[k], d->volume.box_max[k]);
+            v.bound_center[k] = 0.5f * (scene_bound.lo[k] + scene_bound.hi[k]);
+        }
+        v.g = d->volume.g;
+        v.sample_num = d->volume.sample_num;
+        Trs t = compose(d->volume.to_world.position, d->volume.to_world.orientation, d->volume.to_world.scale);
+        store3x4(t.m, v.m);
+        store3x4(t.inv, v.inv);
+        const float dx = scene_bound.hi[0] - scene_bound.lo[0], dy = scene_bound.hi[1] - scene_bound.lo[1], dz = scene_bound.hi[2] - scene_bound.lo[2];
+        v.bound_radius = std::sqrt(dx * dx + dy * dy + dz * dz);
+        out->extended = 1;
+    } else if (d->volume.type != GBL_VOLUME_NONE) {
+        *err = "unknown volume type";
+        return GBL_ERR_INVALID;
     }
 
     // ---- camera

@@ -10,6 +10,7 @@ struct PackedScene {
     std::vector<DevNode> nodes;
     std::vector<DevTri> tris;
     std::vector<DevTriShade> tri_shade;
+    std::vector<DevInstanceBound> instance_bounds;
     std::vector<DevTriOrder> tri_order;
     std::vector<float> positions;         // 3 per vertex
     std::vector<float> normals, uvs;
@@ -26,6 +27,7 @@ struct PackedScene {
     int32_t has_masks = 0;  // DevScene::has_masks
     int32_t has_bssrdf = 0; // DevScene::has_bssrdf
     int32_t wh_slots = 0;   // DevScene::wh_slots
+    DevVolume volume = {};
     uint64_t blas_nodes = 0, tlas_nodes = 0;
     int blas_max_depth = 0, tlas_depth = 0;
     std::vector<float> mesh_lo, mesh_hi;   // 3 per mesh: object bounds
@@ -45,4 +47,5 @@ gbl_status pack_scene(const gbl_scene_desc* desc, PackedScene* out, std::string*
 // The instance records and the TLAS over them (also used by gbl_update_instances to rebuild after transform edits).
 gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* meshes, const gbl_material* materials, const float* mesh_lo,
                       const float* mesh_hi, const int32_t* mesh_root, int32_t tlas_base, std::vector<DevInstance>* out_inst,
-                      std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err);
+                      std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err,
+                      std::vector<DevInstanceBound>* bounds_out = nullptr);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 7
+#define GBL_ABI_VERSION 8
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -223,6 +223,25 @@ typedef struct gbl_render_setting {
     int32_t thread_num; /* CPU paths only */
 } gbl_render_setting;
 
+/* The scene's participating medium ("volume", GoblinContextLoader.cpp:189-207).  RenderTask::run adds it around the
+ * integrator's radiance for the CAMERA ray only: sample = transmittance * Li + Lv (GoblinRenderer.cpp:40-47), the ray
+ * clipped at the first surface.  Homogeneous regions only (createHomogeneousVolume, GoblinVolume.cpp:343-360);
+ * "heterogeneous" (a density grid file) is GBL_ERR_UNSUPPORTED. */
+typedef enum gbl_volume_type {
+    GBL_VOLUME_NONE = 0,
+    GBL_VOLUME_HOMOGENEOUS = 1
+} gbl_volume_type;
+typedef struct gbl_volume {
+    uint32_t type;          /* gbl_volume_type                                              */
+    float attenuation[3];   /* sigma_t                                                      */
+    float albedo[3];        /* sigma_s = attenuation * albedo                               */
+    float emission[3];
+    float g;                /* Henyey-Greenstein asymmetry ("g", default 0)                 */
+    int32_t sample_num;     /* light samples along the camera ray ("sample_num", default 5) */
+    float box_min[3], box_max[3]; /* the region, in its own space                           */
+    gbl_trs to_world;
+} gbl_volume;
+
 typedef struct gbl_scene_desc {
     uint32_t abi_version; /* GBL_ABI_VERSION */
 
@@ -247,6 +266,7 @@ typedef struct gbl_scene_desc {
     gbl_camera camera;
     gbl_film film;
     gbl_render_setting setting;
+    gbl_volume volume;
 } gbl_scene_desc;
 
 /* ------------------------------------------------------------------------- */

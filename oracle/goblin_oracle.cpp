@@ -478,6 +478,15 @@ struct orc_scene {
     std::vector<Xform> tex_xf;   // SphericalMapping::mToTex per texture
     bool has_masks = false;
     std::vector<uint32_t> light_samples;   // Light::getSamplesNum per light (the Whitted renderer's quota)
+    // HomogeneousVolumeRegion (GoblinVolume.h:72-112)
+    struct Volume {
+        bool on = false;
+        Col attenuation, scatter, emission;
+        float g = 0.0f;
+        int sample_num = 0;
+        Box box;
+        Xform xf;
+    } volume;
     std::vector<Light> lights;
     std::vector<Cdf> light_geo_cdf;   // per light (area only)
     Cdf light_power;
@@ -715,6 +724,20 @@ void prepare(orc_scene* s) {
     s->tlas.build(iboxes);
     // lights
     s->lights.resize(d.num_lights);
+    if (d.volume.type == GBL_VOLUME_HOMOGENEOUS) {
+        orc_scene::Volume& v = s->volume;
+        v.on = true;
+        v.attenuation = Col(d.volume.attenuation[0], d.volume.attenuation[1], d.volume.attenuation[2]);
+        v.scatter = v.attenuation * Col(d.volume.albedo[0], d.volume.albedo[1], d.volume.albedo[2]);   // mScatter(attenuation * albedo)
+        v.emission = Col(d.volume.emission[0], d.volume.emission[1], d.volume.emission[2]);
+        v.g = d.volume.g;
+        v.sample_num = d.volume.sample_num;
+        const float* a = d.volume.box_min;
+        const float* b = d.volume.box_max;
+        v.box.lo = V3(std::min(a[0], b[0]), std::min(a[1], b[1]), std::min(a[2], b[2]));   // BBox(p1, p2), GoblinBBox.h:20-23
+        v.box.hi = V3(std::max(a[0], b[0]), std::max(a[1], b[1]), std::max(a[2], b[2]));
+        v.xf.set(d.volume.to_world.position, d.volume.to_world.orientation, d.volume.to_world.scale);
+    }
     s->light_samples.resize(d.num_lights);
     for (uint32_t i = 0; i < d.num_lights; ++i) s->light_samples[i] = d.lights[i].sample_num;
     std::vector<float> powers;
@@ -2049,6 +2072,7 @@ struct LiCtx {
     int ref_faithful;  // also run the reference's redundant traversals
     Counters cnt;
     uint64_t dims_used = 0;
+    float primary_maxt = INF;   // the camera ray's maxt after Li: Ray::maxt is mutable and the first scene query clips it
 };
 
 // BSDFSample(rng), GoblinMaterial.cpp:26-30 -- three draws whose values never
@@ -2352,7 +2376,9 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
     Hit hit;
     hit.frag.n = V3(0, 0, 0);
     hit.frag.dpdv = V3(0, 0, 0);
-    if (!scene_intersect(s, ray, &hit, &c->cnt)) return Li;   // no IBL lights on this path: evalEnvironmentLight = 0
+    const bool primary_hit = scene_intersect(s, ray, &hit, &c->cnt);
+    c->primary_maxt = ray.maxt;
+    if (!primary_hit) return Li;   // no IBL lights on this path: evalEnvironmentLight = 0
     Li += hit_Le(s, hit, -ray.d);
     Li += l_subsurface(c, hit, -ray.d, rec);   // :69 -- before computeUVDifferential, so its lookups see zero differentials
     Ray cur = ray;
@@ -2485,7 +2511,9 @@ Col ao_li(LiCtx* c, const Ray& primary, const float* rec) {
     Hit hit;
     hit.frag.n = V3(0, 0, 0);
     hit.frag.dpdv = V3(0, 0, 0);
-    if (scene_intersect(s, ray, &hit, &c->cnt)) {
+    const bool primary_hit = scene_intersect(s, ray, &hit, &c->cnt);
+    c->primary_maxt = ray.maxt;
+    if (primary_hit) {
         uint32_t n = static_cast<uint32_t>(round_to_square(c->rs->ao_sample_num));   // SampleIndex.sampleNum
         uint32_t occluded = 0;
         const float* u = rec + c->q->off2[0];
@@ -2586,7 +2614,9 @@ Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* dif
     Hit hit;
     hit.frag.n = V3(0, 0, 0);
     hit.frag.dpdv = V3(0, 0, 0);
-    if (!scene_intersect(s, ray, &hit, &c->cnt)) return Li;   // evalEnvironmentLight = 0 on this path
+    const bool primary_hit = scene_intersect(s, ray, &hit, &c->cnt);
+    if (depth == 0) c->primary_maxt = ray.maxt;
+    if (!primary_hit) return Li;   // evalEnvironmentLight = 0 on this path
     compute_uv_differential(&hit.frag, diff);
     Li += hit_Le(s, hit, -ray.d);
     // Lsubsurface: 0 (no BSSRDF under this integrator's device path)
@@ -2640,9 +2670,183 @@ Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* dif
     return Li;
 }
 
+// ---------------------------------------------------------------------------
+// The participating medium around the camera ray: RenderTask::run's tr * L + Lv (GoblinRenderer.cpp:40-47) with
+// Renderer::transmittance / Renderer::Lv (:298-455, homogeneous branch) over HomogeneousVolumeRegion
+// (GoblinVolume.cpp:12-36, GoblinVolume.h:72-112).  Its random numbers come straight from the tile's generator;
+// without one (replay / native records) they are a hash of the sample's image position, the rule the device's
+// non-stream modes share.
+// ---------------------------------------------------------------------------
+inline uint32_t nat_mix(uint32_t a, uint32_t b);
+inline float nat_u01(uint32_t h);
+struct VolRand {
+    LiCtx* c;
+    uint32_t key, i = 0;
+    VolRand(LiCtx* ctx, const float* rec) : c(ctx) {
+        uint32_t bx, by;
+        memcpy(&bx, rec, 4);
+        memcpy(&by, rec + 1, 4);
+        key = nat_mix(bx, by);
+    }
+    float f() { return c->rng ? c->rng->f() : nat_u01(nat_mix(key, 0x766f6c00u + i++)); }
+};
+inline bool box_intersect(const Box& b, V3 o, V3 d, float mint, float maxt, float* tmin, float* tmax) {   // BBox::intersect, GoblinBBox.cpp:57-77
+    float t0 = mint, t1 = maxt;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z};
+    for (int i = 0; i < 3; ++i) {
+        float inv = 1.0f / dd[i];
+        float tn = (lo[i] - oo[i]) * inv, tf = (hi[i] - oo[i]) * inv;
+        if (tn > tf) std::swap(tn, tf);
+        t0 = (tn > t0) ? tn : t0;
+        t1 = (tf < t1) ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    *tmin = t0;
+    *tmax = t1;
+    return true;
+}
+inline bool vol_intersect(const orc_scene* s, const Ray& r, float* tmin, float* tmax) {   // VolumeRegion::intersect, GoblinVolume.cpp:12-15
+    const auto& v = s->volume;
+    return box_intersect(v.box, v.xf.invert_point(r.o), v.xf.invert_vector(r.d), r.mint, r.maxt, tmin, tmax);
+}
+inline bool vol_contains(const orc_scene* s, V3 p) {   // BBox::contain(invertPoint(p))
+    const auto& v = s->volume;
+    V3 q = v.xf.invert_point(p);
+    return v.box.lo.x <= q.x && q.x <= v.box.hi.x && v.box.lo.y <= q.y && q.y <= v.box.hi.y && v.box.lo.z <= q.z && q.z <= v.box.hi.z;
+}
+inline Col vol_transmittance(const orc_scene* s, const Ray& r) {   // HomogeneousVolumeRegion::transmittance, :25-36
+    float tmin, tmax;
+    if (!vol_intersect(s, r, &tmin, &tmax)) return Col(1.0f);
+    Col tau = length((r.o + tmax * r.d) - (r.o + tmin * r.d)) * s->volume.attenuation;
+    return Col(std::exp(-tau.r), std::exp(-tau.g), std::exp(-tau.b));
+}
+// Light::samplePosition (GoblinLight.cpp:101-108, 161-175, 239-244, 396-409)
+V3 light_sample_position(const orc_scene* s, int li, float u_comp, float u1, float u2) {
+    const Light& l = s->lights[li];
+    if (l.type == GBL_LIGHT_AREA) {
+        const Mesh& m = s->meshes[l.mesh];
+        V3 p_local;
+        if (m.shape == GBL_SHAPE_SPHERE) {
+            p_local = m.radius * uniform_sample_sphere(u1, u2);   // Sphere::sample(u1, u2, &n), GoblinSphere.cpp:103-106
+        } else if (m.shape == GBL_SHAPE_DISK) {
+            float x, y;
+            uniform_sample_disk(u1, u2, &x, &y);                  // Disk::sample, GoblinDisk.cpp:78-82
+            p_local = V3(m.radius * x, m.radius * y, 0.0f);
+        } else {
+            int tri = s->light_geo_cdf[li].sample_discrete(u_comp, nullptr);   // GeometrySet::sample(ls, &n), :326-334
+            float root = sqrtf(u1);
+            float b0 = 1.0f - root, b1 = root * u2;
+            V3 p0 = m.P(m.idx[3 * tri]), p1 = m.P(m.idx[3 * tri + 1]), p2 = m.P(m.idx[3 * tri + 2]);
+            p_local = b0 * p0 + b1 * p1 + (1.0f - b0 - b1) * p2;
+        }
+        return l.xf.on_point(p_local);
+    }
+    if (l.type == GBL_LIGHT_DIRECTIONAL) {
+        // a disc of the scene's bounding sphere, pushed back along the light's direction
+        V3 center = 0.5f * (s->tlas.bounds.lo + s->tlas.bounds.hi);
+        float radius = length(s->tlas.bounds.hi - s->tlas.bounds.lo);
+        V3 z = l.spot_axis, x, y;
+        coordinate_axes(z, &x, &y);
+        float dx, dy;
+        uniform_sample_disk(u1, u2, &dx, &dy);
+        V3 disk = center + radius * (dx * x + dy * y);
+        return disk - z * radius;
+    }
+    return l.pos;
+}
+// Renderer::Lv, homogeneous branch (GoblinRenderer.cpp:298-391)
+Col volume_lv(LiCtx* c, const Ray& ray, VolRand& rnd) {
+    const orc_scene* s = c->s;
+    const auto& vol = s->volume;
+    float tmin, tmax;
+    if (!vol.on || !vol_intersect(s, ray, &tmin, &tmax)) return BLACK;
+    if ((tmax - tmin) < 1e-5f) return BLACK;
+    Col Lv(0.0f);
+    const int n_samples = vol.sample_num;
+    for (int i = 0; i < n_samples; ++i) {
+        float pick = rnd.f();
+        float pick_pdf = 0.0f;
+        int light = s->lights.empty() ? -1 : s->light_power.sample_discrete(pick, &pick_pdf);
+        if (light < 0 || pick_pdf == 0.0f) continue;
+        float e_comp = rnd.f(), e_u1 = rnd.f(), e_u2 = rnd.f();   // LightSample lsEqui(rng)
+        V3 p_light = light_sample_position(s, light, e_comp, e_u1, e_u2);
+        float delta = dot(p_light - ray.o, ray.d);
+        float a = tmin - delta, b = tmax - delta;
+        float D = length(p_light - (ray.o + delta * ray.d));
+        float theta_a = std::atan2(a, D), theta_b = std::atan2(b, D);
+        float ue = rnd.f();
+        float te = D * std::tan((1 - ue) * theta_a + ue * theta_b);            // equiAngularSample, GoblinSampler.h:276-279
+        float pdf_te = D / ((theta_b - theta_a) * (D * D + te * te));          // equiAngularPdf
+        V3 p_e = ray.o + (delta + te) * ray.d;
+        bool in_e = vol_contains(s, p_e);
+        Col sigma_te = in_e ? vol.attenuation : Col(0.0f), scatter_e = in_e ? vol.scatter : Col(0.0f);
+        Col tr_e(std::exp(-sigma_te.r * (te - a)), std::exp(-sigma_te.g * (te - a)), std::exp(-sigma_te.b * (te - a)));
+        {
+            V3 wi;
+            float light_pdf_v;
+            Ray shadow;
+            Col Le = light_sample(s, light, p_e, 0.0f, e_comp, e_u1, e_u2, &wi, &light_pdf_v, &shadow);
+            if (Le != BLACK && light_pdf_v > 0.0f) {
+                if (!scene_occluded(s, shadow, &c->cnt)) {
+                    Col tr_light = vol_transmittance(s, shadow);
+                    Col Ld = tr_light * Le / (pick_pdf * light_pdf_v);
+                    float phase = in_e ? phase_hg(ray.d, wi, vol.g) : 0.0f;   // VolumeRegion::phase(p, wi, wo), GoblinVolume.cpp:17-23
+                    float sig = luminance(sigma_te);
+                    float pdf_td = sig / (std::exp(sig * (te - a)) - std::exp(sig * (te - b)));   // exponentialPdf(t, sigma, a, b)
+                    float mis = power_heuristic(1, pdf_te, 1, pdf_td);
+                    Lv += mis * tr_e * scatter_e * phase * Ld / pdf_te;
+                }
+            }
+        }
+        // distance sampling
+        Col sigma_td = vol_contains(s, ray.o + (0.5f * (tmin + tmax)) * ray.d) ? vol.attenuation : Col(0.0f);
+        float ud = rnd.f();
+        float sig_d = luminance(sigma_td);
+        float td = a - std::log(1.0f - ud * (1.0f - std::exp(sig_d * (a - b)))) / sig_d;   // exponentialSample(u, sigma, a, b)
+        float pdf_td = sig_d / (std::exp(sig_d * (td - a)) - std::exp(sig_d * (td - b)));
+        V3 p_d = ray.o + (delta + td) * ray.d;
+        Col tr_d(std::exp(-sigma_td.r * (td - a)), std::exp(-sigma_td.g * (td - a)), std::exp(-sigma_td.b * (td - a)));
+        bool in_d = vol_contains(s, p_d);
+        Col scatter_d = in_d ? vol.scatter : Col(0.0f);
+        float d_comp = rnd.f(), d_u1 = rnd.f(), d_u2 = rnd.f();   // LightSample lsDistance(rng)
+        {
+            V3 wi;
+            float light_pdf_v;
+            Ray shadow;
+            Col Ldist = light_sample(s, light, p_d, 0.0f, d_comp, d_u1, d_u2, &wi, &light_pdf_v, &shadow);
+            if (Ldist != BLACK && light_pdf_v > 0.0f) {
+                if (!scene_occluded(s, shadow, &c->cnt)) {
+                    Col tr_light = vol_transmittance(s, shadow);
+                    Col Ld = tr_light * Ldist / (pick_pdf * light_pdf_v);
+                    float phase = in_d ? phase_hg(ray.d, wi, vol.g) : 0.0f;
+                    float pdf_te2 = D / ((theta_b - theta_a) * (D * D + td * td));
+                    float mis = power_heuristic(1, pdf_td, 1, pdf_te2);
+                    Lv += mis * tr_d * scatter_d * phase * Ld / pdf_td;
+                }
+            }
+        }
+    }
+    return Lv / static_cast<float>(n_samples);
+}
+// what RenderTask::run adds to the tile for one camera sample: w * (tr * L + Lv), w = 1
+inline Col task_sample(LiCtx* c, const float* rec, Col L) {
+    Col tr(1.0f), Lv(BLACK);
+    if (c->s->volume.on) {
+        Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3], nullptr);
+        ray.maxt = c->primary_maxt;
+        VolRand rnd(c, rec);
+        tr = vol_transmittance(c->s, ray);   // Renderer::transmittance: the homogeneous region draws nothing
+        Lv = volume_lv(c, ray, rnd);
+    }
+    Col TL = tr * L;
+    Col out(TL.r + Lv.r, TL.g + Lv.g, TL.b + Lv.b, TL.a);
+    return 1.0f * out;
+}
+
 inline Col eval_li(LiCtx* c, const float* rec) {
     RayDiff rd;
     Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3], &rd);
+    c->primary_maxt = INF;
     c->dims_used += 2;
     if (c->rs->integrator == GBL_INTEGRATOR_WHITTED) return whitted_li(c, ray, rec, &rd, 0);
     return c->rs->integrator == GBL_INTEGRATOR_AO ? ao_li(c, ray, rec) : path_li(c, ray, rec, &rd);
@@ -2858,6 +3062,7 @@ int32_t orc_li_replay(const orc_scene* s, const gbl_render_setting* rs, const fl
         c.s = s; c.rs = rs; c.q = &q; c.ix = &ix; c.rng = nullptr; c.ref_faithful = 0;
         for (int64_t i = tid; i < n; i += nt) {
             Col L = eval_li(&c, samples + i * dims);
+            if (s->volume.on) L = task_sample(&c, samples + i * dims, L);
             li_out[4 * i] = L.r; li_out[4 * i + 1] = L.g; li_out[4 * i + 2] = L.b; li_out[4 * i + 3] = L.a;
         }
         cnts[tid] = c.cnt;
@@ -2986,12 +3191,9 @@ int32_t orc_render(const orc_scene* s, const gbl_render_setting* rs, int32_t thr
                     for (int k = 0; k < spp; ++k) {
                         const float* rec = recs.data() + static_cast<size_t>(k) * dims;
                         Col L = eval_li(&c, rec);
-                        // RenderTask::run: w * (tr * L + Lv) with w = 1, tr = Color(1), Lv = Black
-                        Col tr(1.0f);
-                        Col TL = tr * L;
-                        Col out(TL.r + 0.0f, TL.g + 0.0f, TL.b + 0.0f, TL.a);
-                        out = 1.0f * out;
+                        Col out = task_sample(&c, rec, L);   // RenderTask::run: w * (tr * L + Lv)
                         add_sample(s, film, rec[0], rec[1], out, &splats[tid]);
+                        if (s->volume.on) L = out;           // with a medium the per-sample output is what the tile receives
                         if (samples_out) memcpy(samples_out + rec_index * dims, rec, dims * sizeof(float));
                         if (li_out) {
                             li_out[4 * rec_index] = L.r; li_out[4 * rec_index + 1] = L.g;

@@ -70,6 +70,9 @@ CASES = {
     # the Whitted renderer: multiSampleLd over every light (per-light sample counts 4, 1, 2 -> 4, 1, 4 slots), specular tree
     "whitted": ("whitted", ov((64, 64), 9, 5), 2048, False),
     "whitted_d2": ("whitted", ov((48, 48), 4, 2), 1024, False),
+    # a homogeneous participating medium around the camera ray: RenderTask's tr * L + Lv (Film only: the probes log Li)
+    "volume_pt": ("volume", ov((64, 64), 9, 5), 0, False),
+    "volume_ao": ("volume", ov((48, 48), 4, method="ao", ao=4), 0, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }

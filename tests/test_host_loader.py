@@ -74,7 +74,7 @@ def test_render_methods():
 
 def test_out_of_scope_features_fail_loudly():
     cases = [
-        minimal(volume={"type": "homogeneous"}),
+        minimal(volume={"type": "heterogeneous", "density_grid": "x.vol"}),
         minimal(lights=[{"type": "ibl", "name": "e", "file": "x.exr"}]),
         minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
         minimal(textures=[{"name": "w", "type": "image", "file": "x.png"}]),
@@ -205,6 +205,20 @@ def test_subsurface_material():
     with pytest.raises(_abi.GoblinError) as e:                          # a mask around a subsurface material
         load(minimal(materials=[{"name": "inner", "type": "subsurface"}, {"name": "m", "type": "mask", "material": "inner"}]))
     assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
+
+
+def test_homogeneous_volume():
+    """createVolume / createHomogeneousVolume (GoblinContextLoader.cpp:189-207, GoblinVolume.cpp:343-360)."""
+    s = load(minimal())
+    assert s.desc.volume.type == _abi.GBL_VOLUME_NONE
+    s = load(minimal(volume={"type": "homogeneous", "attenuation": [0.1, 0.2, 0.3], "albedo": [0.5, 0.6, 0.7], "box_min": [-1.0, -2.0, -3.0],
+                             "box_max": [1.0, 2.0, 3.0], "position": [0.0, 1.0, 0.0]}))
+    v = s.desc.volume
+    assert v.type == _abi.GBL_VOLUME_HOMOGENEOUS and (v.g, v.sample_num) == (0.0, 5)
+    np.testing.assert_allclose(list(v.attenuation) + list(v.albedo), [0.1, 0.2, 0.3, 0.5, 0.6, 0.7], rtol=1e-6)
+    assert list(v.box_min) == [-1, -2, -3] and list(v.box_max) == [1, 2, 3] and list(v.to_world.position) == [0, 1, 0]
+    s = load(minimal(volume={"type": "no such medium"}))                  # unknown type -> homogeneous (:205-207)
+    assert s.desc.volume.type == _abi.GBL_VOLUME_HOMOGENEOUS
 
 
 def test_whitted_quota_follows_the_lights():
