@@ -1019,10 +1019,12 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     HIP_TRY(ctx, hipEventRecord(tev[0], stream));
     if (sc.volume.on != 0u) {
         // the participating medium's {tr, Lv} of every camera sample (kernels/volume.h); the splat applies them
-        if (stream_mode) {
-            ctx->error = "GBL_SAMPLES_STREAM does not cover scenes with a participating medium (its draws follow each sample's Li in the tile's stream)";
+        if (stream_mode && p->integrator != GBL_INTEGRATOR_PATH) {
+            ctx->error = "GBL_SAMPLES_STREAM with a participating medium covers the path tracer (its draws follow each sample's Li in the tile's stream)";
             return GBL_ERR_UNSUPPORTED;
         }
+    }
+    if (sc.volume.on != 0u && !stream_mode) {
         const uint64_t entries = npix * ra.spp;
         if (entries * 32 > li_budget_bytes(ctx)) {
             ctx->error = "a scene with a participating medium keeps 32 bytes per camera sample: render this window in smaller pieces";
@@ -1192,7 +1194,9 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                                     : (ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>);
             const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
                                                  p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
-            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L), grid64, npix * ra.spp, &ra);
+            // a sample's tail in the stream: up to 6 discarded floats per bounce, 9 per light sample of the medium
+            const uint32_t tail = 6u * static_cast<uint32_t>(ra.max_depth) + (sc.volume.on ? 9u * static_cast<uint32_t>(std::max(0, sc.volume.sample_num)) : 0u);
+            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = replay ? (want_stats ? path_trace_kernel<true, true, true> : (ext ? path_trace_kernel<true, false, true> : path_trace_kernel<true, false, false>))

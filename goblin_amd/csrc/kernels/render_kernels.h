@@ -20,6 +20,7 @@
 #include "shade.h"
 #include "stream.h"
 #include "bssrdf.h"
+#include "medium.h"
 #include "trace.h"
 #include "vecmath.h"
 
@@ -281,6 +282,18 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
         scx.perm = scx.raw + slay.NF + slay.NU;
         scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
     }
+    // STREAM with a participating medium: per sample of the pixel {Li's discarded draws, the camera ray's maxt after Li,
+    // offset of its draws in the second emit}, then the raw outputs of that emit (RenderArgs::stream_stride covers them)
+    uint32_t* vol_n = nullptr;
+    float* vol_t = nullptr;
+    uint32_t* vol_off = nullptr;
+    uint32_t* vol_raw = nullptr;
+    if constexpr (STREAM) {
+        vol_n = reinterpret_cast<uint32_t*>(scx.recs + static_cast<size_t>(slay.S) * slay.dims);
+        vol_t = reinterpret_cast<float*>(vol_n + slay.S);
+        vol_off = vol_n + 2 * slay.S;
+        vol_raw = vol_n + 3 * slay.S;
+    }
 
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
@@ -308,6 +321,8 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
             mt_seed(scx, ra.tile_seeds[fty * ra.full_tiles_x + ftx]);
         }
         uint32_t stream_draws = 0;   // STREAM: BSDFSample(rng) floats this lane's paths discarded
+        uint32_t path_draws = 0;     // ... and the path in flight alone
+        float prim_t = INFINITY;     // the camera ray's maxt as Li leaves it (the medium integrates up to there)
         unsigned long long stream_t0 = 0ull;
         const int n_sub = STREAM ? tile_item.tw * tile_item.th : 1;
         for (int sub = 0; sub < n_sub; ++sub) {
@@ -381,6 +396,8 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     ps.bounce = -1;
                     ps.punch = false;
                     ps.path = fetched;
+                    path_draws = 0;
+                    prim_t = INFINITY;
                     active = true;
                     if (STATS) cnt.dims += 2;
                 } else {
@@ -425,6 +442,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     }
                 }
                 if (ps.bounce < 0) {
+                    if (STREAM && got) prim_t = hit.t;
                     if (!got) {
                         finished = true;   // no image based light on this path: evalEnvironmentLight == 0
                     } else {
@@ -552,7 +570,10 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     contrib = l_area ? div(l_f * tr * l_L * l_cos * l_w, l_pdf) : div(l_f * tr * l_L * l_cos, l_pdf);
                 }
                 if (!occluded) ps.Ld = f3(ps.Ld.x + contrib.x, ps.Ld.y + contrib.y, ps.Ld.z + contrib.z);
-                if (STREAM && !occluded) stream_draws += 3;   // evalAttenuation(scene, shadowRay, BSDFSample(rng)), :101-103
+                if (STREAM && !occluded) {   // evalAttenuation(scene, shadowRay, BSDFSample(rng)), :101-103
+                    stream_draws += 3;
+                    path_draws += 3;
+                }
             }
             // ---- BSDF sample: the next ray
             if (active && !finished) {
@@ -572,7 +593,10 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 } else if (!is_black(f) && pdf > 0.0f) {
                     float fw = 1.0f;
                     if (!specular) fw = power_heuristic(pdf, light_pdf<EXT>(sc, sc.lights[ps.light], fr.p, wi));
-                    if (STREAM) stream_draws += 3;   // evalAttenuation(scene, r, BSDFSample(rng)) on either branch, :150 / :159
+                    if (STREAM) {   // evalAttenuation(scene, r, BSDFSample(rng)) on either branch, :150 / :159
+                        stream_draws += 3;
+                        path_draws += 3;
+                    }
                     ps.f = f;
                     ps.fw = fw;
                     ps.bsdf_pdf = pdf;
@@ -613,8 +637,64 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, ps.Li, cnt);
                     if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
                 }
+                if (STREAM && EXT && sc.volume.on != 0u) {
+                    vol_n[src.k] = path_draws;
+                    vol_t[src.k] = prim_t;
+                }
                 active = false;
                 paths_done += 1;
+            }
+        }
+        if constexpr (STREAM && EXT) {
+            if (sc.volume.on != 0u) {
+                // RenderTask::run continues each sample with transmittance(ray) and Lv(ray, rng) (GoblinRenderer.cpp:43-46):
+                // the medium's draws sit in the tile's stream right after that sample's Li draws.  Count them (9 per light
+                // sample when the clipped camera ray crosses the region, the pick alone without lights), emit the
+                // pixel's whole tail, and let every sample read its own slice.
+                __syncthreads();
+                const int px = it.px0, py = it.py0;
+                const uint32_t per = static_cast<uint32_t>(max(0, sc.volume.sample_num)) * (sc.num_lights > 0 ? 9u : 1u);
+                for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
+                    const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+                    F3 o, d;
+                    float mint;
+                    camera_ray<EXT>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
+                    float t0, t1;
+                    const bool crosses = vol_intersect(sc.volume, o, d, mint, vol_t[k], &t0, &t1) && !((t1 - t0) < 1e-5f);
+                    vol_off[k] = crosses ? per : 0u;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t run = 0;
+                    for (uint32_t k = 0; k < slay.S; ++k) {
+                        const uint32_t mine = vol_n[k] + vol_off[k];
+                        vol_off[k] = run + vol_n[k];   // where sample k's medium draws start
+                        run += mine;
+                    }
+                    ctrl[2] = run;
+                }
+                __syncthreads();
+                const uint32_t tail = ctrl[2];
+                __syncthreads();
+                stream_emit(scx, vol_raw, tail);
+                for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
+                    const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+                    F3 o, d;
+                    float mint;
+                    camera_ray<EXT>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
+                    VolRand rnd;
+                    rnd.raw = vol_raw + vol_off[k];
+                    rnd.key = 0u;
+                    rnd.i = 0u;
+                    const F3 tr = vol_transmittance(sc.volume, o, d, mint, vol_t[k]);
+                    const F3 Lv = volume_lv<STATS>(sc, o, d, mint, vol_t[k], rnd, stk, cnt);
+                    const size_t oi = static_cast<size_t>(static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0]))) * ra.spp + k;
+                    float4* q = reinterpret_cast<float4*>(ra.li_defer) + oi;
+                    const float4 L = *q;
+                    *q = make_float4(1.0f * (tr.x * L.x + Lv.x), 1.0f * (tr.y * L.y + Lv.y), 1.0f * (tr.z * L.z + Lv.z), L.w);
+                }
+                __syncthreads();
+                continue;   // next pixel: the stream already stands behind this one's last draw
             }
         }
         if constexpr (STREAM) {

@@ -90,8 +90,10 @@ __host__ __device__ inline bool stream_layout_whitted(StreamLayout& L, int spp, 
     return true;
 }
 // words of global scratch one workgroup needs: raw draws, column permutations, records
-__host__ __device__ inline uint64_t stream_scratch_words(const StreamLayout& L) {
-    return static_cast<uint64_t>(L.NF) + L.NU + static_cast<uint64_t>(L.ncols) * L.S + static_cast<uint64_t>(L.S) * L.dims;
+// tail_per_sample: most outputs one sample can take after its record (the integrator's discarded draws + the medium's)
+__host__ __device__ inline uint64_t stream_scratch_words(const StreamLayout& L, uint32_t tail_per_sample = 0) {
+    return static_cast<uint64_t>(L.NF) + L.NU + static_cast<uint64_t>(L.ncols) * L.S + static_cast<uint64_t>(L.S) * L.dims +
+           static_cast<uint64_t>(L.S) * (3u + tail_per_sample);
 }
 
 #ifdef __HIPCC__

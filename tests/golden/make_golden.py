@@ -73,6 +73,9 @@ CASES = {
     # a homogeneous participating medium around the camera ray: RenderTask's tr * L + Lv (Film only: the probes log Li)
     "volume_pt": ("volume", ov((64, 64), 9, 5), 0, False),
     "volume_ao": ("volume", ov((48, 48), 4, method="ao", ao=4), 0, False),
+    "volume_spot": ("volume", dict(ov((64, 64), 9, 5), lights=[{"name": "spot", "type": "spot", "intensity": [30.0, 32.0, 40.0],
+                                                                "position": [-2.4, 2.6, -1.2], "target": [0.2, 0.6, 0.4],
+                                                                "theta_max": 28.0, "falloff_start": 20.0}]), 0, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }

@@ -170,6 +170,27 @@ def test_stream_mode_edge_sizes(torch, name, res, spp, depth, method):
     assert rel <= 1e-4
 
 
+def test_stream_mode_with_a_participating_medium(golden, torch):
+    """The medium's random numbers are the tile generator's own outputs right after each sample's Li draws: with the
+    stream sampler the device's Film of a fogged scene is the compiled reference's (delta light: to summation order;
+    area lights: up to the emitter self-occlusion coin flips described in DESIGN 4.9)."""
+    from goblin_amd.renderer import HipPathTracer
+    meta, data = golden("volume_spot")
+    scene = gs.load_scene(meta["scene"], meta["overrides"])
+    film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    np.testing.assert_allclose(film[..., 3], data["film"][..., 3], rtol=1e-5, atol=1e-6)
+    rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(data["film"]))
+    print("stream + medium, spot light: film relL2", rel)
+    assert rel <= 1e-5
+    meta, data = golden("volume_pt")
+    scene = gs.load_scene(meta["scene"], meta["overrides"])
+    film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    np.testing.assert_allclose(film[..., 3], data["film"][..., 3], rtol=1e-5, atol=1e-6)   # same samples: the stream stays in step
+    rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(data["film"]))
+    print("stream + medium, area lights: film relL2", rel)
+    assert rel <= 5e-2
+
+
 def test_stream_mode_shards_and_windows(torch):
     """Tiles are independent streams: interleaved tile shards and tile-aligned windows give the whole render's film."""
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(40, 32), spp=4, depth=4))
