@@ -413,7 +413,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                 if (sc.num_lights == 0) {
                     finished = true;   // PathTracer::Li returns Black without lights (:53-56)
                 } else {
-                    got = trace<false, STATS, EXT>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
+                    got = trace<false, STATS, EXT, REPLAY || STATS>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
                     if (STATS) cnt.ext += 1;
                 }
             }

@@ -322,7 +322,11 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 // EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
 // `filter` (EXT builds): GBL_FILTER_* -- instances whose material is / is not a mask are skipped whole, which is
 // what Model::intersect does with the isOpaque / notOpaque IntersectFilter (GoblinModel.cpp:30-32, 44-46).
-template <bool ANY, bool STATS, bool EXT, class STK>
+// TIES: resolve exact ties as the reference's BVH does (tie_goes_to).  The compare sits on the accept path of the loop
+// every ray runs and costs the headline kernel 1.4 % (measured both inlined and as a flag + second pass); the native
+// sampler's lean megakernel therefore compiles it out -- its ties, ~5 per 10^7 paths, fall to the device tree's own
+// order -- while every replay / stream / instrumented build and the wavefront kernels keep it.
+template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
                                            int filter = GBL_FILTER_NONE) {
     const int cur = st.cur;
@@ -376,8 +380,11 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, co
                 *occluded = true;
                 return true;
             }
-            if (t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr && !tie_goes_to(sc, st.hit.tri, first + i, st.r.o, st.r.d, st.mint, t))
+#ifndef GBL_NO_TIE_RULE
+            if (TIES && t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr &&
+                !tie_goes_to(sc, st.hit.tri, first + i, st.r.o, st.r.d, st.mint, t))
                 continue;
+#endif
             st.maxt = t;
             st.hit.t = t;
             st.hit.inst = st.inst;
@@ -404,7 +411,7 @@ __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
 
 // ANY = true : Scene::occluded (first accepted triangle ends the query)
 // ANY = false: Scene::intersect (closest hit; hit.t shrinks like ray.maxt)
-template <bool ANY, bool STATS, bool EXT, class STK>
+template <bool ANY, bool STATS, bool EXT, bool TIES = true, class STK>
 __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
                                       LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
     TravState st;
@@ -419,7 +426,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
         if (trav_at_interior(st)) {
             trav_interior<STATS, !ANY>(sc, st, stk, cnt);
             if (STATS) ++steps;
-        } else if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded, filter)) {
+        } else if (trav_other<ANY, STATS, EXT, STK, TIES>(sc, st, stk, cnt, &occluded, filter)) {
             break;
         }
     }

@@ -295,10 +295,15 @@ def test_headline_scene_radiance_is_bit_identical(torch, schedule):
     seed = 77
     samples = o.native_samples(seed)
     li_ref, _ = o.li_replay(samples, threads=4)
-    li = r.render(seed=seed, want_li=True)["li"].cpu().numpy()
+    li = r.render(replay_samples=samples, want_li=True)["li"].cpu().numpy()
     same = (li == li_ref).all(axis=1)
-    print("bit-identical samples", int(same.sum()), "of", same.size)
-    assert same.mean() >= 0.99999
+    print("bit-identical samples (replay)", int(same.sum()), "of", same.size)
+    assert same.all()
+    # the native sampler draws the same numbers; its lean megakernel leaves exact-t ties (~5 in 10^7 paths) to its own tree
+    li_n = r.render(seed=seed, want_li=True)["li"].cpu().numpy()
+    same_n = (li_n == li_ref).all(axis=1)
+    print("bit-identical samples (native)", int(same_n.sum()), "of", same_n.size)
+    assert same_n.mean() >= 0.99999
 
 
 def test_window_sharding_equals_whole_render(torch, schedule):
@@ -450,9 +455,16 @@ def test_full_size_properties_on_the_headline_config(torch):
     # same arithmetic under both schedules: identical per-sample radiance
     assert torch.equal(li_mk, li_wf)
     del li_wf
-    # determinism
-    again = r.render(seed=seed, want_li=True, schedule="megakernel")["li"]
-    assert torch.equal(li_mk, again)
+    # determinism of the lean kernel the bench times (no counters: the native sampler's build without the tie rule) ...
+    lean = r.render(seed=seed, want_li=True, schedule="megakernel")
+    again, film_lean = lean["li"], lean["film"].numpy()
+    again2 = r.render(seed=seed, want_li=True, schedule="megakernel")["li"]
+    assert torch.equal(again, again2)
+    del again2
+    # ... which differs from the tie-exact builds above only where a ray meets two triangles at exactly equal t
+    differing = int((again != li_mk).any(dim=1).sum())
+    print("lean vs tie-exact megakernel: differing samples", differing, "of", li_mk.shape[0])
+    assert differing <= 2e-6 * li_mk.shape[0]
     del again
     # films: same up to float summation order
     np.testing.assert_allclose(wf["film"].numpy(), film_mk, rtol=1e-4, atol=1e-5)
@@ -460,7 +472,7 @@ def test_full_size_properties_on_the_headline_config(torch):
     film = r.new_film()
     for rank in range(4):
         r.render(film=film, seed=seed, shard=(rank, 4), schedule="megakernel")
-    np.testing.assert_allclose(film.numpy(), film_mk, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(film.numpy(), film_lean, rtol=1e-4, atol=1e-5)
     # the weight channel only depends on where the samples fall
     s1 = _abi.gbl_render_setting.from_buffer_copy(scene.desc.setting)
     s1.max_ray_depth = 1
