@@ -667,7 +667,9 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
     // Native samples lie inside their pixel, so with a filter half-width <= 2 the footprint of every
     // sample of pixel (px,py) is inside the 5x5 block around it: accumulate the lane's samples in
     // registers and touch LDS once per footprint pixel instead of once per sample.
-    const bool fast5 = !REPLAY && sc.film.wx <= 2.0f && sc.film.wy <= 2.0f;
+    // (The stream sampler's records are the reference's own: also inside their pixel; their image positions were kept
+    // in ra.image_xy.  Arbitrary replay records may belong anywhere and take the general path.)
+    const bool fast5 = (!REPLAY || ra.image_xy != nullptr) && sc.film.wx <= 2.0f && sc.film.wy <= 2.0f;
     if (px < ra.window[1] && py < ra.window[3]) {
         SampleSource src;
         src.spp = ra.spp;
@@ -684,9 +686,17 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_splat(DevScene sc, RenderArgs ra
             const int ylo = sc.film.ystart, yhi = sc.film.ystart + sc.film.ycount - 1;
             for (int kk = wave; kk < wa.pass_spp; kk += GBL_BLOCK / 64) {
                 src.k = static_cast<uint32_t>(wa.pass_k0 + kk);
-                float u, v;
-                src.native_2d(0u, 1u, 0u, false, &u, &v);
-                const float image_x = px + u, image_y = py + v;
+                float image_x, image_y;
+                if (REPLAY) {
+                    const float* xy = ra.image_xy + 2 * (static_cast<size_t>(local_pixel) * ra.spp + src.k);
+                    image_x = xy[0];
+                    image_y = xy[1];
+                } else {
+                    float u, v;
+                    src.native_2d(0u, 1u, 0u, false, &u, &v);
+                    image_x = px + u;
+                    image_y = py + v;
+                }
                 const float4 L = wf_apply_medium(ra, wa.li_buf[static_cast<size_t>(local_pixel) * wa.pass_spp + kk],
                                                  static_cast<size_t>(local_pixel) * ra.spp + src.k);
                 if (L.x != L.x || L.y != L.y || L.z != L.z) continue;   // NaN sample: dropped
