@@ -231,7 +231,7 @@ struct RenderArgs {
     uint32_t* stream_scratch;   // stream_stride words per workgroup
     uint64_t stream_stride;
     int32_t full_tiles_x;
-    int32_t pad_stream;
+    uint32_t stream_lperm_words;   // LDS words behind the traversal stacks' base the shuffles may use (>= the stacks' own)
     float* image_xy;            // per camera sample (indexed like li_out): the image position its record held, for the splat
     const float* replay;        // Sample records for the sub-window, pixel-major
     float* li_out;

@@ -988,6 +988,19 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             return GBL_ERR_UNSUPPORTED;
         }
         lds += GBL_STREAM_LDS_WORDS * sizeof(uint32_t);
+        {
+            // the shuffles run one column per lane in the LDS region of the (idle) traversal stacks; widening that region
+            // to 40 KB lets 40 columns of 256 samples go at once (65 columns at config 2: two rounds instead of three)
+            // and still leaves three workgroups per CU
+            const size_t stack_bytes = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            const size_t want = std::max<size_t>(stack_bytes, 40 * 1024);
+            if (lds - stack_bytes + want <= 52 * 1024) {
+                lds += want - stack_bytes;
+                ra.stream_lperm_words = static_cast<uint32_t>(want / sizeof(uint32_t));
+            } else {
+                ra.stream_lperm_words = static_cast<uint32_t>(stack_bytes / sizeof(uint32_t));
+            }
+        }
         const int ftx = (full[1] - full[0] + GBL_TILE - 1) / GBL_TILE, fty = (full[3] - full[2] + GBL_TILE - 1) / GBL_TILE;
         ra.full_tiles_x = ftx;
         if (!ctx->stream_seeds) {
@@ -1088,7 +1101,11 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                     : replay    ? (want_stats ? whitted_kernel<true, true> : whitted_kernel<true, false>)
                                 : (want_stats ? whitted_kernel<false, true> : whitted_kernel<false, false>);
         size_t lds_wh = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-        if (stream_mode) lds_wh += (4 + GBL_STREAM_LDS_WORDS) * sizeof(uint32_t);
+        if (stream_mode) {
+            const size_t want = std::max<size_t>(lds_wh, 40 * 1024);
+            ra.stream_lperm_words = static_cast<uint32_t>(want / sizeof(uint32_t));
+            lds_wh = want + (4 + GBL_STREAM_LDS_WORDS) * sizeof(uint32_t);
+        }
         if (lds_wh > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_wh), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds_wh)));

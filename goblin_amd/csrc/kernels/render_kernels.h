@@ -277,7 +277,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
         scx.mt = ctrl + 4;
         scx.pos = ctrl + 4 + GBL_MT_N;
         scx.lperm = stack;
-        scx.lperm_words = static_cast<uint32_t>(sc.stack_entries) * GBL_BLOCK;
+        scx.lperm_words = ra.stream_lperm_words;
         scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
         scx.perm = scx.raw + slay.NF + slay.NU;
         scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
         scx.mt = ctrl + 4;
         scx.pos = ctrl + 4 + GBL_MT_N;
         scx.lperm = stack;
-        scx.lperm_words = static_cast<uint32_t>(sc.stack_entries) * GBL_BLOCK;
+        scx.lperm_words = ra.stream_lperm_words;
         scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
         scx.perm = scx.raw + slay.NF + slay.NU;
         scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void whitted_stream_kernel(DevScene sc, 
     scx.mt = ctrl + 4;
     scx.pos = ctrl + 4 + GBL_MT_N;
     scx.lperm = stack;
-    scx.lperm_words = static_cast<uint32_t>(sc.stack_entries) * GBL_BLOCK;
+    scx.lperm_words = ra.stream_lperm_words;
     scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
     scx.perm = scx.raw + slay.NF + slay.NU;
     scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
