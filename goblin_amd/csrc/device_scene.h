@@ -230,6 +230,7 @@ struct RenderArgs {
     const uint32_t* tile_seeds; // the reference's per-tile mt19937 seeds, row-major over the FULL sample window's tiles
     uint32_t* stream_scratch;   // stream_stride words per workgroup
     uint64_t stream_stride;
+    uint32_t stream_tail_cap;   // words of a workgroup's scratch behind its records that hold a pixel's medium draws (>= one sample's)
     int32_t full_tiles_x;
     uint32_t stream_lperm_words;   // LDS words behind the traversal stacks' base the shuffles may use (>= the stacks' own)
     float* image_xy;            // per camera sample (indexed like li_out): the image position its record held, for the splat

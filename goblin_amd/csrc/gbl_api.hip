@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1030,13 +1031,9 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     for (int k = 0; k < 3; ++k)
         if (!tev[k]) HIP_TRY(ctx, hipEventCreate(&tev[k]));
     HIP_TRY(ctx, hipEventRecord(tev[0], stream));
-    if (sc.volume.on != 0u) {
-        // the participating medium's {tr, Lv} of every camera sample (kernels/volume.h); the splat applies them
-        if (stream_mode && p->integrator != GBL_INTEGRATOR_PATH) {
-            ctx->error = "GBL_SAMPLES_STREAM with a participating medium covers the path tracer (its draws follow each sample's Li in the tile's stream)";
-            return GBL_ERR_UNSUPPORTED;
-        }
-    }
+    // the participating medium's {tr, Lv} of every camera sample (kernels/volume.h); the splat applies them.  Under
+    // GBL_SAMPLES_STREAM the integrator kernels do it per pixel instead: the medium's draws follow each sample's Li draws
+    // in the tile's stream (stream_medium_phase)
     if (sc.volume.on != 0u && !stream_mode) {
         const uint64_t entries = npix * ra.spp;
         if (entries * 32 > li_budget_bytes(ctx)) {
@@ -1115,7 +1112,21 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             blocks = std::min<uint64_t>(static_cast<uint64_t>(ra.local_tiles), static_cast<uint64_t>(ctx->num_cus) * 4);
             StreamLayout L;
             stream_layout_whitted(L, ra.spp, ra.root, ra.bssrdf_n, ra.bssrdf_n2, sc.num_lights, [&](int i) { return ctx->h_light_slots[i]; });
-            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L), blocks, entries, &ra);
+            // a pixel's tail in the stream when a medium is present: per Li evaluation 6 floats per (light, slot) and 6 for the
+            // two specular children, up to 2^(depth+1) - 1 evaluations per sample, then 9 per light sample of the medium.  The
+            // phase walks the pixel in chunks, so the scratch only has to hold one sample's medium draws; give it the
+            // worst case when that is small, 4 MiB per workgroup otherwise
+            uint32_t tail = 0;
+            if (sc.volume.on != 0u) {
+                uint64_t slots = 0;
+                for (int i = 0; i < sc.num_lights; ++i) slots += ctx->h_light_slots[i];
+                const uint64_t med = 9ull * static_cast<uint64_t>(std::max(0, sc.volume.sample_num)) + 1;
+                const uint64_t worst = ((2ull << std::min(ra.max_depth, 20)) - 1) * (6 * slots + 6) + med;
+                tail = static_cast<uint32_t>(std::max<uint64_t>(med, std::min<uint64_t>(worst, (1ull << 20) / L.S)));
+                if (const char* e = getenv("GBL_STREAM_TAIL")) tail = static_cast<uint32_t>(std::max<uint64_t>(med, strtoull(e, nullptr, 10)));   // tests: force the chunked walk
+            }
+            ra.stream_tail_cap = L.S * tail;
+            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail), blocks, entries, &ra);
             if (sst != GBL_OK) return sst;
         }
         hipLaunchKernelGGL(k_wh, dim3(static_cast<unsigned>(blocks)), dim3(GBL_BLOCK), lds_wh, stream, sc, ra, li);
@@ -1212,8 +1223,13 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
                                                  p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
             // a sample's tail in the stream: up to 6 discarded floats per bounce, 9 per light sample of the medium
-            const uint32_t tail = 6u * static_cast<uint32_t>(ra.max_depth) + (sc.volume.on ? 9u * static_cast<uint32_t>(std::max(0, sc.volume.sample_num)) : 0u);
-            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail), grid64, npix * ra.spp, &ra);
+            const uint32_t tail = (p->integrator == GBL_INTEGRATOR_AO ? 0u : 6u * static_cast<uint32_t>(ra.max_depth)) +
+                                  (sc.volume.on ? 9u * static_cast<uint32_t>(std::max(0, sc.volume.sample_num)) + 1u : 0u);
+            uint32_t tail_words = tail;
+            if (const char* e = getenv("GBL_STREAM_TAIL"))   // tests: force the medium phase's chunked walk
+                if (sc.volume.on) tail_words = std::max<uint32_t>(9u * static_cast<uint32_t>(std::max(0, sc.volume.sample_num)) + 1u, static_cast<uint32_t>(strtoul(e, nullptr, 10)));
+            ra.stream_tail_cap = L.S * tail_words;
+            gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail_words), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = replay ? (want_stats ? path_trace_kernel<true, true, true> : (ext ? path_trace_kernel<true, false, true> : path_trace_kernel<true, false, false>))

@@ -257,6 +257,82 @@ struct PathState {
     bool punch;         // EXT: the ray in flight left a mask surface through its alpha (sampledType == BSDFnullptr)
 };
 
+// GBL_SAMPLES_STREAM with a participating medium.  RenderTask::run continues each sample with transmittance(ray) and
+// Lv(ray, rng) (GoblinRenderer.cpp:43-46), so the medium's draws sit in the tile's stream right after that sample's Li
+// draws.  Per sample of the pixel the integrator leaves {n: the floats its Li discarded, t: the camera ray's maxt as Li
+// left it}; this phase counts the medium's draws (9 per light sample when the clipped camera ray crosses the region, the
+// pick alone without lights), walks the samples in stream order in chunks that fit the scratch -- skipping the first
+// sample's Li draws, emitting the rest of the chunk, letting every sample read its own slice -- and folds
+// 1 * (tr * Li + Lv) into li[].  Ends with the stream behind the pixel's last draw.  Workgroup-uniform.
+struct StreamVol {
+    uint32_t* n;     // [S]
+    float* t;        // [S]
+    uint32_t* off;   // [S]
+    uint32_t* raw;   // [RenderArgs::stream_tail_cap]
+};
+__device__ inline StreamVol stream_vol_scratch(const StreamCtx& scx, const StreamLayout& slay) {
+    StreamVol v;
+    v.n = reinterpret_cast<uint32_t*>(scx.recs + static_cast<size_t>(slay.S) * slay.dims);
+    v.t = reinterpret_cast<float*>(v.n + slay.S);
+    v.off = v.n + 2 * slay.S;
+    v.raw = v.n + 3 * slay.S;
+    return v;
+}
+template <bool STATS, class STK>
+__device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, const StreamCtx& scx, const StreamLayout& slay, const StreamVol& sv,
+                                    uint32_t* ctrl, float4* li, const STK& stk, LaneCounters& cnt) {
+    __syncthreads();
+    const uint32_t per = static_cast<uint32_t>(max(0, sc.volume.sample_num)) * (sc.num_lights > 0 ? 9u : 1u);
+    for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
+        const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+        F3 o, d;
+        float mint;
+        camera_ray<true>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
+        float t0, t1;
+        const bool crosses = vol_intersect(sc.volume, o, d, mint, sv.t[k], &t0, &t1) && !((t1 - t0) < 1e-5f);
+        sv.off[k] = crosses ? per : 0u;
+    }
+    uint32_t k0 = 0;
+    while (k0 < slay.S) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // samples [k0, k1): the first one's Li draws are skipped, not stored
+            uint32_t run = sv.off[k0], k1 = k0 + 1;
+            sv.off[k0] = 0u;
+            while (k1 < slay.S && run + sv.n[k1] + sv.off[k1] <= ra.stream_tail_cap) {
+                const uint32_t mine = sv.off[k1];
+                sv.off[k1] = run + sv.n[k1];   // where sample k1's medium draws start
+                run += sv.n[k1] + mine;
+                k1 += 1;
+            }
+            ctrl[1] = sv.n[k0];
+            ctrl[2] = run;
+            ctrl[3] = k1;
+        }
+        __syncthreads();
+        const uint32_t skip = ctrl[1], total = ctrl[2], k1 = ctrl[3];
+        __syncthreads();
+        stream_emit(scx, nullptr, skip);
+        stream_emit(scx, sv.raw, total);
+        for (uint32_t k = k0 + threadIdx.x; k < k1; k += GBL_BLOCK) {
+            const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+            F3 o, d;
+            float mint;
+            camera_ray<true>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
+            VolRand rnd;
+            rnd.raw = sv.raw + sv.off[k];
+            rnd.key = 0u;
+            rnd.i = 0u;
+            const F3 tr = vol_transmittance(sc.volume, o, d, mint, sv.t[k]);
+            const F3 Lv = volume_lv<STATS>(sc, o, d, mint, sv.t[k], rnd, stk, cnt);
+            const float4 L = li[k];
+            li[k] = make_float4(1.0f * (tr.x * L.x + Lv.x), 1.0f * (tr.y * L.y + Lv.y), 1.0f * (tr.z * L.z + Lv.z), L.w);
+        }
+        k0 = k1;
+    }
+    __syncthreads();
+}
+
 // STREAM (implies REPLAY): the records are the reference's own, generated per pixel from the tile's mt19937
 // (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
 #define GBL_STREAM_LDS_WORDS 640   // 624 state words + cursor, padded
@@ -282,18 +358,8 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
         scx.perm = scx.raw + slay.NF + slay.NU;
         scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
     }
-    // STREAM with a participating medium: per sample of the pixel {Li's discarded draws, the camera ray's maxt after Li,
-    // offset of its draws in the second emit}, then the raw outputs of that emit (RenderArgs::stream_stride covers them)
-    uint32_t* vol_n = nullptr;
-    float* vol_t = nullptr;
-    uint32_t* vol_off = nullptr;
-    uint32_t* vol_raw = nullptr;
-    if constexpr (STREAM) {
-        vol_n = reinterpret_cast<uint32_t*>(scx.recs + static_cast<size_t>(slay.S) * slay.dims);
-        vol_t = reinterpret_cast<float*>(vol_n + slay.S);
-        vol_off = vol_n + 2 * slay.S;
-        vol_raw = vol_n + 3 * slay.S;
-    }
+    StreamVol svol = {};   // STREAM with a participating medium (stream_medium_phase)
+    if constexpr (STREAM) svol = stream_vol_scratch(scx, slay);
 
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
@@ -638,8 +704,8 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
                     if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
                 }
                 if (STREAM && EXT && sc.volume.on != 0u) {
-                    vol_n[src.k] = path_draws;
-                    vol_t[src.k] = prim_t;
+                    svol.n[src.k] = path_draws;
+                    svol.t[src.k] = prim_t;
                 }
                 active = false;
                 paths_done += 1;
@@ -647,53 +713,8 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(Dev
         }
         if constexpr (STREAM && EXT) {
             if (sc.volume.on != 0u) {
-                // RenderTask::run continues each sample with transmittance(ray) and Lv(ray, rng) (GoblinRenderer.cpp:43-46):
-                // the medium's draws sit in the tile's stream right after that sample's Li draws.  Count them (9 per light
-                // sample when the clipped camera ray crosses the region, the pick alone without lights), emit the
-                // pixel's whole tail, and let every sample read its own slice.
-                __syncthreads();
-                const int px = it.px0, py = it.py0;
-                const uint32_t per = static_cast<uint32_t>(max(0, sc.volume.sample_num)) * (sc.num_lights > 0 ? 9u : 1u);
-                for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
-                    const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
-                    F3 o, d;
-                    float mint;
-                    camera_ray<EXT>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
-                    float t0, t1;
-                    const bool crosses = vol_intersect(sc.volume, o, d, mint, vol_t[k], &t0, &t1) && !((t1 - t0) < 1e-5f);
-                    vol_off[k] = crosses ? per : 0u;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    uint32_t run = 0;
-                    for (uint32_t k = 0; k < slay.S; ++k) {
-                        const uint32_t mine = vol_n[k] + vol_off[k];
-                        vol_off[k] = run + vol_n[k];   // where sample k's medium draws start
-                        run += mine;
-                    }
-                    ctrl[2] = run;
-                }
-                __syncthreads();
-                const uint32_t tail = ctrl[2];
-                __syncthreads();
-                stream_emit(scx, vol_raw, tail);
-                for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
-                    const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
-                    F3 o, d;
-                    float mint;
-                    camera_ray<EXT>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
-                    VolRand rnd;
-                    rnd.raw = vol_raw + vol_off[k];
-                    rnd.key = 0u;
-                    rnd.i = 0u;
-                    const F3 tr = vol_transmittance(sc.volume, o, d, mint, vol_t[k]);
-                    const F3 Lv = volume_lv<STATS>(sc, o, d, mint, vol_t[k], rnd, stk, cnt);
-                    const size_t oi = static_cast<size_t>(static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0]))) * ra.spp + k;
-                    float4* q = reinterpret_cast<float4*>(ra.li_defer) + oi;
-                    const float4 L = *q;
-                    *q = make_float4(1.0f * (tr.x * L.x + Lv.x), 1.0f * (tr.y * L.y + Lv.y), 1.0f * (tr.z * L.z + Lv.z), L.w);
-                }
-                __syncthreads();
+                const size_t oi = static_cast<size_t>(static_cast<uint32_t>((it.py0 - ra.window[2]) * sub_w + (it.px0 - ra.window[0]))) * ra.spp;
+                stream_medium_phase<STATS>(sc, ra, scx, slay, svol, ctrl, reinterpret_cast<float4*>(ra.li_defer) + oi, stk, cnt);
                 continue;   // next pixel: the stream already stands behind this one's last draw
             }
         }
@@ -746,6 +767,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
         scx.perm = scx.raw + slay.NF + slay.NU;
         scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
     }
+    StreamVol svol = {};   // STREAM with a participating medium (stream_medium_phase)
+    if constexpr (STREAM) svol = stream_vol_scratch(scx, slay);
 
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
@@ -861,8 +884,18 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
                 splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, L, cnt);
                 if (ra.li_out) reinterpret_cast<float4*>(ra.li_out)[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
             }
+            if (STREAM && EXT && sc.volume.on != 0u) {   // AORenderer::Li draws nothing; scene->intersect clipped the camera ray
+                svol.n[src.k] = 0u;
+                svol.t[src.k] = got ? hit.t : INFINITY;
+            }
             paths_done += 1;
             }   // valid
+        }
+        if constexpr (STREAM && EXT) {
+            if (sc.volume.on != 0u) {
+                const size_t oi = static_cast<size_t>(static_cast<uint32_t>((it.py0 - ra.window[2]) * sub_w + (it.px0 - ra.window[0]))) * ra.spp;
+                stream_medium_phase<STATS>(sc, ra, scx, slay, svol, ctrl, reinterpret_cast<float4*>(ra.li_defer) + oi, stk, cnt);
+            }
         }
         if constexpr (STREAM) __syncthreads();   // every record of this pixel has been read before the next overwrites them
         }   // sub

@@ -117,7 +117,7 @@ __device__ __forceinline__ F3 wh_fold(F3 acc, F3 f, F3 Lr, F3 wi, F3 n) {
 
 template <bool REPLAY, bool STATS, class STK>
 __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleSource& src, F3 o, F3 d, float mint, float image_x, float image_y,
-                         const STK& stk, LaneCounters& cnt, uint32_t* draws = nullptr) {
+                         const STK& stk, LaneCounters& cnt, uint32_t* draws = nullptr, float* prim_t = nullptr) {
     WhFrame frames[GBL_WHITTED_MAX_DEPTH + 1];
     int depth = 0;
     F3 ret = f3(0, 0, 0);
@@ -128,6 +128,7 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
         ret = f3(0, 0, 0);
         if (STATS) cnt.ext += 1;
         if (trace<false, STATS, true>(sc, o, d, mint, INFINITY, stk, hit, cnt)) {
+            if (prim_t && depth == 0) *prim_t = hit.t;   // the camera ray's maxt after scene->intersect
             Frag fr;
             TexFrag tf;
             make_fragment<true>(sc, hit, o, d, fr, &tf);
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void whitted_stream_kernel(DevScene sc, 
     scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
     scx.perm = scx.raw + slay.NF + slay.NU;
     scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+    const StreamVol svol = stream_vol_scratch(scx, slay);   // with a participating medium (stream_medium_phase)
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles);
@@ -341,9 +343,20 @@ __global__ __launch_bounds__(GBL_BLOCK) void whitted_stream_kernel(DevScene sc, 
                 F3 o, d;
                 float mint;
                 camera_ray<true>(sc.camera, image_x, image_y, src.rec[2], src.rec[3], &o, &d, &mint);
-                const F3 L = whitted_li<true, STATS>(sc, ra, src, o, d, mint, image_x, image_y, stk, cnt, &draws);
+                const uint32_t before = draws;
+                float prim_t = INFINITY;
+                const F3 L = whitted_li<true, STATS>(sc, ra, src, o, d, mint, image_x, image_y, stk, cnt, &draws, &prim_t);
                 out[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+                if (sc.volume.on != 0u) {
+                    svol.n[k] = draws - before;
+                    svol.t[k] = prim_t;
+                }
                 paths_done += 1;
+            }
+            if (sc.volume.on != 0u) {
+                const size_t oi = static_cast<size_t>(static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0]))) * ra.spp;
+                stream_medium_phase<STATS>(sc, ra, scx, slay, svol, ctrl, out + oi, stk, cnt);
+                continue;   // next pixel: the stream already stands behind this one's last draw
             }
             if (draws) atomicAdd(ctrl + 2, draws);
             __syncthreads();

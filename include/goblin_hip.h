@@ -345,6 +345,8 @@ typedef enum gbl_sample_mode {
      * GoblinRenderer.cpp:29-52, 99-126), Sampler::requestSamples per pixel
      * (GoblinSampler.cpp:108-197) and the three discarded floats of every
      * BSDFSample(rng) in PathTracer::Li (GoblinPathtracer.cpp:103,150,159).
+     * A participating medium's draws follow each sample's Li draws in the
+     * tile's stream (RenderTask::run, GoblinRenderer.cpp:43-46): carried too.
      * The Film accumulators then equal the reference binary's (glibc /
      * libstdc++ build) up to float summation order, with nothing uploaded.
      * A tile is sequential by construction -- this is the bit-faithful mode,

@@ -42,6 +42,9 @@ def ov(resolution, spp, depth=None, method=None, ao=None, filt=None, crop=None, 
 VN_GEOMS = [{"name": "bunny", "type": "mesh", "file": "models/bunny_vn.obj"},
             {"name": "plane", "type": "mesh", "file": "models/plane.obj"}]
 
+SPOT = [{"name": "spot", "type": "spot", "intensity": [30.0, 32.0, 40.0], "position": [-2.4, 2.6, -1.2], "target": [0.2, 0.6, 0.4],
+         "theta_max": 28.0, "falloff_start": 20.0}]
+
 # name -> (scene, overrides, number of (Sample -> Li) records to keep, with_kat)
 CASES = {
     "bunny_pt": ("bunny", ov((64, 64), 16, 4), 2048, True),
@@ -73,9 +76,11 @@ CASES = {
     # a homogeneous participating medium around the camera ray: RenderTask's tr * L + Lv (Film only: the probes log Li)
     "volume_pt": ("volume", ov((64, 64), 9, 5), 0, False),
     "volume_ao": ("volume", ov((48, 48), 4, method="ao", ao=4), 0, False),
-    "volume_spot": ("volume", dict(ov((64, 64), 9, 5), lights=[{"name": "spot", "type": "spot", "intensity": [30.0, 32.0, 40.0],
-                                                                "position": [-2.4, 2.6, -1.2], "target": [0.2, 0.6, 0.4],
-                                                                "theta_max": 28.0, "falloff_start": 20.0}]), 0, False),
+    "volume_spot": ("volume", dict(ov((64, 64), 9, 5), lights=SPOT), 0, False),
+    # ... under the other two renderers with the delta light alone (the medium's samples are then exact):
+    # AORenderer::Li draws nothing from the tile's generator, WhittedRenderer::Li 6 floats per (light, slot) and per level
+    "volume_ao_spot": ("volume", dict(ov((48, 48), 4, method="ao", ao=4), lights=SPOT), 0, False),
+    "volume_whitted_spot": ("volume", dict(ov((48, 48), 4, 3, method="whitted"), lights=SPOT), 0, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }

@@ -191,6 +191,35 @@ def test_stream_mode_with_a_participating_medium(golden, torch):
     assert rel <= 5e-2
 
 
+@pytest.mark.parametrize("case", ["volume_spot", "volume_whitted_spot"])
+def test_stream_mode_medium_chunked_walk(golden, torch, case, monkeypatch):
+    """A pixel whose tail in the stream outgrows the workgroup's scratch is walked in chunks of samples (the first
+    sample's Li draws skipped, the rest emitted): same Film as the one-chunk walk."""
+    from goblin_amd.renderer import HipPathTracer
+    meta, data = golden(case)
+    scene = gs.load_scene(meta["scene"], meta["overrides"])
+    whole = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    monkeypatch.setenv("GBL_STREAM_TAIL", "1")   # scratch for one sample's medium draws per sample, no room for Li's
+    chunked = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    np.testing.assert_allclose(chunked, whole, rtol=1e-6, atol=1e-7)
+    rel = helpers.rel_l2(ob.normalize_film(chunked), ob.normalize_film(data["film"]))
+    assert rel <= 1e-5
+
+
+@pytest.mark.parametrize("case,tol", [("volume_ao_spot", 1e-5), ("volume_whitted_spot", 1e-5), ("volume_ao", 5e-2)])
+def test_stream_mode_medium_under_ao_and_whitted(golden, torch, case, tol):
+    """RenderTask wraps every renderer's Li in tr * L + Lv: AORenderer::Li leaves the tile's generator alone,
+    WhittedRenderer::Li discards 6 floats per (light, slot) and 6 per recursion level before the medium draws."""
+    from goblin_amd.renderer import HipPathTracer
+    meta, data = golden(case)
+    scene = gs.load_scene(meta["scene"], meta["overrides"])
+    film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    np.testing.assert_allclose(film[..., 3], data["film"][..., 3], rtol=1e-5, atol=1e-6)
+    rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(data["film"]))
+    print(case, "stream + medium film relL2", rel)
+    assert rel <= tol
+
+
 def test_stream_mode_shards_and_windows(torch):
     """Tiles are independent streams: interleaved tile shards and tile-aligned windows give the whole render's film."""
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(40, 32), spp=4, depth=4))
