@@ -230,6 +230,8 @@ struct RenderArgs {
     const uint32_t* tile_seeds; // the reference's per-tile mt19937 seeds, row-major over the FULL sample window's tiles
     uint32_t* stream_scratch;   // stream_stride words per workgroup
     uint64_t stream_stride;
+    uint32_t sss_off1, sss_off2;   // the BSSRDF block of a camera sample's record: first 1D / first 2D float (kernels/bssrdf.h)
+    uint32_t sss_pat1, sss_pat2;   // ... and its first 1D / 2D pattern number under the native sampler
     uint32_t stream_tail_cap;   // words of a workgroup's scratch behind its records that hold a pixel's medium draws (>= one sample's)
     int32_t full_tiles_x;
     uint32_t stream_lperm_words;   // LDS words behind the traversal stacks' base the shuffles may use (>= the stacks' own)

@@ -66,6 +66,7 @@ struct gbl_ctx {
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;
+    bool has_mask_materials = false;       // an instance carries a MaskMaterial
     std::vector<uint32_t> h_light_slots;   // DevLight::wh_n per light (the Whitted quota, host copy for the stream sampler's layout)
     std::vector<gbl_mesh> h_meshes;
     std::vector<gbl_material> h_materials;
@@ -614,6 +615,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     sc.stack_entries = packed.stack_entries;
     sc.extended = packed.extended;
     sc.has_masks = packed.has_masks;
+    ctx->has_mask_materials = packed.has_mask_materials != 0;
     sc.has_bssrdf = packed.has_bssrdf;
     sc.wh_slots = packed.wh_slots;
     sc.volume = packed.volume;
@@ -890,9 +892,17 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ra.off2_base = 4 + 3 * ra.max_depth + 4 * n1;
         ra.bssrdf_n = n1;
         ra.bssrdf_n2 = n2;
+        ra.sss_off1 = static_cast<uint32_t>(4 + 3 * ra.max_depth);
+        ra.sss_off2 = static_cast<uint32_t>(ra.off2_base + 4 * ra.max_depth);
+        ra.sss_pat1 = 3u * static_cast<uint32_t>(ra.max_depth);
+        ra.sss_pat2 = 2u * static_cast<uint32_t>(ra.max_depth);
         if (p->integrator == GBL_INTEGRATOR_WHITTED) {   // per-light patterns instead of per-bounce ones (kernels/whitted.h)
             ra.dims = 4 + 6 * sc.wh_slots + 1 + 4 * n1 + 4 * n2;
             ra.off2_base = 4 + 2 * sc.wh_slots + 1 + 4 * n1;
+            ra.sss_off1 = static_cast<uint32_t>(4 + 2 * sc.wh_slots + 1);
+            ra.sss_off2 = static_cast<uint32_t>(ra.off2_base + 4 * sc.wh_slots);
+            ra.sss_pat1 = 2u * static_cast<uint32_t>(sc.num_lights) + 1u;   // after the per-light ls / bs patterns and pickLight
+            ra.sss_pat2 = 2u * static_cast<uint32_t>(sc.num_lights);
         }
     }
     const int32_t* full = sc.film.window;
@@ -1070,8 +1080,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ctx->error = "the Whitted integrator has one kernel of its own: there is no wavefront schedule for it";
             return GBL_ERR_UNSUPPORTED;
         }
-        if (sc.has_masks != 0 || sc.has_bssrdf != 0) {
-            ctx->error = "the Whitted integrator's device path does not cover mask or subsurface materials";
+        if (ctx->has_mask_materials) {
+            ctx->error = "the Whitted integrator's device path does not cover mask materials";
             return GBL_ERR_UNSUPPORTED;
         }
         if (ra.max_depth > GBL_WHITTED_MAX_DEPTH) {

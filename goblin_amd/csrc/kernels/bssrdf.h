@@ -109,14 +109,16 @@ struct SssSample {   // BSSRDFSample(sample, index, n), GoblinLight.cpp:53-61
     float ls_comp, ls_geo0, ls_geo1, pick_light, pick_axis, disc0, disc1, single;
 };
 // Slot i of the camera sample's BSSRDF block.  Record layout (SampleQuota, GoblinSampler.cpp:23-58): the 1D patterns
-// ls / pickLight / pickAxis / singleScatter follow the 3 D per-bounce ones, the 2D patterns ls / disc the 2 D per-bounce ones.
+// ls / pickLight / pickAxis / singleScatter and the 2D patterns ls / disc follow the integrator's own -- 3 D and 2 D
+// per-bounce ones under the path tracer, 2 per light slot + pickLight and 2 per light slot under Whitted
+// (RenderArgs::sss_off1 / sss_off2, sss_pat1 / sss_pat2).
 template <bool REPLAY>
 __device__ __forceinline__ SssSample sss_sample(const RenderArgs& ra, const SampleSource& src, uint32_t i) {
     SssSample s;
-    const uint32_t D = static_cast<uint32_t>(ra.max_depth), n = static_cast<uint32_t>(ra.bssrdf_n), n2 = static_cast<uint32_t>(ra.bssrdf_n2);
+    const uint32_t n = static_cast<uint32_t>(ra.bssrdf_n), n2 = static_cast<uint32_t>(ra.bssrdf_n2);
     if (REPLAY) {
-        const float* r1 = src.rec + 4 + 3 * D;
-        const float* r2 = src.rec + ra.off2_base + 4 * D;
+        const float* r1 = src.rec + ra.sss_off1;
+        const float* r2 = src.rec + ra.sss_off2;
         s.ls_comp = r1[i];
         s.pick_light = r1[n + i];
         s.pick_axis = r1[2 * n + i];
@@ -126,12 +128,12 @@ __device__ __forceinline__ SssSample sss_sample(const RenderArgs& ra, const Samp
         s.disc0 = r2[2 * n2 + 2 * i];
         s.disc1 = r2[2 * n2 + 2 * i + 1];
     } else {
-        s.ls_comp = src.native_1d_n(3u * D + 0u, n, i);
-        s.pick_light = src.native_1d_n(3u * D + 1u, n, i);
-        s.pick_axis = src.native_1d_n(3u * D + 2u, n, i);
-        s.single = src.native_1d_n(3u * D + 3u, n, i);
-        src.native_2d_slot(0x10000u + 2u * D, n2, i, &s.ls_geo0, &s.ls_geo1);
-        src.native_2d_slot(0x10000u + 2u * D + 1u, n2, i, &s.disc0, &s.disc1);
+        s.ls_comp = src.native_1d_n(ra.sss_pat1 + 0u, n, i);
+        s.pick_light = src.native_1d_n(ra.sss_pat1 + 1u, n, i);
+        s.pick_axis = src.native_1d_n(ra.sss_pat1 + 2u, n, i);
+        s.single = src.native_1d_n(ra.sss_pat1 + 3u, n, i);
+        src.native_2d_slot(0x10000u + ra.sss_pat2, n2, i, &s.ls_geo0, &s.ls_geo1);
+        src.native_2d_slot(0x10000u + ra.sss_pat2 + 1u, n2, i, &s.disc0, &s.disc1);
     }
     return s;
 }
@@ -146,9 +148,11 @@ __device__ __forceinline__ int sss_pick_light(const DevScene& sc, float u, float
     return li;
 }
 
-// the subsurface material `material` resolved at a fragment that has seen no ray differentials
+// the subsurface material `material` resolved at a fragment that has seen no ray differentials (PathTracer::Li runs
+// Lsubsurface before computeUVDifferential) or, KEEP, with the ones the caller computed (WhittedRenderer::Li: after)
+template <bool KEEP = false>
 __device__ __forceinline__ void sss_resolve(const DevScene& sc, int material, const Frag& fr, TexFrag& tf, DevMaterial& out) {
-    uv_differential(fr, tf, false, fr.p, fr.p, fr.p, fr.p);
+    if (!KEEP) uv_differential(fr, tf, false, fr.p, fr.p, fr.p, fr.p);
     resolve_material(sc, sc.materials[material], fr, tf, out);
 }
 

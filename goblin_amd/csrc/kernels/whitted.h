@@ -67,8 +67,9 @@ __device__ __forceinline__ F3 wh_estimate_ld(const DevScene& sc, const Frag& fr,
             }
         }
     }
-    // sampleBSDF(..., BSDFAll & ~BSDFSpecular): Transparent and Mirror do not match (pdf 0); Lambert / Blinn sample as always
-    if (rmat.m.type == GBL_MAT_TRANSPARENT || rmat.m.type == GBL_MAT_MIRROR) return Ld;
+    // sampleBSDF(..., BSDFAll & ~BSDFSpecular): Transparent and Mirror do not match (pdf 0), nor does SubsurfaceMaterial whose
+    // BSDFAll type only matches that very request (GoblinMaterial.cpp:732-736); Lambert / Blinn sample as always
+    if (rmat.m.type == GBL_MAT_TRANSPARENT || rmat.m.type == GBL_MAT_MIRROR || rmat.m.type == GBL_MAT_SUBSURFACE) return Ld;
     F3 wi;
     float pdf;
     bool specular, null_sampled;
@@ -137,6 +138,16 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
             const F3 wo = -d;
             const F3 le = hit_Le(sc, hit.inst, fr.n, wo);
             F3 Li = f3(0.0f + le.x, 0.0f + le.y, 0.0f + le.z);
+            if (sc.has_bssrdf != 0 && sc.num_lights > 0 && sc.materials[material].type == GBL_MAT_SUBSURFACE) {
+                // Li += Lsubsurface(...) with the differentials in place, at every level, always from the camera sample's
+                // one BSSRDF block (GoblinWhitted.cpp:25-27)
+                DevMaterial mo;
+                sss_resolve<true>(sc, material, fr, tf, mo);
+                const F3 single = l_bssrdf_single<REPLAY, STATS>(sc, ra, src, fr, mo, material, wo, stk, cnt);
+                const F3 multi = l_bssrdf_diffusion<REPLAY, STATS>(sc, ra, src, fr, tf, mo, material, wo, stk, cnt);
+                const F3 ss = single + multi;
+                Li = f3(Li.x + ss.x, Li.y + ss.y, Li.z + ss.z);
+            }
             ResolvedMat rmat;
             resolve_hit_material(sc, material, fr, tf, rmat);
             // multiSampleLd: every light, its samplesNum slots averaged

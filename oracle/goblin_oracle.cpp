@@ -2535,7 +2535,11 @@ Col ao_li(LiCtx* c, const Ray& primary, const float* rec) {
 // WhittedRenderer (GoblinWhitted.cpp:13-44) over Renderer::multiSampleLd / estimateLd / specularReflect /
 // specularRefract (GoblinRenderer.cpp:474-648).  Mask and subsurface materials are not restated for this integrator.
 // ---------------------------------------------------------------------------
-inline bool mat_is_specular(const gbl_material& m) { return m.type == GBL_MAT_TRANSPARENT || m.type == GBL_MAT_MIRROR; }
+// materials whose sampleBSDF does not match a BSDFAll & ~BSDFSpecular request: the specular ones, and SubsurfaceMaterial whose
+// type is BSDFAll and only matches that very request (matchType, GoblinMaterial.h:191-193; GoblinMaterial.cpp:732-736)
+inline bool mat_is_specular(const gbl_material& m) {
+    return m.type == GBL_MAT_TRANSPARENT || m.type == GBL_MAT_MIRROR || m.type == GBL_MAT_SUBSURFACE;
+}
 
 // Renderer::estimateLd with type = BSDFAll & ~BSDFSpecular (:502-567)
 Col estimate_ld(LiCtx* c, V3 wo, float epsilon, const Hit& hit, const ResolvedMat& mat, int light, float ls_comp, const float* ls_geo,
@@ -2619,7 +2623,10 @@ Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* dif
     if (!primary_hit) return Li;   // evalEnvironmentLight = 0 on this path
     compute_uv_differential(&hit.frag, diff);
     Li += hit_Le(s, hit, -ray.d);
-    // Lsubsurface: 0 (no BSSRDF under this integrator's device path)
+    // Lsubsurface with the fragment's differentials in place (GoblinWhitted.cpp:22-27: after computeUVDifferential, at every
+    // level of the recursion, always from the camera sample's one BSSRDF block).  The material's Fresnel mirror lobe never
+    // answers the two specular requests below: its type is BSDFAll
+    Li += l_subsurface(c, hit, -ray.d, rec);
     const ResolvedMat mat = resolve_hit_material(s, s->instances[hit.instance].material, hit.frag);
     Li += multi_sample_ld(c, ray, hit.epsilon, hit, mat, rec);
     if (depth < c->rs->max_ray_depth) {

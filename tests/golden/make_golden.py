@@ -45,6 +45,34 @@ VN_GEOMS = [{"name": "bunny", "type": "mesh", "file": "models/bunny_vn.obj"},
 SPOT = [{"name": "spot", "type": "spot", "intensity": [30.0, 32.0, 40.0], "position": [-2.4, 2.6, -1.2], "target": [0.2, 0.6, 0.4],
          "theta_max": 28.0, "falloff_start": 20.0}]
 
+def whitted_sss_materials():
+    """whitted.json's materials with the red lambert and the blinn plastic replaced by subsurface.json's skin and jade."""
+    with open(gs.scene_path("whitted")) as f:
+        mats = json.load(f)["materials"]
+    with open(gs.scene_path("subsurface")) as f:
+        sss = {m["name"]: m for m in json.load(f)["materials"] if m["type"] == "subsurface"}
+    out = []
+    for m in mats:
+        if m["name"] == "red":
+            m = dict(sss["skin"], name="red")
+        elif m["name"] == "plastic":
+            m = dict(sss["jade"], name="plastic")
+        out.append(m)
+    return out
+
+
+def whitted_sss_textures():
+    with open(gs.scene_path("whitted")) as f:
+        tex = json.load(f)["textures"]
+    with open(gs.scene_path("subsurface")) as f:
+        have = {t["name"] for t in tex}
+        tex += [t for t in json.load(f)["textures"] if t["name"] not in have]
+    return tex
+
+
+WHITTED_SSS_MATERIALS = whitted_sss_materials()
+WHITTED_SSS_TEXTURES = whitted_sss_textures()
+
 # name -> (scene, overrides, number of (Sample -> Li) records to keep, with_kat)
 CASES = {
     "bunny_pt": ("bunny", ov((64, 64), 16, 4), 2048, True),
@@ -82,6 +110,10 @@ CASES = {
     "volume_ao_spot": ("volume", dict(ov((48, 48), 4, method="ao", ao=4), lights=SPOT), 0, False),
     "volume_whitted_spot": ("volume", dict(ov((48, 48), 4, 3, method="whitted"), lights=SPOT), 0, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
+    # subsurface materials under the Whitted renderer: Lsubsurface at every level of the recursion (here also behind the
+    # mirror and the glass), SubsurfaceMaterial's BSDFAll lobe never matching the non-specular / specular requests
+    "subsurface_whitted": ("subsurface", ov((48, 48), 4, 3, method="whitted"), 1024, False),
+    "whitted_sss": ("whitted", dict(ov((48, 48), 4, 3), materials=WHITTED_SSS_MATERIALS, textures=WHITTED_SSS_TEXTURES), 1024, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }
 
