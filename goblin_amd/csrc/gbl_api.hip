@@ -66,7 +66,6 @@ struct gbl_ctx {
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;
-    bool has_mask_materials = false;       // an instance carries a MaskMaterial
     std::vector<uint32_t> h_light_slots;   // DevLight::wh_n per light (the Whitted quota, host copy for the stream sampler's layout)
     std::vector<gbl_mesh> h_meshes;
     std::vector<gbl_material> h_materials;
@@ -615,7 +614,6 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     sc.stack_entries = packed.stack_entries;
     sc.extended = packed.extended;
     sc.has_masks = packed.has_masks;
-    ctx->has_mask_materials = packed.has_mask_materials != 0;
     sc.has_bssrdf = packed.has_bssrdf;
     sc.wh_slots = packed.wh_slots;
     sc.volume = packed.volume;
@@ -1078,10 +1076,6 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         // shared splat kernel
         if (p->schedule == GBL_SCHEDULE_WAVEFRONT) {
             ctx->error = "the Whitted integrator has one kernel of its own: there is no wavefront schedule for it";
-            return GBL_ERR_UNSUPPORTED;
-        }
-        if (ctx->has_mask_materials) {
-            ctx->error = "the Whitted integrator's device path does not cover mask materials";
             return GBL_ERR_UNSUPPORTED;
         }
         if (ra.max_depth > GBL_WHITTED_MAX_DEPTH) {

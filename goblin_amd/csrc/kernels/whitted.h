@@ -69,7 +69,11 @@ __device__ __forceinline__ F3 wh_estimate_ld(const DevScene& sc, const Frag& fr,
     }
     // sampleBSDF(..., BSDFAll & ~BSDFSpecular): Transparent and Mirror do not match (pdf 0), nor does SubsurfaceMaterial whose
     // BSDFAll type only matches that very request (GoblinMaterial.cpp:732-736); Lambert / Blinn sample as always
-    if (rmat.m.type == GBL_MAT_TRANSPARENT || rmat.m.type == GBL_MAT_MIRROR || rmat.m.type == GBL_MAT_SUBSURFACE) return Ld;
+    // A MaskMaterial forwards the request to the wrapped material when uComponent < alpha and answers it itself with the
+    // BSDFnullptr lobe otherwise (:757-784): straight through, non-specular, so it still looks for the light behind.
+    if ((rmat.m.type == GBL_MAT_TRANSPARENT || rmat.m.type == GBL_MAT_MIRROR || rmat.m.type == GBL_MAT_SUBSURFACE) &&
+        !(rmat.is_mask && !(w.bs_comp < rmat.alpha)))
+        return Ld;
     F3 wi;
     float pdf;
     bool specular, null_sampled;
@@ -200,6 +204,16 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
                         const float refract = eta * eta * (1.0f - f2) / absdot(F.refr_wi, nn);
                         F.refr_f = f3(m.color2[0], m.color2[1], m.color2[2]) * refract;
                         if (!is_black(F.refr_f) && absdot(F.refr_wi, n) != 0.0f) F.flags |= 2u;
+                    }
+                }
+                if (rmat.is_mask) {   // neither request has the BSDFnullptr bit: the wrapped material's answer times alpha, at its pdf (:781-783)
+                    if (F.flags & 1u) {
+                        F.refl_f = rmat.alpha * F.refl_f;
+                        if (is_black(F.refl_f)) F.flags &= ~1u;
+                    }
+                    if (F.flags & 2u) {
+                        F.refr_f = rmat.alpha * F.refr_f;
+                        if (is_black(F.refr_f)) F.flags &= ~2u;
                     }
                 }
                 if (F.flags != 0u) {

@@ -755,8 +755,6 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     }
     for (const DevInstance& di : out->instances)
         if (di.is_mask) out->has_masks = out->extended = 1;
-    for (uint32_t i = 0; i < d->num_instances; ++i)   // MaskMaterial proper (is_mask also marks subsurface materials, whose type is BSDFAll)
-        if (d->materials[d->instances[i].material].type == GBL_MAT_MASK) out->has_mask_materials = 1;
     Aabb scene_bound;   // BVH::getAABB of the scene BVH: the union of the instance boxes (GoblinBVH.cpp:46-50)
     scene_bound.grow(sb_lo);
     scene_bound.grow(sb_hi);

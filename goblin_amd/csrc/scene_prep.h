@@ -25,7 +25,6 @@ struct PackedScene {
     int32_t stack_entries = 0;
     int32_t extended = 0;   // DevScene::extended
     int32_t has_masks = 0;  // DevScene::has_masks
-    int32_t has_mask_materials = 0;   // some instance carries a MaskMaterial (the Whitted kernel has no path for those)
     int32_t has_bssrdf = 0; // DevScene::has_bssrdf
     int32_t wh_slots = 0;   // DevScene::wh_slots
     DevVolume volume = {};

@@ -2563,7 +2563,9 @@ Col estimate_ld(LiCtx* c, V3 wo, float epsilon, const Hit& hit, const ResolvedMa
     }
     // sampleBSDF(..., BSDFAll & ~BSDFSpecular): the specular materials do not match the request (pdf 0, Black);
     // Lambert and Blinn sample exactly as under BSDFAll
-    if (mat_is_specular(mat.m)) return Ld;
+    // (a MaskMaterial forwards the request to the wrapped material when uComponent < alpha -- Black, pdf 0 for those -- and
+    // answers it itself with the BSDFnullptr lobe otherwise, GoblinMaterial.cpp:757-784)
+    if (mat_is_specular(mat.m) && !(mat.is_mask && !(bs_comp < mat.alpha))) return Ld;
     int sampled = 0;
     Col f = rmat_sample(mat, frag, wo, bs_comp, bs_dir[0], bs_dir[1], &wi, &bsdf_pdf, &sampled);
     if (f != BLACK && bsdf_pdf > 0.0f) {
@@ -2646,6 +2648,9 @@ Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* dif
                 f = mat_color(mat.m) * specular_reflect_dielectric(n, wo, &wi, 1.0f, mat.m.index);
                 pdf = 1.0f;
             }
+            // MaskMaterial: the request has no BSDFnullptr bit, so it is the wrapped material's answer times alpha, at the
+            // wrapped material's pdf (GoblinMaterial.cpp:781-783)
+            if (mat.is_mask) f = mat.alpha * f;
             if (f != BLACK && absdot(wi, n) != 0.0f) {
                 Ray child;
                 child.o = p; child.d = wi; child.mint = hit.epsilon; child.maxt = INF;
@@ -2665,6 +2670,9 @@ Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* dif
                 f = mat_color2(mat.m) * specular_refract(n, wo, &wi, 1.0f, mat.m.index);
                 pdf = 1.0f;
             }
+            // MaskMaterial: the request has no BSDFnullptr bit, so it is the wrapped material's answer times alpha, at the
+            // wrapped material's pdf (GoblinMaterial.cpp:781-783)
+            if (mat.is_mask) f = mat.alpha * f;
             if (f != BLACK && absdot(wi, n) != 0.0f) {
                 Ray child;
                 child.o = p; child.d = wi; child.mint = hit.epsilon; child.maxt = INF;

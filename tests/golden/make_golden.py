@@ -114,6 +114,9 @@ CASES = {
     # mirror and the glass), SubsurfaceMaterial's BSDFAll lobe never matching the non-specular / specular requests
     "subsurface_whitted": ("subsurface", ov((48, 48), 4, 3, method="whitted"), 1024, False),
     "whitted_sss": ("whitted", dict(ov((48, 48), 4, 3), materials=WHITTED_SSS_MATERIALS, textures=WHITTED_SSS_TEXTURES), 1024, False),
+    # mask materials under the Whitted renderer: opaque to every query; the BSDFnullptr lobe only shows up in estimateLd's
+    # BSDF sample (straight through, towards an area light); masked mirror / glass answer the specular requests times alpha
+    "masked_whitted": ("masked", ov((48, 48), 4, 3, method="whitted"), 1024, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }
 

@@ -75,7 +75,7 @@ def fake_window(full, n_pixels):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss"])
+                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -104,7 +104,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss"])
+                                  "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -131,7 +131,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
-                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss"])
+                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
     """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
     Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators
@@ -251,6 +251,7 @@ def test_stream_mode_shards_and_windows(torch):
     ("whitted", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("subsurface", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("subsurface", gs.config_overrides(resolution=(32, 32), spp=9, depth=3, method="whitted")),
+    ("masked", gs.config_overrides(resolution=(32, 32), spp=9, depth=3, method="whitted")),
     ("subsurface", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
                         render_setting=dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4)["render_setting"], bssrdf_sample_num=7))),
     ("shapes", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),
