@@ -135,3 +135,14 @@ def random_scene(seed):
     return doc, use_mask or use_sss
 
 
+def random_whitted_scene(seed):
+    """random_scene(seed) under the Whitted renderer: shallow recursion, per-light sample counts on the area lights."""
+    doc, special = random_scene(seed)
+    rng = np.random.default_rng(seed + 104729)
+    doc["render_setting"]["render_method"] = "whitted"
+    doc["render_setting"]["max_ray_depth"] = int(rng.integers(1, 4))
+    for l in doc["lights"]:
+        if l["type"] == "area":
+            l["sample_num"] = int(rng.integers(1, 6))
+    return doc, special
+

@@ -22,9 +22,9 @@ SCENE_DIR = os.path.dirname(gs.scene_path("bunny"))
 pytestmark = pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not built (needs /root/reference)")
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
-def test_oracle_matches_reference_on_random_scene(seed):
-    doc, _ = helpers.random_scene(1000 + seed)
+@pytest.mark.parametrize("seed,whitted", [(s, False) for s in range(10)] + [(s, True) for s in range(6)])
+def test_oracle_matches_reference_on_random_scene(seed, whitted):
+    doc, _ = (helpers.random_whitted_scene if whitted else helpers.random_scene)(1000 + seed)
     doc["render_setting"]["thread_num"] = 1
     ref_doc = json.loads(json.dumps(doc))
     for g in ref_doc["geometries"]:
