@@ -311,7 +311,9 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     const bool ext = sc.extended != 0;
     const bool masks = sc.has_masks != 0;
     auto k_ext = masks ? (want_stats ? wf_trace<false, true, true, true> : wf_trace<false, false, true, true>)
-                       : (want_stats ? wf_trace<false, true, true> : (ext ? wf_trace<false, false, true> : wf_trace<false, false, false>));
+                       : (want_stats ? wf_trace<false, true, true>
+                                     : replay ? (ext ? wf_trace<false, false, true> : wf_trace<false, false, false>)
+                                              : (ext ? wf_trace<false, false, true, false, false> : wf_trace<false, false, false, false, false>));   // native, lean: no tie rule
     auto k_shd = masks ? (want_stats ? wf_trace<true, true, true, true> : wf_trace<true, false, true, true>)
                        : (want_stats ? wf_trace<true, true, true> : (ext ? wf_trace<true, false, true> : wf_trace<true, false, false>));
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
@@ -1021,8 +1023,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     }
     // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while a path is cheap
     // (short paths through a small scene: configs 1, 2), the wavefront formulation once traversal dominates and its
-    // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 4.2 s against 6.4 s) or many
-    // instanced triangles (config 4, 15 bunnies: 317 ms against 438 ms).  AO always runs the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
+    // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 3.5 s against 6.5 s) or many
+    // instanced triangles (config 4, 15 bunnies: 300 ms against 438 ms).  AO always runs the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
     // filtered MIS query and the attenuation walks inline in the trace kernel: 48.6 ms against 16.1 ms on masked.json).
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             camera_ray<EXT>(sc.camera, image_x, image_y, lens_u1, lens_u2, &o, &d, &cam_mint);
             Hit hit;
             F3 L = f3(0, 0, 0);
-            bool got = trace<false, STATS, EXT>(sc, o, d, cam_mint, INFINITY, stk, hit, cnt);
+            bool got = trace<false, STATS, EXT, REPLAY || STATS>(sc, o, d, cam_mint, INFINITY, stk, hit, cnt);   // lean native build: no tie rule (trace.h)
             if (STATS) {
                 cnt.ext += 1;
                 cnt.dims += 2;

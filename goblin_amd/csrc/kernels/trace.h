@@ -325,7 +325,7 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 // TIES: resolve exact ties as the reference's BVH does (tie_goes_to).  The compare sits on the accept path of the loop
 // every ray runs and costs the headline kernel 1.4 % (measured both inlined and as a flag + second pass); the native
 // sampler's lean megakernel therefore compiles it out -- its ties, ~5 per 10^7 paths, fall to the device tree's own
-// order -- while every replay / stream / instrumented build and the wavefront kernels keep it.
+// order -- and so does the wavefront's lean extension kernel, while every replay / stream / instrumented build keeps it.
 template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
                                            int filter = GBL_FILTER_NONE) {

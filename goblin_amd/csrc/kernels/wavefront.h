@@ -135,7 +135,9 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 #endif
 // MASKS: the scene has mask materials (implies EXT); only those builds carry the filtered queries and the
 // attenuation walks, which would otherwise cost every EXT scene ~150 spilled registers.
-template <bool ANY, bool STATS, bool EXT, bool MASKS = false>
+// TIES: closest-hit ties at exactly equal t go the way the reference BVH's visiting order decides (trace.h); the lean
+// native-sampler build leaves the rule out, like the lean megakernel.
+template <bool ANY, bool STATS, bool EXT, bool MASKS = false, bool TIES = true>
 __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
     const SplitStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x),
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_
                 if (at_int) trav_interior<STATS, !ANY>(sc, st, stk, cnt);
             } else if (at_oth) {
                 bool occluded = false;
-                if (trav_other<ANY, STATS, EXT>(sc, st, stk, cnt, &occluded, filter)) {
+                if (trav_other<ANY, STATS, EXT, SplitStack, TIES>(sc, st, stk, cnt, &occluded, filter)) {
                     if (ANY) {
                         if constexpr (masks) if (!occluded) {
                             // evalAttenuation along the unoccluded shadow segment, then f * tr * L * |n.wi| (* lWeight) / lightPdf
