@@ -208,8 +208,8 @@ typedef enum gbl_integrator {
     GBL_INTEGRATOR_PATH = 0, /* PathTracer  (GoblinPathtracer.cpp) */
     GBL_INTEGRATOR_AO = 1,   /* AORenderer  (GoblinAO.cpp)         */
     /* WhittedRenderer (GoblinWhitted.cpp:13-44): emission + multiSampleLd over every light (GoblinRenderer.cpp:474-596)
-     * + the specular reflection / refraction tree (:598-648).  Mask and subsurface materials are outside this
-     * integrator's device path (GBL_ERR_UNSUPPORTED). */
+     * + Lsubsurface at every level (:25-27) + the specular reflection / refraction tree (:598-648); mask materials
+     * answer its requests as MaskMaterial does (GoblinMaterial.cpp:747-811).  max_ray_depth <= 12. */
     GBL_INTEGRATOR_WHITTED = 2
 } gbl_integrator;
 
