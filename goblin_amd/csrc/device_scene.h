@@ -20,6 +20,8 @@
 #define GBL_PT_WAVES 3
 #endif
 #define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
+#define GBL_STREAM_LDS_WORDS 640   // GBL_SAMPLES_STREAM: 624 mt19937 state words + cursor, padded (kernels/stream.h)
+#define GBL_WHITTED_MAX_DEPTH 12   // frames of the Whitted kernel's explicit recursion (kernels/whitted.h)
 
 // child reference: >= 0 interior node index; < 0 leaf: ~ref = (first << 2) | (count - 1)
 // (TLAS leaves: first = instance id, count = 1); GBL_REF_NONE marks an unused child slot.

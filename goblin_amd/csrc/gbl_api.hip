@@ -19,79 +19,16 @@
 
 #include "../../include/goblin_hip.h"
 #include "device_scene.h"
-#include "kernels/render_kernels.h"
-#include "kernels/wavefront.h"
-#include "kernels/subsurface.h"
-#include "kernels/whitted.h"
-#include "kernels/volume.h"
-#include "kernels/lbvh.h"
-#include <hipcub/hipcub.hpp>
+#include "gbl_internal.h"
+#include "kernels/stream.h"     // StreamLayout: the host sizes the stream sampler's scratch
+#include "kernels/trace.h"      // GBL_WF_STACK_LDS
 #include "scene_prep.h"
 
 namespace {
 thread_local std::string g_create_error;
 }
 
-struct gbl_ctx {
-    int device = 0;
-    std::string error;
-    std::vector<void*> allocations;
-    DevScene scene;
-    gbl_info info;
-    uint32_t* work_counter = nullptr;
-    unsigned long long* stats = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int num_cus = 256;
-    void* rccl = nullptr;
-    void* rccl_allreduce = nullptr;
-    // wavefront pool (allocated on first use)
-    uint32_t wf_pool = 0;
-    uint32_t* wf_spill = nullptr;   // wf_ensure_spill()
-    hipStream_t wf_aux = nullptr;   // shadow rays of iteration k trace here while the main stream traces extension rays k+1
-    hipEvent_t wf_ev_shade = nullptr, wf_ev_shadow = nullptr;
-    int wf_spill_levels = 0;
-    WfArgs wf;
-    float4* wf_li = nullptr;
-    size_t wf_li_entries = 0;
-    uint64_t li_budget = 0;   // li_budget_bytes()
-    uint32_t* stream_seeds = nullptr;     // GBL_SAMPLES_STREAM: per-tile mt19937 seeds of the full sample window
-    uint32_t* stream_scratch = nullptr;   // ... and the workgroups' sample-generation scratch
-    uint64_t stream_scratch_bytes = 0;
-    float* stream_xy = nullptr;           // ... and the image position of every camera sample of the call (for the splat)
-    uint64_t stream_xy_bytes = 0;
-    float* vol_buf = nullptr;    // per-sample {transmittance, Lv} of the render in flight (scenes with a participating medium)
-    uint64_t vol_entries = 0;
-    float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
-    uint64_t sss_entries = 0;
-    double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
-    // what gbl_update_instances needs to rebuild the TLAS
-    std::vector<gbl_instance> h_instances;
-    std::vector<uint32_t> h_light_slots;   // DevLight::wh_n per light (the Whitted quota, host copy for the stream sampler's layout)
-    std::vector<gbl_mesh> h_meshes;
-    std::vector<gbl_material> h_materials;
-    std::vector<float> mesh_lo, mesh_hi;
-    std::vector<int32_t> mesh_root;
-    int32_t tlas_base = 0;
-    uint32_t tlas_capacity = 0;
-    int blas_depth = 0;
-    bool has_directional = false;
-    uint32_t* wf_host_flags = nullptr;   // pinned
-    // ring of event triples for gbl_get_timings
-    static const int kTimingRing = 64;
-    hipEvent_t t_ev[64][3] = {};
-    unsigned long long t_calls = 0;
-};
-
 namespace {
-
-#define HIP_TRY(ctx, expr)                                                                     \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) {                                                                \
-            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
-            return GBL_ERR_DEVICE;                                                             \
-        }                                                                                      \
-    } while (0)
 
 template <class T>
 gbl_status upload(gbl_ctx* ctx, const std::vector<T>& v, const T** out) {
@@ -310,12 +247,10 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     // build.  Instrumented launches always use the EXT build (same work, same counters).
     const bool ext = sc.extended != 0;
     const bool masks = sc.has_masks != 0;
-    auto k_ext = masks ? (want_stats ? wf_trace<false, true, true, true> : wf_trace<false, false, true, true>)
-                       : (want_stats ? wf_trace<false, true, true>
-                                     : replay ? (ext ? wf_trace<false, false, true> : wf_trace<false, false, false>)
-                                              : (ext ? wf_trace<false, false, true, false, false> : wf_trace<false, false, false, false, false>));   // native, lean: no tie rule
-    auto k_shd = masks ? (want_stats ? wf_trace<true, true, true, true> : wf_trace<true, false, true, true>)
-                       : (want_stats ? wf_trace<true, true, true> : (ext ? wf_trace<true, false, true> : wf_trace<true, false, false>));
+    // native sampler, lean build: no tie rule (trace.h)
+    const bool lean_native = !masks && !want_stats && !replay;
+    gbl_wf_kernel k_ext = gbl_kernel_wf_trace(false, want_stats, ext || masks || want_stats, masks, !lean_native);
+    gbl_wf_kernel k_shd = gbl_kernel_wf_trace(true, want_stats, ext || masks || want_stats, masks, true);
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
     // workgroup that has to wait for a free CU would serialise its share), never more waves than regions
     int occ_ext = 0, occ_shd = 0;
@@ -344,10 +279,12 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     uint32_t* const spill_ext = ctx->wf_spill;
     uint32_t* const spill_shd = ctx->wf_spill + static_cast<size_t>(ctx->wf_spill_levels) * ext_wgs * GBL_BLOCK;
     dim3 block(GBL_BLOCK), grid_ext(ext_wgs), grid_shd(shd_wgs), grid_shade(pool / GBL_BLOCK);
-    auto k_shade = replay ? (want_stats ? wf_shade<true, true, true> : (ext ? wf_shade<true, false, true> : wf_shade<true, false, false>))
-                          : (want_stats ? wf_shade<false, true, true> : (ext ? wf_shade<false, false, true> : wf_shade<false, false, false>));
-    auto k_splat = replay ? (want_stats ? wf_splat<true, true> : wf_splat<true, false>)
-                          : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
+    gbl_wf_kernel k_shade = gbl_kernel_wf_shade(replay, want_stats, ext || want_stats);
+    gbl_wf_kernel k_splat = gbl_kernel_wf_splat(replay, want_stats);
+    if (!k_ext || !k_shd || !k_shade || !k_splat) {
+        ctx->error = "wavefront kernel variant not built";
+        return GBL_ERR_UNSUPPORTED;
+    }
     if (lds_stack > 64 * 1024) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ext), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          static_cast<int>(lds_stack)));
@@ -402,100 +339,6 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     return GBL_OK;
 }
 
-}  // namespace
-
-// ---------------------------------------------------------------------------
-// Device BLAS build (kernels/lbvh.h).  One mesh at a time: nodes are written at node_base (absolute child
-// references), DevTri records at tri_base in Morton order.  Returns the mesh's root reference.
-// ---------------------------------------------------------------------------
-namespace {
-struct LbvhScratch {
-    std::vector<void*> ptrs;
-    ~LbvhScratch() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
-    template <class T>
-    bool alloc(T** out, size_t n) {
-        void* p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return false;
-        ptrs.push_back(p);
-        *out = static_cast<T*>(p);
-        return true;
-    }
-};
-
-gbl_status build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,
-                             DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base,
-                             int32_t* root_out, uint32_t* nodes_out, int* depth_out) {
-    LbvhScratch sc;
-    unsigned long long *keys = nullptr, *keys_sorted = nullptr;
-    LbvhBox* tri_box = nullptr;
-    LbvhTree t;
-    memset(&t, 0, sizeof(t));
-    LbvhFrontier *fa = nullptr, *fb = nullptr;
-    uint32_t* counters = nullptr;   // [0] next frontier size, [1] nodes emitted
-    const size_t ni = n > 1 ? n - 1 : 1;
-    if (!sc.alloc(&keys, n) || !sc.alloc(&keys_sorted, n) || !sc.alloc(&tri_box, n) || !sc.alloc(&t.left, ni) || !sc.alloc(&t.right, ni) ||
-        !sc.alloc(&t.parent, 2 * static_cast<size_t>(n)) || !sc.alloc(&t.first, ni) || !sc.alloc(&t.last, ni) || !sc.alloc(&t.box, ni) ||
-        !sc.alloc(&t.leaf_box, n) || !sc.alloc(&t.visits, ni) || !sc.alloc(&fa, ni) || !sc.alloc(&fb, ni) || !sc.alloc(&counters, 2)) {
-        ctx->error = "hipMalloc(device BVH build scratch) failed";
-        return GBL_ERR_OOM;
-    }
-    LbvhBox mesh;
-    for (int a = 0; a < 3; ++a) {
-        mesh.lo[a] = lo[a];
-        mesh.hi[a] = hi[a];
-    }
-    const dim3 block(256), grid((n + 255) / 256);
-    hipLaunchKernelGGL(lbvh_keys, grid, block, 0, 0, d_pos, d_idx, n, mesh, keys, tri_box);
-    size_t temp_bytes = 0;
-    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
-    unsigned char* temp = nullptr;
-    if (!sc.alloc(&temp, temp_bytes)) {
-        ctx->error = "hipMalloc(radix sort scratch) failed";
-        return GBL_ERR_OOM;
-    }
-    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
-    hipLaunchKernelGGL(lbvh_tris, grid, block, 0, 0, d_pos, d_idx, keys_sorted, n, shade_base, d_tris + tri_base);
-    *nodes_out = 0;
-    *depth_out = 0;
-    if (n <= GBL_MAX_LEAF_TRIS) {   // the whole mesh is one leaf
-        *root_out = ~static_cast<int32_t>((tri_base << 2) | (n - 1u));
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        return GBL_OK;
-    }
-    hipLaunchKernelGGL(lbvh_gather_boxes, grid, block, 0, 0, keys_sorted, tri_box, n, t.leaf_box);
-    hipLaunchKernelGGL(lbvh_hierarchy, grid, block, 0, 0, keys_sorted, static_cast<int>(n), t);
-    HIP_TRY(ctx, hipMemsetAsync(t.visits, 0, ni * sizeof(uint32_t), 0));
-    hipLaunchKernelGGL(lbvh_fit, grid, block, 0, 0, static_cast<int>(n), t);
-    // collapse, one 4-wide level per launch
-    LbvhFrontier rootf = {0, 0};
-    uint32_t init[2] = {0u, 1u};
-    HIP_TRY(ctx, hipMemcpy(fa, &rootf, sizeof(rootf), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(counters, init, sizeof(init), hipMemcpyHostToDevice));
-    uint32_t n_in = 1;
-    int depth = 0;
-    while (n_in > 0) {
-        ++depth;
-        hipLaunchKernelGGL(lbvh_collapse, dim3((n_in + 255) / 256), block, 0, 0, t, fa, n_in, fb, counters, counters + 1, d_nodes + node_base,
-                           node_base, tri_base);
-        uint32_t h[2];
-        HIP_TRY(ctx, hipMemcpy(h, counters, sizeof(h), hipMemcpyDeviceToHost));
-        n_in = h[0];
-        *nodes_out = h[1];
-        HIP_TRY(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t), 0));
-        std::swap(fa, fb);
-        if (depth > 128) {
-            ctx->error = "device BVH build did not terminate";
-            return GBL_ERR_DEVICE;
-        }
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    *root_out = node_base;
-    *depth_out = depth;
-    return GBL_OK;
-}
 }  // namespace
 
 extern "C" {
@@ -577,7 +420,7 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
             if (gm.shape != GBL_SHAPE_MESH) continue;
             uint32_t used = 0;
             int depth = 0;
-            st = build_blas_device(ctx, d_pos + 3 * static_cast<size_t>(gm.vertex_offset), d_idx + 3 * static_cast<size_t>(gm.tri_offset), gm.tri_count,
+            st = gbl_build_blas_device(ctx, d_pos + 3 * static_cast<size_t>(gm.vertex_offset), d_idx + 3 * static_cast<size_t>(gm.tri_offset), gm.tri_count,
                                    &packed.mesh_lo[3 * m], &packed.mesh_hi[3 * m], const_cast<DevNode*>(sc.nodes), node_base,
                                    const_cast<DevTri*>(sc.tris), tri_base, gm.tri_offset, &mesh_root[m], &used, &depth);
             if (st != GBL_OK) return bail(st);
@@ -715,87 +558,6 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
     ctx->info.tlas_depth = depth;
     ctx->info.tlas_nodes = tlas.size();
     ctx->h_instances.swap(edited);
-    return GBL_OK;
-}
-
-__global__ void selftest_sincos_kernel(const float* in, float* s, float* c, uint64_t n) {
-    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    s[i] = gbl_sinf(in[i]);
-    c[i] = gbl_cosf(in[i]);
-}
-
-// rays: n x {kind (0 closest, 1 any), o(3), d(3), mint, maxt}; out: n x {t of the closest hit or -1 | 1 occluded or 0, instance, shading normal(3), tangent(3)}
-__global__ void selftest_trace_kernel(DevScene sc, const float* rays, float* out, uint32_t n) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const LdsStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x)};
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = rays + 9 * i;
-    LaneCounters cnt = {};
-    Hit hit;
-    hit.inst = -1;
-    hit.t = -1.0f;
-    const F3 o = f3(r[1], r[2], r[3]), d = f3(r[4], r[5], r[6]);
-    float* q = out + 8 * i;
-    for (int k = 0; k < 8; ++k) q[k] = 0.0f;
-    if (r[0] != 0.0f) {
-        q[0] = trace<true, false, true>(sc, o, d, r[7], r[8], stk, hit, cnt) ? 1.0f : 0.0f;
-        q[1] = -1.0f;
-    } else {
-        const bool got = trace<false, false, true>(sc, o, d, r[7], r[8], stk, hit, cnt);
-        q[0] = got ? hit.t : -1.0f;
-        q[1] = got ? static_cast<float>(hit.inst) : -1.0f;
-        if (got) {
-            Frag fr;
-            make_fragment<true>(sc, hit, o, d, fr);
-            q[2] = fr.n.x; q[3] = fr.n.y; q[4] = fr.n.z;
-            q[5] = fr.t.x; q[6] = fr.t.y; q[7] = fr.t.z;
-        }
-    }
-}
-
-gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n) {
-    if (!ctx || !rays || !out) return GBL_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n == 0) return GBL_OK;
-    const size_t lds = static_cast<size_t>(ctx->scene.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-    if (lds > 64 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(selftest_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds)));
-    hipLaunchKernelGGL(selftest_trace_kernel, dim3((n + GBL_BLOCK - 1) / GBL_BLOCK), dim3(GBL_BLOCK), lds, nullptr, ctx->scene, rays, out, n);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    return GBL_OK;
-}
-
-// out[4 i ..] = {sqrtf(a), a / b, 1 / a, expected to be IEEE correctly rounded like the host's}
-__global__ void selftest_arith_kernel(const float* a, const float* b, float* out, uint64_t n) {
-    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out[4 * i] = sqrtf(a[i]);
-    out[4 * i + 1] = a[i] / b[i];
-    out[4 * i + 2] = 1.0f / a[i];
-    const F3 v = normalize(f3(a[i], b[i], 0.5f));
-    out[4 * i + 3] = v.x;
-}
-gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n) {
-    if (!ctx || !a || !b || !out) return GBL_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n == 0) return GBL_OK;
-    hipLaunchKernelGGL(selftest_arith_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, a, b, out, n);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    return GBL_OK;
-}
-
-gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
-    if (!ctx || !in || !sin_out || !cos_out) return GBL_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (n == 0) return GBL_OK;
-    hipLaunchKernelGGL(selftest_sincos_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, in, sin_out, cos_out, n);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipDeviceSynchronize());
     return GBL_OK;
 }
 
@@ -1062,8 +824,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ctx->vol_entries = entries;
         }
         ra.vol = ctx->vol_buf;
-        auto k_vol = replay ? (want_stats ? vol_kernel<true, true> : vol_kernel<true, false>)
-                            : (want_stats ? vol_kernel<false, true> : vol_kernel<false, false>);
+        gbl_render_kernel k_vol = gbl_kernel_vol(replay, want_stats);
         const size_t lds_vol = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
         if (lds_vol > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vol), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1100,9 +861,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         for (int k = 0; k < 3; ++k)
             if (!wev[k]) HIP_TRY(ctx, hipEventCreate(&wev[k]));
         HIP_TRY(ctx, hipEventRecord(wev[0], stream));
-        auto k_wh = stream_mode ? (want_stats ? whitted_stream_kernel<true> : whitted_stream_kernel<false>)
-                    : replay    ? (want_stats ? whitted_kernel<true, true> : whitted_kernel<true, false>)
-                                : (want_stats ? whitted_kernel<false, true> : whitted_kernel<false, false>);
+        gbl_li_kernel k_wh = stream_mode ? gbl_kernel_whitted_stream(want_stats) : gbl_kernel_whitted(replay, want_stats);
         size_t lds_wh = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
         if (stream_mode) {
             const size_t want = std::max<size_t>(lds_wh, 40 * 1024);
@@ -1145,15 +904,13 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             wa.pass_k0 = 0;
             wa.pass_spp = ra.spp;
             // replay records of another quota: the splat only reads their image positions, at the Whitted record stride
-            auto k_splat = replay ? (want_stats ? wf_splat<true, true> : wf_splat<true, false>)
-                                  : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
+            gbl_wf_kernel k_splat = gbl_kernel_wf_splat(replay, want_stats);
             const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
             hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), dim3(GBL_BLOCK), lds_tile, stream, sc, ra, wa);
             HIP_TRY(ctx, hipGetLastError());
         }
         if (ra.vol && ra.li_out) {   // the caller's per-sample output carries what the tile received: tr * Li + Lv
-            hipLaunchKernelGGL(vol_combine_kernel, dim3(static_cast<unsigned>((entries + 255) / 256)), dim3(256), 0, stream,
-                               reinterpret_cast<float4*>(ra.li_out), reinterpret_cast<const float4*>(ra.vol), entries);
+            gbl_launch_vol_combine(reinterpret_cast<float4*>(ra.li_out), reinterpret_cast<const float4*>(ra.vol), entries, stream);
             HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipEventRecord(wev[2], stream));
@@ -1199,8 +956,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ctx->sss_entries = entries;
         }
         ra.sss = reinterpret_cast<const float*>(ctx->sss_buf);
-        auto k_sss = replay ? (want_stats ? sss_kernel<true, true> : sss_kernel<true, false>)
-                            : (want_stats ? sss_kernel<false, true> : sss_kernel<false, false>);
+        gbl_li_kernel k_sss = gbl_kernel_sss(replay, want_stats);
         const size_t lds_sss = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
         if (lds_sss > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sss), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1221,11 +977,8 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
         if (stream_mode) {
-            if (p->integrator == GBL_INTEGRATOR_AO)
-                kernel = want_stats ? ao_kernel<true, true, true, true> : (ext ? ao_kernel<true, false, true, true> : ao_kernel<true, false, false, true>);
-            else
-                kernel = want_stats ? path_trace_kernel<true, true, true, true>
-                                    : (ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>);
+            kernel = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_stream(want_stats, ext || want_stats)
+                                                        : gbl_kernel_path_stream(want_stats, ext || want_stats);
             const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
                                                  p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
             // a sample's tail in the stream: up to 6 discarded floats per bounce, 9 per light sample of the medium
@@ -1238,11 +991,9 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail_words), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
-            kernel = replay ? (want_stats ? path_trace_kernel<true, true, true> : (ext ? path_trace_kernel<true, false, true> : path_trace_kernel<true, false, false>))
-                            : (want_stats ? path_trace_kernel<false, true, true> : (ext ? path_trace_kernel<false, false, true> : path_trace_kernel<false, false, false>));
+            kernel = gbl_kernel_path(replay, want_stats, ext || want_stats);
         } else {
-            kernel = replay ? (want_stats ? ao_kernel<true, true, true> : (ext ? ao_kernel<true, false, true> : ao_kernel<true, false, false>))
-                            : (want_stats ? ao_kernel<false, true, true> : (ext ? ao_kernel<false, false, true> : ao_kernel<false, false, false>));
+            kernel = gbl_kernel_ao(replay, want_stats, ext || want_stats);
         }
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1280,8 +1031,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             wa.li_buf = reinterpret_cast<float4*>(ra.li_defer);
             wa.pass_k0 = 0;
             wa.pass_spp = ra.spp;
-            auto k_splat = replay ? (want_stats ? wf_splat<true, true> : wf_splat<true, false>)
-                                  : (want_stats ? wf_splat<false, true> : wf_splat<false, false>);
+            gbl_wf_kernel k_splat = gbl_kernel_wf_splat(replay, want_stats);
             const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
             hipLaunchKernelGGL(k_splat, dim3(ra.local_tiles), block, lds_tile, stream, sc, ra, wa);
             HIP_TRY(ctx, hipGetLastError());
@@ -1289,8 +1039,7 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     }
     if (ra.vol && ra.li_out) {   // the caller's per-sample output carries what the tile received: tr * Li + Lv
         const uint64_t n_li = npix * ra.spp;
-        hipLaunchKernelGGL(vol_combine_kernel, dim3(static_cast<unsigned>((n_li + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<float4*>(ra.li_out), reinterpret_cast<const float4*>(ra.vol), n_li);
+        gbl_launch_vol_combine(reinterpret_cast<float4*>(ra.li_out), reinterpret_cast<const float4*>(ra.vol), n_li, stream);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(tev[2], stream));
@@ -1365,8 +1114,7 @@ gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_ou
     if (!ctx || !film_accum || !rgb_out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int n = ctx->info.xres * ctx->info.yres;
-    hipLaunchKernelGGL(film_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), film_accum,
-                       rgb_out, n);
+    gbl_launch_film_resolve(film_accum, rgb_out, n, static_cast<hipStream_t>(stream));
     HIP_TRY(ctx, hipGetLastError());
     return GBL_OK;
 }

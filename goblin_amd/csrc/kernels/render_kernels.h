@@ -335,7 +335,6 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 
 // STREAM (implies REPLAY): the records are the reference's own, generated per pixel from the tile's mt19937
 // (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
-#define GBL_STREAM_LDS_WORDS 640   // 624 state words + cursor, padded
 template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false>
 __global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -903,15 +902,4 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
         if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
-}
-
-// Film::writeImage's normalise step on the device: rgb = color / weight
-__global__ void film_resolve_kernel(const float* accum, float* rgb, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 a = reinterpret_cast<const float4*>(accum)[i];
-    float inv = 1.0f / a.w;
-    rgb[3 * i + 0] = a.x * inv;
-    rgb[3 * i + 1] = a.y * inv;
-    rgb[3 * i + 2] = a.z * inv;
 }

@@ -63,11 +63,3 @@ __global__ __launch_bounds__(GBL_BLOCK) void vol_kernel(DevScene sc, RenderArgs 
     }
     if (STATS) accumulate_stats(ra, cnt, 0);
 }
-
-// li[i] = 1 * (tr[i] * li[i] + Lv[i]) over the call's camera samples: the caller's li_out, after the splat has read it
-__global__ void vol_combine_kernel(float4* li, const float4* vol, uint64_t n) {
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 L = li[i], tr = vol[2 * i], lv = vol[2 * i + 1];
-    li[i] = make_float4(1.0f * (tr.x * L.x + lv.x), 1.0f * (tr.y * L.y + lv.y), 1.0f * (tr.z * L.z + lv.z), L.w);
-}

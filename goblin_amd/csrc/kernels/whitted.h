@@ -16,7 +16,6 @@
 #pragma once
 #include "render_kernels.h"
 
-#define GBL_WHITTED_MAX_DEPTH 12
 
 struct WhSlots {   // the Sample values of one (light, slot) pair
     float ls_comp, ls_u1, ls_u2, bs_comp, bs_u1, bs_u2;

@@ -1,0 +1,224 @@
+// libgoblin_hip.so, kernel unit: the first-hit passes (subsurface term, participating medium), the film resolve, the
+// device BLAS build (kernels/lbvh.h) and the device self tests of the C ABI.
+#include "gbl_internal.h"
+#include "kernels/render_kernels.h"
+#include "kernels/subsurface.h"
+#include "kernels/volume.h"
+#include "kernels/lbvh.h"
+#include <hipcub/hipcub.hpp>
+
+#include <cstring>
+
+gbl_li_kernel gbl_kernel_sss(bool replay, bool stats) {
+    if (replay) return stats ? sss_kernel<true, true> : sss_kernel<true, false>;
+    return stats ? sss_kernel<false, true> : sss_kernel<false, false>;
+}
+
+gbl_render_kernel gbl_kernel_vol(bool replay, bool stats) {
+    if (replay) return stats ? vol_kernel<true, true> : vol_kernel<true, false>;
+    return stats ? vol_kernel<false, true> : vol_kernel<false, false>;
+}
+
+// li[i] = 1 * (tr[i] * li[i] + Lv[i]) over the call's camera samples: the caller's li_out, after the splat has read it
+__global__ void vol_combine_kernel(float4* li, const float4* vol, uint64_t n) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 L = li[i], tr = vol[2 * i], lv = vol[2 * i + 1];
+    li[i] = make_float4(1.0f * (tr.x * L.x + lv.x), 1.0f * (tr.y * L.y + lv.y), 1.0f * (tr.z * L.z + lv.z), L.w);
+}
+void gbl_launch_vol_combine(float4* li, const float4* vol, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vol_combine_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, li, vol, n);
+}
+
+// Film::writeImage's normalise step on the device: rgb = color / weight
+__global__ void film_resolve_kernel(const float* accum, float* rgb, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = reinterpret_cast<const float4*>(accum)[i];
+    float inv = 1.0f / a.w;
+    rgb[3 * i + 0] = a.x * inv;
+    rgb[3 * i + 1] = a.y * inv;
+    rgb[3 * i + 2] = a.z * inv;
+}
+void gbl_launch_film_resolve(const float* accum, float* rgb, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(film_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, rgb, n);
+}
+
+// ---------------------------------------------------------------------------
+// Device BLAS build (kernels/lbvh.h).  One mesh at a time: nodes are written at node_base (absolute child
+// references), DevTri records at tri_base in Morton order.  Returns the mesh's root reference.
+// ---------------------------------------------------------------------------
+namespace {
+struct LbvhScratch {
+    std::vector<void*> ptrs;
+    ~LbvhScratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    bool alloc(T** out, size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return false;
+        ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return true;
+    }
+};
+}  // namespace
+
+gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,
+                             DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base,
+                             int32_t* root_out, uint32_t* nodes_out, int* depth_out) {
+    LbvhScratch sc;
+    unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+    LbvhBox* tri_box = nullptr;
+    LbvhTree t;
+    memset(&t, 0, sizeof(t));
+    LbvhFrontier *fa = nullptr, *fb = nullptr;
+    uint32_t* counters = nullptr;   // [0] next frontier size, [1] nodes emitted
+    const size_t ni = n > 1 ? n - 1 : 1;
+    if (!sc.alloc(&keys, n) || !sc.alloc(&keys_sorted, n) || !sc.alloc(&tri_box, n) || !sc.alloc(&t.left, ni) || !sc.alloc(&t.right, ni) ||
+        !sc.alloc(&t.parent, 2 * static_cast<size_t>(n)) || !sc.alloc(&t.first, ni) || !sc.alloc(&t.last, ni) || !sc.alloc(&t.box, ni) ||
+        !sc.alloc(&t.leaf_box, n) || !sc.alloc(&t.visits, ni) || !sc.alloc(&fa, ni) || !sc.alloc(&fb, ni) || !sc.alloc(&counters, 2)) {
+        ctx->error = "hipMalloc(device BVH build scratch) failed";
+        return GBL_ERR_OOM;
+    }
+    LbvhBox mesh;
+    for (int a = 0; a < 3; ++a) {
+        mesh.lo[a] = lo[a];
+        mesh.hi[a] = hi[a];
+    }
+    const dim3 block(256), grid((n + 255) / 256);
+    hipLaunchKernelGGL(lbvh_keys, grid, block, 0, 0, d_pos, d_idx, n, mesh, keys, tri_box);
+    size_t temp_bytes = 0;
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
+    unsigned char* temp = nullptr;
+    if (!sc.alloc(&temp, temp_bytes)) {
+        ctx->error = "hipMalloc(radix sort scratch) failed";
+        return GBL_ERR_OOM;
+    }
+    HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
+    hipLaunchKernelGGL(lbvh_tris, grid, block, 0, 0, d_pos, d_idx, keys_sorted, n, shade_base, d_tris + tri_base);
+    *nodes_out = 0;
+    *depth_out = 0;
+    if (n <= GBL_MAX_LEAF_TRIS) {   // the whole mesh is one leaf
+        *root_out = ~static_cast<int32_t>((tri_base << 2) | (n - 1u));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        return GBL_OK;
+    }
+    hipLaunchKernelGGL(lbvh_gather_boxes, grid, block, 0, 0, keys_sorted, tri_box, n, t.leaf_box);
+    hipLaunchKernelGGL(lbvh_hierarchy, grid, block, 0, 0, keys_sorted, static_cast<int>(n), t);
+    HIP_TRY(ctx, hipMemsetAsync(t.visits, 0, ni * sizeof(uint32_t), 0));
+    hipLaunchKernelGGL(lbvh_fit, grid, block, 0, 0, static_cast<int>(n), t);
+    // collapse, one 4-wide level per launch
+    LbvhFrontier rootf = {0, 0};
+    uint32_t init[2] = {0u, 1u};
+    HIP_TRY(ctx, hipMemcpy(fa, &rootf, sizeof(rootf), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(counters, init, sizeof(init), hipMemcpyHostToDevice));
+    uint32_t n_in = 1;
+    int depth = 0;
+    while (n_in > 0) {
+        ++depth;
+        hipLaunchKernelGGL(lbvh_collapse, dim3((n_in + 255) / 256), block, 0, 0, t, fa, n_in, fb, counters, counters + 1, d_nodes + node_base,
+                           node_base, tri_base);
+        uint32_t h[2];
+        HIP_TRY(ctx, hipMemcpy(h, counters, sizeof(h), hipMemcpyDeviceToHost));
+        n_in = h[0];
+        *nodes_out = h[1];
+        HIP_TRY(ctx, hipMemsetAsync(counters, 0, sizeof(uint32_t), 0));
+        std::swap(fa, fb);
+        if (depth > 128) {
+            ctx->error = "device BVH build did not terminate";
+            return GBL_ERR_DEVICE;
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    *root_out = node_base;
+    *depth_out = depth;
+    return GBL_OK;
+}
+
+extern "C" {
+
+__global__ void selftest_sincos_kernel(const float* in, float* s, float* c, uint64_t n) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i] = gbl_sinf(in[i]);
+    c[i] = gbl_cosf(in[i]);
+}
+
+// rays: n x {kind (0 closest, 1 any), o(3), d(3), mint, maxt}; out: n x {t of the closest hit or -1 | 1 occluded or 0, instance, shading normal(3), tangent(3)}
+__global__ void selftest_trace_kernel(DevScene sc, const float* rays, float* out, uint32_t n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LdsStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x)};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 9 * i;
+    LaneCounters cnt = {};
+    Hit hit;
+    hit.inst = -1;
+    hit.t = -1.0f;
+    const F3 o = f3(r[1], r[2], r[3]), d = f3(r[4], r[5], r[6]);
+    float* q = out + 8 * i;
+    for (int k = 0; k < 8; ++k) q[k] = 0.0f;
+    if (r[0] != 0.0f) {
+        q[0] = trace<true, false, true>(sc, o, d, r[7], r[8], stk, hit, cnt) ? 1.0f : 0.0f;
+        q[1] = -1.0f;
+    } else {
+        const bool got = trace<false, false, true>(sc, o, d, r[7], r[8], stk, hit, cnt);
+        q[0] = got ? hit.t : -1.0f;
+        q[1] = got ? static_cast<float>(hit.inst) : -1.0f;
+        if (got) {
+            Frag fr;
+            make_fragment<true>(sc, hit, o, d, fr);
+            q[2] = fr.n.x; q[3] = fr.n.y; q[4] = fr.n.z;
+            q[5] = fr.t.x; q[6] = fr.t.y; q[7] = fr.t.z;
+        }
+    }
+}
+
+gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n) {
+    if (!ctx || !rays || !out) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    const size_t lds = static_cast<size_t>(ctx->scene.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(selftest_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds)));
+    hipLaunchKernelGGL(selftest_trace_kernel, dim3((n + GBL_BLOCK - 1) / GBL_BLOCK), dim3(GBL_BLOCK), lds, nullptr, ctx->scene, rays, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+
+// out[4 i ..] = {sqrtf(a), a / b, 1 / a, expected to be IEEE correctly rounded like the host's}
+__global__ void selftest_arith_kernel(const float* a, const float* b, float* out, uint64_t n) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[4 * i] = sqrtf(a[i]);
+    out[4 * i + 1] = a[i] / b[i];
+    out[4 * i + 2] = 1.0f / a[i];
+    const F3 v = normalize(f3(a[i], b[i], 0.5f));
+    out[4 * i + 3] = v.x;
+}
+gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n) {
+    if (!ctx || !a || !b || !out) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    hipLaunchKernelGGL(selftest_arith_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, a, b, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+
+gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
+    if (!ctx || !in || !sin_out || !cos_out) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    hipLaunchKernelGGL(selftest_sincos_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, in, sin_out, cos_out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+
+}   // extern "C"
