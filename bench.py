@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / l2 legs")
-    ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel"], default="auto")
+    ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel", "wavepool"], default="auto")
     args = ap.parse_args()
 
     import torch

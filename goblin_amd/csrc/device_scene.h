@@ -244,5 +244,6 @@ struct RenderArgs {
                                 // and a separate splat kernel filters it into the film afterwards
     float* film;                // xres*yres float4 accumulators
     uint32_t* work_counter;     // zeroed before each launch
+    void* wp_pool;              // wave-pool schedule: path state of the persistent waves (kernels/wavepool.h), or null
     unsigned long long* stats;  // 8 counters
 };

@@ -572,6 +572,7 @@ void gbl_destroy(gbl_ctx* ctx) {
     if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
     if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
     if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
+    if (ctx->wp_pool) (void)hipFree(ctx->wp_pool);
     if (ctx->wf_ev_shade) (void)hipEventDestroy(ctx->wf_ev_shade);
     if (ctx->wf_ev_shadow) (void)hipEventDestroy(ctx->wf_ev_shadow);
     if (ctx->wf_aux) (void)hipStreamDestroy(ctx->wf_aux);
@@ -796,6 +797,11 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;
     }
+    const bool wavepool = p->schedule == GBL_SCHEDULE_WAVEPOOL;
+    if (wavepool && (!wf_capable || stream_mode || sc.has_masks)) {
+        ctx->error = "the wave-pool schedule covers the path tracer on mask-free scenes under the native and replay samplers";
+        return GBL_ERR_UNSUPPORTED;
+    }
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));
     per_cu = std::max(1, per_cu);
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -990,6 +996,37 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
             ra.stream_tail_cap = L.S * tail_words;
             gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail_words), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;
+        } else if (wavepool) {
+            // every wave of the persistent grid owns WP_SLOTS path slots (kernels/wavepool.h); the grid is exactly what is
+            // resident, so the pool is a few tens of MB and stays in L2 / Infinity Cache
+            kernel = gbl_kernel_wavepool(replay, want_stats, ext || want_stats);
+            if (!kernel) {
+                ctx->error = "wave-pool kernel variant not built";
+                return GBL_ERR_UNSUPPORTED;
+            }
+            lds = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t) + (GBL_BLOCK / 64) * 2 * gbl_wavepool_slots() * sizeof(uint32_t);
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kernel), GBL_BLOCK, lds) != hipSuccess || occ < 1) occ = 1;
+            if (const char* e = getenv("GBL_WP_OCC")) occ = std::max(1, std::min(occ, atoi(e)));
+            // a wave keeps WP_SLOTS paths in flight: no more waves than the launch has paths for
+            const uint64_t paths_total = static_cast<uint64_t>(ra.local_tiles) * 64 * ra.spp;
+            const uint64_t wg_cap = std::max<uint64_t>(1, paths_total / (static_cast<uint64_t>(gbl_wavepool_slots()) * (GBL_BLOCK / 64)));
+            grid64 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_items, wg_cap), static_cast<uint64_t>(ctx->num_cus) * occ));
+            grid = dim3(static_cast<unsigned>(grid64));
+            const uint64_t need = grid64 * (GBL_BLOCK / 64) * gbl_wavepool_bytes_per_wave();
+            if (need > ctx->wp_pool_bytes) {
+                if (ctx->wp_pool) (void)hipFree(ctx->wp_pool);
+                ctx->wp_pool = nullptr;
+                ctx->wp_pool_bytes = 0;
+                if (hipMalloc(&ctx->wp_pool, need) != hipSuccess) {
+                    ctx->error = "hipMalloc(wave-pool path state) failed";
+                    return GBL_ERR_OOM;
+                }
+                ctx->wp_pool_bytes = need;
+            }
+            ra.wp_pool = ctx->wp_pool;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = gbl_kernel_path(replay, want_stats, ext || want_stats);
         } else {
@@ -1016,6 +1053,10 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         }
         if (sc.volume.on != 0u && !defer) {
             ctx->error = "a scene with a participating medium needs the per-sample radiance buffer: render this window in smaller pieces";
+            return GBL_ERR_UNSUPPORTED;
+        }
+        if (wavepool && !defer) {
+            ctx->error = "the wave-pool schedule keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
         }
         if (stream_mode && !defer) {
@@ -1070,7 +1111,14 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
                 fprintf(stderr, "probe: stream sampler phases (share of the workgroups' time): emit %.1f%% permute %.1f%% assemble %.1f%% paths %.1f%% skip %.1f%%\n",
                         100.0 * h[25] / tot, 100.0 * h[26] / tot, 100.0 * h[27] / tot, 100.0 * h[28] / tot, 100.0 * h[29] / tot);
             }
-            if (getenv("GBL_PROBE") && h[11] + h[12] + h[13] + h[14] + h[15] + h[16] + h[17]) {
+            if (getenv("GBL_PROBE") && wavepool) {
+                fprintf(stderr, "probe: wave-pool refill events %llu, shade batches %llu with %.1f slots each, traversal iterations %llu with %.1f busy lanes each\n",
+                        h[11], h[12], h[12] ? static_cast<double>(h[13]) / h[12] : 0.0, h[14], h[14] ? static_cast<double>(h[15]) / h[14] : 0.0);
+                const double tt = static_cast<double>(h[18] + h[19] + h[20]);
+                if (tt > 0.0)
+                    fprintf(stderr, "probe: wave-pool time per phase (share of the waves' time): publish + shade %.1f%% refill %.1f%% traverse %.1f%%\n",
+                            100.0 * h[18] / tt, 100.0 * h[19] / tt, 100.0 * h[20] / tt);
+            } else if (getenv("GBL_PROBE") && h[11] + h[12] + h[13] + h[14] + h[15] + h[16] + h[17]) {
                 const char* names[7] = {"<=3", "4-7", "8-15", "16-31", "32-63", "64-127", ">=128"};
                 unsigned long long rays = 0, steps = 0;
                 for (int i = 0; i < 7; ++i) {

@@ -326,9 +326,11 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 // every ray runs and costs the headline kernel 1.4 % (measured both inlined and as a flag + second pass); the native
 // sampler's lean megakernel therefore compiles it out -- its ties, ~5 per 10^7 paths, fall to the device tree's own
 // order -- and so does the wavefront's lean extension kernel, while every replay / stream / instrumented build keeps it.
-template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true>
-__device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
-                                           int filter = GBL_FILTER_NONE) {
+// `any`: the query kind as a value -- a compile-time constant through trav_other<ANY, ...> below, a per-lane flag in the
+// wave-pool kernel (kernels/wavepool.h), whose lanes trace shadow and extension rays side by side.
+template <bool STATS, bool EXT, class STK, bool TIES>
+__device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, const bool ANY,
+                                                bool* occluded, int filter) {
     const int cur = st.cur;
     if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
     if (cur == GBL_STACK_EXIT) return true;
@@ -395,6 +397,11 @@ __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, co
     }
     st.cur = static_cast<int>(stk.load(--st.sp));
     return false;
+}
+template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true>
+__device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
+                                           int filter = GBL_FILTER_NONE) {
+    return trav_other_kind<STATS, EXT, STK, TIES>(sc, st, stk, cnt, ANY, occluded, filter);
 }
 
 __device__ __forceinline__ bool trav_at_interior(const TravState& st) {

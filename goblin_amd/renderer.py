@@ -119,7 +119,7 @@ class HipPathTracer:
         p.li_out = li_out.data_ptr() if li_out is not None else None
         p.russian_roulette = 1 if rr else 0
         p.collect_stats = 1 if stats else 0
-        p.schedule = {"auto": 0, "megakernel": 1, "wavefront": 2}.get(schedule, schedule)
+        p.schedule = {"auto": 0, "megakernel": 1, "wavefront": 2, "wavepool": 3}.get(schedule, schedule)
         torch = _torch()
         p.stream = torch.cuda.current_stream(self.device).cuda_stream
         return p

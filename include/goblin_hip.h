@@ -357,14 +357,18 @@ typedef enum gbl_sample_mode {
 
 /* How the device schedules the same arithmetic (identical per-sample radiance):
  *  WAVEFRONT   path pool in HBM, compacted ray queues, extend / shade / shadow kernels
- *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration */
+ *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration
+ *  WAVEPOOL    one persistent kernel; every wave runs its own wavefront loop over a small cache-resident
+ *              pool of path slots (trace with in-wave refill, shade in full batches; path tracer only,
+ *              mask-free scenes, native / replay samplers) */
 /* AUTO: max_ray_depth >= DEPTH or instanced triangles >= TRIS -> WAVEFRONT, else MEGAKERNEL */
 #define GBL_AUTO_WAVEFRONT_DEPTH 12
 #define GBL_AUTO_WAVEFRONT_TRIS 400000
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,
     GBL_SCHEDULE_MEGAKERNEL = 1,
-    GBL_SCHEDULE_WAVEFRONT = 2
+    GBL_SCHEDULE_WAVEFRONT = 2,
+    GBL_SCHEDULE_WAVEPOOL = 3
 } gbl_schedule;
 
 typedef struct gbl_render_params {
