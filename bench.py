@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mpaths/s of the HIP path tracer on BASELINE.json configs[1]
-(bunny.json, 512x512 film, 256 spp, max_ray_depth 8) on N MI355X GPUs.
+"""Headline benchmark: Mpaths/s of the HIP path tracer on N MI355X GPUs.
 
-    python bench.py                      # 1 GPU, 5 steps, 1 warmup
+    python bench.py                      # 1 GPU: BASELINE.json configs[1], 5 steps, 1 warmup
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full pass of the hot path over the workload with the scene already
-resident in HBM: zero the film, trace every camera path of the sample window
-(516x516 pixels x 256 spp = 68,161,536 paths), splat, and -- for N > 1 -- sum the
-film over the ranks with one RCCL all-reduce.  Rank 0 prints ONE JSON line.
+A "step" is one full pass of the hot path over the workload with the scene already resident in HBM: zero the film,
+trace every camera path of the sample window, splat, and -- for N > 1 -- sum the film over the ranks with one RCCL
+all-reduce.  Rank 0 prints ONE JSON line.
 
-Multi-GPU work split (goblin_amd/distributed.py):
-  --scaling weak   (default) every rank traces the whole window with its own sample
-                   set (seed + rank); the reduced film holds N x 256 spp.  Per-GPU
-                   work is fixed as N grows.
-  --scaling strong rank r traces every N-th 8x8 sample tile of the one 256-spp frame.
+Workloads (--workload):
+  bunny  BASELINE configs[1]: bunny.json, 512x512 film (516x516 sampled px), 256 spp, max_ray_depth 8 = 68,161,536
+         paths per step.  The default at N = 1: the configuration the headline metric is quoted on.
+  grid   BASELINE configs[3]: grid.json, 15 instances of the 69k-triangle bunny (1.04 M instanced triangles), 1024x1024
+         film, 256 spp, max_ray_depth 8 = 270,536,704 paths per step.  The default for N > 1, as north_star words it:
+         "image tiles shard across the 8 GPUs of one node with a final RCCL reduce of Film tiles".
+
+Multi-GPU work split (goblin_amd/distributed.py), --scaling:
+  strong (default for N > 1) rank r traces every N-th 8x8 sample tile of the ONE frame (Film::mergeTile's sum over
+         per-thread full-film tiles, GoblinFilm.cpp:140-153, becomes one all-reduce of the W x H float4 accumulators).
+  weak   every rank traces the whole window with its own sample set (seed + rank): the reduced film holds N x spp.
 """
 import argparse
 import json
@@ -31,23 +35,37 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def algorithmic_bytes(st, main_kernel_only=True):
-    """Algorithmic bytes of one launch: per ray 32 B per BVH box node tested +
-    48 B per triangle tested + 48 B (32 B ray in, 16 B hit out); per path 4 B per sample
-    dimension consumed + 16 B of radiance written.  The film splat (16 B per touched pixel)
-    belongs to the separate splat kernel and is excluded from the dominant kernel's figure."""
-    rays = st["extension_rays"] + st["shadow_rays"]
-    b = 32 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
-    if not main_kernel_only:
-        b += 16 * st["splats"]
-    return b
-
-
-def requested_bytes(st):
-    """Bytes the dominant kernel's loads/stores actually request for the same work: the 4-wide node is
-    64 B for four quantised boxes (16 B per box tested instead of 32)."""
+def algorithmic_bytes(st):
+    """Algorithmic bytes of one launch of the tracing kernel (with the build's real node size): per ray
+    64 B per BVH node VISITED (one 4-wide node = four 16-B quantised child boxes; st["nodes"] counts child boxes tested,
+    4 per visit) + 48 B per triangle tested + 48 B (32 B ray in, 16 B hit out); per path 4 B per sample dimension
+    consumed + 16 B of radiance written.  The film splat (16 B per touched pixel) belongs to the splat kernel."""
     rays = st["extension_rays"] + st["shadow_rays"]
     return 16 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
+
+
+def survey_literal_bytes(st):
+    """SURVEY 8d read literally on node VISITS: 32 B (the reference's CompactBVHNode) per node visited."""
+    rays = st["extension_rays"] + st["shadow_rays"]
+    return 32 * (st["nodes"] // 4) + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
+
+
+def pmc_for(kernel_tag, workload, schedule):
+    """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_<workload>_<schedule>.json,
+    written by tools/summarize_profile.py) -- only if they were collected from THIS source tree (build stamp)."""
+    from goblin_amd import build
+    path = os.path.join(REPO, "profiles", "pmc_%s_%s.json" % (workload, schedule))
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_%s_%s.json" % (workload, schedule)
+    with open(path) as f:
+        d = json.load(f)
+    stamp = build.source_stamp()
+    if d.get("source_stamp") != stamp:
+        return None, "%s was collected from source stamp %s, this tree is %s" % (os.path.basename(path), d.get("source_stamp"), stamp)
+    for name, c in d.get("counters_per_launch", {}).items():
+        if kernel_tag in name:
+            return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp), None
+    return None, "no kernel matching %r in %s" % (kernel_tag, os.path.basename(path))
 
 
 def cpu_baseline(workload_overrides, spp_sample, cores):
@@ -157,15 +175,56 @@ def l2_vs_cpu(tracer, workload_overrides, spp_sample, cores, seed):
             "sample": "512x512 film, %d spp, the oracle's counter-based samples replayed on the device" % spp_sample}
 
 
+WORKLOADS = {
+    # name: (scene, resolution, spp, depth, what it is)
+    "bunny": ("bunny", (512, 512), 256, 8, "BASELINE configs[1]: bunny.json, glass stand-in bunny (69120 tris) on a plane, spot light"),
+    "grid": ("grid", (1024, 1024), 256, 8, "BASELINE configs[3]: grid.json, 15 instances of the bunny BLAS (1.04 M instanced triangles)"),
+}
+VALU_CYCLES_PER_WAVE_INSTRUCTION = 4   # MI355X_MICROARCH.md: one wave64 f32 VALU instruction holds its SIMD's issue for 4 cycles
+SIMDS = 256 * 4
+
+
+def run_steps(render, zero_film, allreduce, barrier, sync, steps, warmup, world, make_event=None):
+    """The timed region of the contract: W untimed warmup steps, then exactly K steps bracketed by barrier + device sync on
+    both sides.  `render()` traces this rank's share into its film, `allreduce()` sums the films (N > 1).
+    Returns (elapsed seconds on this rank, per-step (render_ms, reduce_ms) from device events or None)."""
+    def step(ev=None):
+        zero_film()
+        if ev:
+            ev[0].record()
+        render()
+        if ev:
+            ev[1].record()
+        if world > 1:
+            allreduce()
+        if ev:
+            ev[2].record()
+
+    for _ in range(warmup):
+        step()
+    events = [tuple(make_event() for _ in range(3)) for _ in range(steps)] if make_event else [None] * steps
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(events[i])
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_step = [(e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])) for e in events] if make_event else None
+    return elapsed, per_step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--resolution", type=int, nargs=2, default=[512, 512])
-    ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: bunny at N = 1, grid for N > 1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="default for N > 1: strong (tile shards of one frame)")
+    ap.add_argument("--resolution", type=int, nargs=2, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / l2 legs")
     ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel", "wavepool"], default="auto")
     args = ap.parse_args()
@@ -174,6 +233,7 @@ def main():
     import torch.distributed as dist
     from goblin_amd import distributed as gd
     from goblin_amd import scene as gs
+    from goblin_amd import _abi
     from goblin_amd.renderer import HipPathTracer
 
     rank, local_rank, world = gd.init()
@@ -188,42 +248,45 @@ def main():
     device_index = local_rank % max(1, ndev)   # one GPU per rank on a full node; ranks share GPUs only in the gloo rehearsal
     torch.cuda.set_device(device_index)
 
-    overrides = gs.config_overrides(resolution=tuple(args.resolution), spp=args.spp, depth=args.depth)
-    scene = gs.load_scene("bunny", overrides)
+    wl_name = args.workload or ("bunny" if world == 1 else "grid")
+    scene_name, res, spp, depth, wl_text = WORKLOADS[wl_name]
+    res = tuple(args.resolution) if args.resolution else res
+    spp = args.spp or spp
+    depth = args.depth or depth
+    standard = (res, spp, depth) == WORKLOADS[wl_name][1:4]
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    overrides = gs.config_overrides(resolution=res, spp=spp, depth=depth)
+    scene = gs.load_scene(scene_name, overrides)
     tracer = HipPathTracer(scene, device_index)
     film = tracer.new_film()
     base_seed = 20261003
-    part = gd.shard_for(rank, world, "samples" if args.scaling == "weak" else "tiles", base_seed)
+    part = gd.shard_for(rank, world, "samples" if scaling == "weak" else "tiles", base_seed)
 
     # counters for the roofline (one instrumented launch, outside the timed region;
     # the sampler is counter-based so every timed launch does exactly this work)
     counted = tracer.render(film=film, seed=part["seed"], shard=part["shard"], stats=True, schedule=args.schedule)["stats"]
     my_paths = counted["paths"]
 
-    def step(ev=None):
-        film.zero_()
-        if ev is not None:
-            ev[0].record()
-        tracer.render(film=film, seed=part["seed"], shard=part["shard"], schedule=args.schedule)
-        if ev is not None:
-            ev[1].record()
-        if world > 1:
-            gd.allreduce_film(film.accum)
+    one_gpu_ms = None
+    if world > 1 and rank == 0 and scaling == "strong":
+        # the WHOLE frame on one GPU, outside the timed region: the N-GPU line then carries its own strong-scaling baseline
+        whole = tracer.new_film()
+        tracer.render(film=whole, seed=base_seed, schedule=args.schedule)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        whole.zero_()
+        tracer.render(film=whole, seed=base_seed, schedule=args.schedule)
+        torch.cuda.synchronize()
+        one_gpu_ms = (time.perf_counter() - t1) * 1e3
+        del whole
 
     if world > 1:   # set the communicator up outside the timed region even when --warmup is 0
         gd.allreduce_film(torch.zeros(16, device=tracer.device))
         gd.barrier()
-    for _ in range(args.warmup):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    gd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
-    torch.cuda.synchronize()
-    gd.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, per_step = run_steps(
+        render=lambda: tracer.render(film=film, seed=part["seed"], shard=part["shard"], schedule=args.schedule),
+        zero_film=film.zero_, allreduce=lambda: gd.allreduce_film(film.accum), barrier=gd.barrier, sync=torch.cuda.synchronize,
+        steps=args.steps, warmup=args.warmup, world=world, make_event=lambda: torch.cuda.Event(enable_timing=True))
 
     red_dev = tracer.device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -234,26 +297,59 @@ def main():
     elapsed = float(t.item())
     job_paths = float(paths.item())   # paths all ranks traced in one step
 
-    resolved = args.schedule if args.schedule != "auto" else ("wavefront" if args.depth >= 12 else "megakernel")
+    auto_wavefront = depth >= _abi.GBL_AUTO_WAVEFRONT_DEPTH or tracer.info.instanced_triangles >= _abi.GBL_AUTO_WAVEFRONT_TRIS
+    resolved = args.schedule if args.schedule != "auto" else ("wavefront" if auto_wavefront else "megakernel")
     if rank == 0:
-        call_ms = sorted(e0.elapsed_time(e1) for e0, e1 in events)          # torch events around gbl_render
-        timings = tracer.timings(args.steps)                                   # HIP events inside, per kernel class
-        main_ms = [t[0] for t in timings] or call_ms
+        call_ms = [a for a, _ in per_step]                                    # device events around gbl_render (the launch stream)
+        reduce_ms = [b for _, b in per_step]
+        timings = tracer.timings(args.steps)                                   # HIP events inside the library, per kernel class
+        main_ms = [x[0] for x in timings] or call_ms
         avg_kernel_ms = sum(main_ms) / len(main_ms)
         alg_bytes = algorithmic_bytes(counted)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        req_bytes = requested_bytes(counted)
-        traffic, pmc = None, {}
-        tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath) and args.spp == 256 and args.resolution == [512, 512] and args.depth == 8 and world == 1 \
-                and resolved == "megakernel":
-            with open(tpath) as f:
-                pmc = json.load(f)
-            traffic = pmc.get("hbm_bytes_per_launch")
+        kernel_tag = {"megakernel": "path_trace_kernel<false, false, false, false>", "wavepool": "wp_kernel<false, false, false>",
+                      "wavefront": "wf_trace<false, false, false, false, false>"}[resolved]
+        pmc, pmc_note = (pmc_for(kernel_tag, wl_name, resolved) if (standard and world == 1) else (None, "non-standard run: no counters quoted"))
         rays = counted["extension_rays"] + counted["shadow_rays"]
         value = job_paths * args.steps / elapsed * 1e-6
+        window_px = (tracer.window[1] - tracer.window[0], tracer.window[3] - tracer.window[2])
+        hbm = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": round(achieved / HBM_PEAK_GBPS, 4),
+               "algorithmic_bytes_per_launch": int(alg_bytes),
+               "survey_8d_literal": {"bytes_per_launch": int(survey_literal_bytes(counted)),
+                                     "frac": round(survey_literal_bytes(counted) / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+               "note": "algorithmic bytes (64 B per 4-wide node visited, 48 B per triangle, 48 B per ray, 4 B per sample "
+                       "dimension, 16 B per path) over the kernel's measured time: a cache-served figure -- the scene is "
+                       "L2-resident, `traffic` below is what reaches HBM"}
+        roofline = dict(hbm)
+        if pmc and pmc.get("SQ_INSTS_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+            # the kernel is VALU-issue bound: its instruction stream over what the 1024 SIMDs can issue in the measured time.
+            # Instruction count from the stamped PMC pass of this very build; time and clock measured here / there.
+            clock_hz = pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["kernel_avg_ms"] * 1e-3)
+            peak = SIMDS * clock_hz / VALU_CYCLES_PER_WAVE_INSTRUCTION * 1e-9
+            ach = pmc["SQ_INSTS_VALU"] / (avg_kernel_ms * 1e-3) * 1e-9
+            traffic = int((2 * pmc.get("FETCH_SIZE", 0.0) + pmc.get("WRITE_SIZE", 0.0)) * 1024) if "FETCH_SIZE" in pmc else None
+            roofline = {"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                        "frac": round(ach / peak, 4), "traffic": traffic,
+                        "valu_wave_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]),
+                        "valu_busy_pmc": round(pmc["SQ_ACTIVE_INST_VALU"] * 4 / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS), 4) if "SQ_ACTIVE_INST_VALU" in pmc else None,
+                        "clock_ghz_pmc": round(clock_hz * 1e-9, 3),
+                        "l2_hit_rate": round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in pmc else None,
+                        "pmc": {"file": pmc["file"], "source_stamp": pmc["source_stamp"], "kernel": pmc["kernel"],
+                                "kernel_avg_ms_rocprof": pmc["kernel_avg_ms"]},
+                        "hbm": dict(hbm, traffic=traffic, traffic_gbps=round(traffic / (avg_kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
+                        "note": "peak = 1024 SIMDs x clock / 4 cycles per wave64 VALU instruction; frac = the share of the "
+                                "SIMDs' issue slots the kernel's own instruction stream fills -- high means issue bound, and "
+                                "the headroom is in the lanes (see DESIGN.md 4.1: lane utilisation), not in this fraction"}
+        else:
+            roofline["traffic"] = None
+            roofline["pmc_note"] = pmc_note
+        roofline.update({"kernel": kernel_tag if resolved != "wavefront" else "wf_trace / wf_shade (all wavefront kernels of a step)",
+                         "kernel_ms_avg": round(avg_kernel_ms, 3), "call_ms_avg": round(sum(call_ms) / len(call_ms), 3),
+                         "counters": {k: int(v) for k, v in counted.items() if k != "kernel_ms"}})
         line = {
-            "metric": "Mpaths/sec at 512x512x256spp (GoblinPathtracer hot path, bunny.json, max_ray_depth 8)",
+            "metric": "Mpaths/sec at 512x512x256spp (GoblinPathtracer hot path, bunny.json, max_ray_depth 8)" if wl_name == "bunny" and standard
+                      else "Mpaths/sec at %dx%dx%dspp (GoblinPathtracer hot path, %s.json, max_ray_depth %d)" % (res[0], res[1], scene.spp(), scene_name, depth),
             "value": round(value, 3),
             "unit": "Mpaths/s",
             "n_gpus": world,
@@ -261,47 +357,34 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "bunny.json %dx%d film (%dx%d sampled px), %d spp, max_ray_depth %d, gaussian r=2, glass "
-                            "stand-in bunny (69120 tris) + spot light" % (
-                                args.resolution[0], args.resolution[1], tracer.window[1] - tracer.window[0],
-                                tracer.window[3] - tracer.window[2], scene.spp(), args.depth),
+                "workload": "%s -- %dx%d film (%dx%d sampled px), %d spp, max_ray_depth %d, gaussian r=2" % (
+                    wl_text, res[0], res[1], window_px[0], window_px[1], scene.spp(), depth),
                 "schedule": resolved,
                 "paths_per_step": int(job_paths),
                 "rays_per_path": round(rays / max(1, my_paths), 3),
                 "mrays_per_s": round(value * rays / max(1, my_paths), 2),
                 "sampler": "native counter-based, reference stratification law",
-                "sharding": {"weak": "whole window per rank, seed+rank, RCCL film all-reduce",
-                             "strong": "8x8 tiles interleaved over ranks, RCCL film all-reduce"}[args.scaling]
-                if world > 1 else "single GPU",
+                "sharding": ({"weak": "whole window per rank, seed+rank, one film all-reduce",
+                              "strong": "8x8 tiles interleaved over ranks (rank r owns tiles t = r mod N), one film all-reduce"}[scaling]
+                             if world > 1 else "single GPU"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": traffic,
-                "kernel": "path_trace_kernel<false,false,false,false>" if resolved != "wavefront" else "wf_trace/wf_shade (all wavefront kernels of a step)",
-                "kernel_ms_avg": round(avg_kernel_ms, 3),
-                "call_ms_avg": round(sum(call_ms) / len(call_ms), 3),
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-                "requested_bytes_per_launch": int(req_bytes),
-                "achieved_requested": round(req_bytes / (avg_kernel_ms * 1e-3) / 1e9, 2),
-                "note": "algorithmic = SURVEY 8d convention (32 B per box node tested); requested = what the 4-wide "
-                        "quantised node layout really loads (16 B per box); traffic = HBM bytes from rocprofv3 PMC "
-                        "(profiles/), the scene is cache resident",
-                "counters": {k: int(v) for k, v in counted.items() if k != "kernel_ms"},
-                # from the committed rocprofv3 PMC passes of this command (profiles/): what really bounds the kernel
-                "valu_busy_frac": pmc.get("valu_busy_frac"),
-                "l2_hit_rate": pmc.get("l2_hit_rate"),
-            },
+            "roofline": roofline,
         }
-        if world == 1:
+        if world > 1:
+            line["collective"] = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (CPU rehearsal)"),
+                                  "ranks": dist.get_world_size(), "op": "all_reduce(sum) of the film accumulators",
+                                  "bytes": int(film.accum.numel() * 4),
+                                  "ms_avg": round(sum(reduce_ms) / len(reduce_ms), 3), "trace_ms_avg": round(sum(call_ms) / len(call_ms), 3)}
+            if one_gpu_ms is not None:
+                line["config"]["one_gpu_same_workload"] = {"ms_per_step": round(one_gpu_ms, 3), "mpaths_per_s": round(job_paths / one_gpu_ms * 1e-3, 2),
+                                                           "speedup": round(one_gpu_ms / (elapsed / args.steps * 1e3), 3),
+                                                           "note": "rank 0 alone, whole frame, outside the timed region"}
+        if world == 1 and wl_name == "bunny":
             # the same frame with the reference's own mt19937 sample stream generated on the device (GBL_SAMPLES_STREAM):
             # its Film is the reference binary's; reported beside the headline, never as `value`
             try:
@@ -319,12 +402,15 @@ def main():
                 del sfilm
             except Exception as e:
                 print("reference_stream_sampler leg failed: %s" % e, file=sys.stderr)
-        if world == 1 and not args.no_cpu:
-            cores = max(1, min(16, len(os.sched_getaffinity(0))))
-            # the CPU leg renders the FULL workload when the box has the cores to do it in ~15 s (68 M paths at
-            # ~5 Mpaths/s on 16 threads), so that its Film can be compared at BASELINE's own size; fewer samples otherwise
-            cpu_spp = args.spp if cores >= 12 else (64 if cores >= 4 else 16)
+        if world == 1 and wl_name == "bunny" and not args.no_cpu:
+            # every host core this process may run on (the reference defaults to hardware_concurrency, GoblinThreadPool.cpp:5-10)
+            cores = max(1, len(os.sched_getaffinity(0)))
+            # the CPU leg renders the FULL workload when the box has the cores to do it in ~15-30 s (68 M paths at
+            # ~0.3 Mpaths/s per thread), so that its Film can be compared at BASELINE's own size; fewer samples otherwise
+            cpu_spp = spp if cores >= 12 else (64 if cores >= 4 else 16)
             line["cpu_baseline"] = cpu_baseline(overrides, cpu_spp, cores)
+            if line["cpu_baseline"]:
+                line["cpu_baseline"]["host"] = {"os_cpu_count": os.cpu_count(), "affinity": cores}
             ref_film = line["cpu_baseline"].pop("_film", None) if line["cpu_baseline"] else None
             if ref_film is not None:
                 try:
@@ -332,7 +418,7 @@ def main():
                 except Exception as e:
                     print("l2_vs_reference failed: %s" % e, file=sys.stderr)
             try:
-                line["l2_vs_cpu"] = l2_vs_cpu(tracer, overrides, 16, cores, base_seed)
+                line["l2_vs_cpu"] = l2_vs_cpu(tracer, overrides, 16, min(cores, 32), base_seed)
             except Exception as e:
                 print("l2_vs_cpu failed: %s" % e, file=sys.stderr)
             if line["cpu_baseline"]:

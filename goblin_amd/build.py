@@ -102,3 +102,19 @@ def build_all(force=False):
 
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv)
+
+
+def source_stamp():
+    """sha256 (first 16 hex digits) over every source file the HIP library is built from: profiles/ records it with the
+    counters it collects, bench.py only quotes counters whose stamp is the running tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for root, _, names in os.walk(CSRC):
+        files += [os.path.join(root, n) for n in names if n.endswith((".h", ".hip", ".cpp"))]
+    files.append(os.path.join(REPO, "include", "goblin_hip.h"))
+    for f in sorted(files):
+        h.update(os.path.relpath(f, REPO).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -19,6 +19,7 @@
 
 #include "../../include/goblin_hip.h"
 #include "device_scene.h"
+#include "abi_guard.h"
 #include "gbl_internal.h"
 #include "kernels/stream.h"     // StreamLayout: the host sizes the stream sampler's scratch
 #include "kernels/trace.h"      // GBL_WF_STACK_LDS
@@ -275,9 +276,15 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     const uint64_t max_wgs = (pool / 64 + 3) / 4;
     unsigned ext_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_ext, max_wgs)));
     unsigned shd_wgs = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(ctx->num_cus) * occ_shd, max_wgs)));
-    // the two trace launches may run at the same time: disjoint columns of the stack backing
+    // the two trace launches may run at the same time: disjoint columns of the stack backing (ext <= 7 and shd = 1
+    // workgroups per CU of the 8 the backing is sized for).  Without the overlap they are serialised on one stream and
+    // each may take up to 8 per CU, so they share the columns.
     uint32_t* const spill_ext = ctx->wf_spill;
-    uint32_t* const spill_shd = ctx->wf_spill + static_cast<size_t>(ctx->wf_spill_levels) * ext_wgs * GBL_BLOCK;
+    uint32_t* const spill_shd = overlap ? ctx->wf_spill + static_cast<size_t>(ctx->wf_spill_levels) * ext_wgs * GBL_BLOCK : ctx->wf_spill;
+    if (static_cast<uint64_t>(overlap ? ext_wgs + shd_wgs : std::max(ext_wgs, shd_wgs)) > static_cast<uint64_t>(ctx->num_cus) * 8) {
+        ctx->error = "wavefront trace grids exceed the stack backing";
+        return GBL_ERR_DEVICE;
+    }
     dim3 block(GBL_BLOCK), grid_ext(ext_wgs), grid_shd(shd_wgs), grid_shade(pool / GBL_BLOCK);
     gbl_wf_kernel k_shade = gbl_kernel_wf_shade(replay, want_stats, ext || want_stats);
     gbl_wf_kernel k_splat = gbl_kernel_wf_splat(replay, want_stats);
@@ -352,7 +359,7 @@ gbl_status gbl_create(const gbl_scene_desc* desc, int device, gbl_ctx** out) {
     return gbl_create_ex(desc, device, (e && !strcmp(e, "device")) ? GBL_CREATE_DEVICE_BVH : 0u, out);
 }
 
-gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags, gbl_ctx** out) {
+static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uint32_t flags, gbl_ctx** out) {
     const bool device_bvh = (flags & GBL_CREATE_DEVICE_BVH) != 0;
     if (!desc || !out) {
         g_create_error = "null argument";
@@ -507,8 +514,11 @@ gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags,
     *out = ctx;
     return GBL_OK;
 }
+gbl_status gbl_create_ex(const gbl_scene_desc* desc, int device, uint32_t flags, gbl_ctx** out) {
+    return gbl_guard([&] { return gbl_create_ex_impl(desc, device, flags, out); }, [&](const std::string& what) { g_create_error = what; });
+}
 
-gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world) {
+static gbl_status gbl_update_instances_impl(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world) {
     if (!ctx) return GBL_ERR_INVALID;
     if (!to_world || static_cast<uint64_t>(first) + count > ctx->h_instances.size()) {
         ctx->error = "gbl_update_instances: instance range out of bounds";
@@ -559,6 +569,9 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
     ctx->info.tlas_nodes = tlas.size();
     ctx->h_instances.swap(edited);
     return GBL_OK;
+}
+gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world) {
+    return gbl_guard([&] { return gbl_update_instances_impl(ctx, first, count, to_world); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
 }
 
 void gbl_destroy(gbl_ctx* ctx) {
@@ -620,7 +633,7 @@ std::vector<uint32_t> glibc_rand_sequence(size_t n) {
 
 extern "C" {
 
-gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accum, gbl_stats* stats) {
+static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, float* film_accum, gbl_stats* stats) {
     if (!ctx) return GBL_ERR_INVALID;
     if (!p || !film_accum) {
         ctx->error = "null argument";
@@ -797,11 +810,14 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
         ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;
     }
-    const bool wavepool = p->schedule == GBL_SCHEDULE_WAVEPOOL;
+    bool wavepool = p->schedule == GBL_SCHEDULE_WAVEPOOL;
     if (wavepool && (!wf_capable || stream_mode || sc.has_masks)) {
         ctx->error = "the wave-pool schedule covers the path tracer on mask-free scenes under the native and replay samplers";
         return GBL_ERR_UNSUPPORTED;
     }
+    // the wave-pool kernel writes per-sample radiance only (no LDS film tile): a call whose radiance buffer exceeds the
+    // budget runs the megakernel, which then splats through its tile -- same arithmetic, same film
+    if (wavepool && !ra.li_out && (npix * ra.spp * 16 > li_budget_bytes(ctx) || npix * ra.spp >= (1ull << 32))) wavepool = false;
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));
     per_cu = std::max(1, per_cu);
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -1141,6 +1157,9 @@ gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accu
     }
     return GBL_OK;
 }
+gbl_status gbl_render(gbl_ctx* ctx, const gbl_render_params* p, float* film_accum, gbl_stats* stats) {
+    return gbl_guard([&] { return gbl_render_impl(ctx, p, film_accum, stats); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
+}
 
 int gbl_get_timings(gbl_ctx* ctx, int n, gbl_timing* out) {
     if (!ctx || !out || n <= 0) return 0;
@@ -1158,7 +1177,7 @@ int gbl_get_timings(gbl_ctx* ctx, int n, gbl_timing* out) {
     return n;
 }
 
-gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_out, void* stream) {
+static gbl_status gbl_film_resolve_impl(gbl_ctx* ctx, const float* film_accum, float* rgb_out, void* stream) {
     if (!ctx || !film_accum || !rgb_out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int n = ctx->info.xres * ctx->info.yres;
@@ -1166,10 +1185,13 @@ gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_ou
     HIP_TRY(ctx, hipGetLastError());
     return GBL_OK;
 }
+gbl_status gbl_film_resolve(gbl_ctx* ctx, const float* film_accum, float* rgb_out, void* stream) {
+    return gbl_guard([&] { return gbl_film_resolve_impl(ctx, film_accum, rgb_out, stream); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
+}
 
 // ncclAllReduce(sum, float) over the film, resolved from librccl at first use so
 // single-GPU users never load RCCL.
-gbl_status gbl_film_allreduce(gbl_ctx* ctx, void* rccl_comm, float* film_accum, void* stream) {
+static gbl_status gbl_film_allreduce_impl(gbl_ctx* ctx, void* rccl_comm, float* film_accum, void* stream) {
     if (!ctx || !rccl_comm || !film_accum) return GBL_ERR_INVALID;
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     if (!ctx->rccl_allreduce) {
@@ -1195,6 +1217,9 @@ gbl_status gbl_film_allreduce(gbl_ctx* ctx, void* rccl_comm, float* film_accum, 
         return GBL_ERR_DEVICE;
     }
     return GBL_OK;
+}
+gbl_status gbl_film_allreduce(gbl_ctx* ctx, void* rccl_comm, float* film_accum, void* stream) {
+    return gbl_guard([&] { return gbl_film_allreduce_impl(ctx, rccl_comm, film_accum, stream); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
 }
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../../include/goblin_hip.h"
+#include "../abi_guard.h"
 
 namespace gbl_host_detail {
 gbl_status fail(gbl_status st, const std::string& msg);   // scene_loader.cpp: sets gbl_host_last_error
@@ -76,7 +77,7 @@ void put_attr(std::vector<uint8_t>& b, const char* name, const char* type, const
 
 extern "C" {
 
-void gbl_host_bloom(float* rgb, int32_t width, int32_t height, float bloom_radius, float bloom_weight) {
+static void gbl_host_bloom_impl(float* rgb, int32_t width, int32_t height, float bloom_radius, float bloom_weight) {
     if (bloom_radius <= 0.0f || bloom_weight <= 0.0f) return;
     int fw = static_cast<int>(std::ceil(bloom_radius * std::max(width, height))) / 2;
     if (fw <= 0) return;   // the reference would divide 0 by 0 for every pixel; a zero-tap filter is a no-op here
@@ -111,8 +112,11 @@ void gbl_host_bloom(float* rgb, int32_t width, int32_t height, float bloom_radiu
         }
     for (size_t i = 0; i < res.size(); ++i) rgb[i] = (1.0f - bloom_weight) * rgb[i] + bloom_weight * res[i];
 }
+void gbl_host_bloom(float* rgb, int32_t width, int32_t height, float bloom_radius, float bloom_weight) {   // out of memory leaves the image as it was
+    (void)gbl_guard([&] { gbl_host_bloom_impl(rgb, width, height, bloom_radius, bloom_weight); return GBL_OK; }, [](const std::string&) {});
+}
 
-void gbl_host_tone_map(float* rgb, int32_t width, int32_t height) {
+static void gbl_host_tone_map_impl(float* rgb, int32_t width, int32_t height) {
     const size_t n = static_cast<size_t>(width) * height;
     float ywa = 0.0f;
     for (size_t i = 0; i < n; ++i) ywa += logf(1e4f + luminance(rgb + 3 * i));
@@ -126,8 +130,11 @@ void gbl_host_tone_map(float* rgb, int32_t width, int32_t height) {
         rgb[3 * i + 2] *= s;
     }
 }
+void gbl_host_tone_map(float* rgb, int32_t width, int32_t height) {   // out of memory leaves the image as it was
+    (void)gbl_guard([&] { gbl_host_tone_map_impl(rgb, width, height); return GBL_OK; }, [](const std::string&) {});
+}
 
-gbl_status gbl_host_write_ppm(const char* path, const float* rgb, int32_t width, int32_t height) {
+static gbl_status gbl_host_write_ppm_impl(const char* path, const float* rgb, int32_t width, int32_t height) {
     FILE* fp = fopen(path, "w");
     if (!fp) return fail(GBL_ERR_IO, std::string("can not open file ") + path);
     fprintf(fp, "P3\n%d %d\n%d\n", width, height, 255);
@@ -144,8 +151,11 @@ gbl_status gbl_host_write_ppm(const char* path, const float* rgb, int32_t width,
     fclose(fp);
     return GBL_OK;
 }
+gbl_status gbl_host_write_ppm(const char* path, const float* rgb, int32_t width, int32_t height) {
+    return gbl_guard([&] { return gbl_host_write_ppm_impl(path, rgb, width, height); }, [](const std::string&) {});
+}
 
-gbl_status gbl_host_write_exr(const char* path, const float* rgb, int32_t width, int32_t height) {
+static gbl_status gbl_host_write_exr_impl(const char* path, const float* rgb, int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return fail(GBL_ERR_INVALID, "image size must be positive");
     std::vector<uint8_t> b;
     const uint32_t magic = 20000630u, version = 2u;   // single-part scanline, short names
@@ -222,8 +232,11 @@ gbl_status gbl_host_write_exr(const char* path, const float* rgb, int32_t width,
     if (wrote != b.size()) return fail(GBL_ERR_IO, std::string("short write to ") + path);
     return GBL_OK;
 }
+gbl_status gbl_host_write_exr(const char* path, const float* rgb, int32_t width, int32_t height) {
+    return gbl_guard([&] { return gbl_host_write_exr_impl(path, rgb, width, height); }, [](const std::string&) {});
+}
 
-gbl_status gbl_host_write_image(const char* path, float* rgb, int32_t width, int32_t height, int32_t tone_mapping) {
+static gbl_status gbl_host_write_image_impl(const char* path, float* rgb, int32_t width, int32_t height, int32_t tone_mapping) {
     if (!path || !rgb) return fail(GBL_ERR_INVALID, "null argument");
     std::string filename(path);
     size_t dot = filename.rfind(".");
@@ -236,6 +249,9 @@ gbl_status gbl_host_write_image(const char* path, float* rgb, int32_t width, int
     if (ext == ".exr" || ext == ".EXR") return gbl_host_write_exr(path, rgb, width, height);
     if (ext == ".pfm" || ext == ".PFM") return gbl_host_write_pfm(path, rgb, width, height);   // build-side extra
     return gbl_host_write_ppm((filename + ".ppm").c_str(), rgb, width, height);   // "format is not supported yet"
+}
+gbl_status gbl_host_write_image(const char* path, float* rgb, int32_t width, int32_t height, int32_t tone_mapping) {
+    return gbl_guard([&] { return gbl_host_write_image_impl(path, rgb, width, height, tone_mapping); }, [](const std::string&) {});
 }
 
 }  // extern "C"

@@ -19,7 +19,8 @@ struct Value {
     double d = 0.0;
     std::string s;
     std::vector<Value> arr;
-    // first definition of a key wins, keys iterate sorted (std::map like the reference's json type)
+    // a repeated key keeps its LAST value (the reference's nlohmann DOM parser does operator[](key) and assigns,
+    // json.hpp:2899,2987); keys iterate sorted (std::map like the reference's json type)
     std::map<std::string, Value> obj;
 
     bool is_number() const { return kind == Int || kind == Float; }
@@ -143,7 +144,17 @@ private:
         }
         return true;
     }
+    // containers nest at most kMaxDepth deep: a hostile file cannot run the recursive descent out of stack
+    static const int kMaxDepth = 256;
+    int depth_ = 0;
+    struct DepthGuard {
+        int& d;
+        explicit DepthGuard(int& dd) : d(dd) { ++d; }
+        ~DepthGuard() { --d; }
+    };
     bool value(Value* out) {
+        DepthGuard guard(depth_);
+        if (depth_ > kMaxDepth) return fail("json nested too deeply");
         skip();
         if (p_ >= end_) return fail("unexpected end of json");
         char c = *p_;
@@ -164,7 +175,7 @@ private:
                 ++p_;
                 Value v;
                 if (!value(&v)) return false;
-                out->obj.insert(std::make_pair(key, std::move(v)));
+                out->obj[key] = std::move(v);
                 skip();
                 if (p_ < end_ && *p_ == ',') {
                     ++p_;

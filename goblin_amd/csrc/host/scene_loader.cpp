@@ -20,6 +20,7 @@
 
 #include "../../../include/goblin_hip.h"
 #include "json_lite.h"
+#include "../abi_guard.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -1049,8 +1050,11 @@ extern "C" {
 
 static gbl_status load_text(const char* json_text, const char* scene_dir, const std::string& default_output, gbl_host_scene** out);
 
-gbl_status gbl_host_load_string(const char* json_text, const char* scene_dir, gbl_host_scene** out) {
+static gbl_status gbl_host_load_string_impl(const char* json_text, const char* scene_dir, gbl_host_scene** out) {
     return load_text(json_text, scene_dir, "goblin.exr", out);   // createImageFilm's own default (GoblinFilm.cpp:212)
+}
+gbl_status gbl_host_load_string(const char* json_text, const char* scene_dir, gbl_host_scene** out) {
+    return gbl_guard([&] { return gbl_host_load_string_impl(json_text, scene_dir, out); }, [&](const std::string& what) { g_last_error = what; });
 }
 
 static gbl_status load_text(const char* json_text, const char* scene_dir, const std::string& default_output, gbl_host_scene** out) {
@@ -1074,7 +1078,7 @@ static gbl_status load_text(const char* json_text, const char* scene_dir, const 
     return GBL_OK;
 }
 
-gbl_status gbl_host_load_file(const char* json_path, gbl_host_scene** out) {
+static gbl_status gbl_host_load_file_impl(const char* json_path, gbl_host_scene** out) {
     if (!json_path || !out) return fail(GBL_ERR_INVALID, "null argument");
     *out = nullptr;
     bool ok;
@@ -1090,6 +1094,9 @@ gbl_status gbl_host_load_file(const char* json_path, gbl_host_scene** out) {
     if (ext != std::string::npos && ext < path.length() - 1 && path[ext + 1] != '/' && path[ext + 1] != '\\') def = path.substr(0, ext) + ".exr";
     else def = path + ".exr";
     return load_text(text.c_str(), dir.c_str(), def, out);
+}
+gbl_status gbl_host_load_file(const char* json_path, gbl_host_scene** out) {
+    return gbl_guard([&] { return gbl_host_load_file_impl(json_path, out); }, [&](const std::string& what) { g_last_error = what; });
 }
 
 const char* gbl_host_output_path(const gbl_host_scene* scene) { return scene ? scene->output_path.c_str() : ""; }
@@ -1150,13 +1157,16 @@ void gbl_host_film_normalize(const float* accum, int32_t xres, int32_t yres, flo
     }
 }
 
-gbl_status gbl_host_write_pfm(const char* path, const float* rgb, int32_t xres, int32_t yres) {
+static gbl_status gbl_host_write_pfm_impl(const char* path, const float* rgb, int32_t xres, int32_t yres) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(GBL_ERR_IO, std::string("can't open ") + path);
     fprintf(f, "PF\n%d %d\n-1.0\n", xres, yres);
     for (int y = yres - 1; y >= 0; --y) fwrite(rgb + 3 * static_cast<size_t>(y) * xres, sizeof(float), 3 * static_cast<size_t>(xres), f);
     fclose(f);
     return GBL_OK;
+}
+gbl_status gbl_host_write_pfm(const char* path, const float* rgb, int32_t xres, int32_t yres) {
+    return gbl_guard([&] { return gbl_host_write_pfm_impl(path, rgb, xres, yres); }, [&](const std::string& what) { g_last_error = what; });
 }
 
 }  // extern "C"

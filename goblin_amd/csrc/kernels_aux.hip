@@ -1,5 +1,6 @@
 // libgoblin_hip.so, kernel unit: the first-hit passes (subsurface term, participating medium), the film resolve, the
 // device BLAS build (kernels/lbvh.h) and the device self tests of the C ABI.
+#include "abi_guard.h"
 #include "gbl_internal.h"
 #include "kernels/render_kernels.h"
 #include "kernels/subsurface.h"
@@ -177,7 +178,7 @@ __global__ void selftest_trace_kernel(DevScene sc, const float* rays, float* out
     }
 }
 
-gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n) {
+static gbl_status gbl_selftest_trace_impl(gbl_ctx* ctx, const float* rays, float* out, uint32_t n) {
     if (!ctx || !rays || !out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n == 0) return GBL_OK;
@@ -190,6 +191,9 @@ gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint3
     HIP_TRY(ctx, hipDeviceSynchronize());
     return GBL_OK;
 }
+gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n) {
+    return gbl_guard([&] { return gbl_selftest_trace_impl(ctx, rays, out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
+}
 
 // out[4 i ..] = {sqrtf(a), a / b, 1 / a, expected to be IEEE correctly rounded like the host's}
 __global__ void selftest_arith_kernel(const float* a, const float* b, float* out, uint64_t n) {
@@ -201,7 +205,7 @@ __global__ void selftest_arith_kernel(const float* a, const float* b, float* out
     const F3 v = normalize(f3(a[i], b[i], 0.5f));
     out[4 * i + 3] = v.x;
 }
-gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n) {
+static gbl_status gbl_selftest_arith_impl(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n) {
     if (!ctx || !a || !b || !out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n == 0) return GBL_OK;
@@ -210,8 +214,11 @@ gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, floa
     HIP_TRY(ctx, hipDeviceSynchronize());
     return GBL_OK;
 }
+gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n) {
+    return gbl_guard([&] { return gbl_selftest_arith_impl(ctx, a, b, out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
+}
 
-gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
+static gbl_status gbl_selftest_sincos_impl(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
     if (!ctx || !in || !sin_out || !cos_out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n == 0) return GBL_OK;
@@ -219,6 +226,9 @@ gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, fl
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipDeviceSynchronize());
     return GBL_OK;
+}
+gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
+    return gbl_guard([&] { return gbl_selftest_sincos_impl(ctx, in, sin_out, cos_out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
 }
 
 }   // extern "C"

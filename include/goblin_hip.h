@@ -33,7 +33,8 @@ typedef enum gbl_status {
     GBL_ERR_UNSUPPORTED = 2, /* scene uses a Goblin feature outside the path  */
     GBL_ERR_IO = 3,          /* file missing / parse error                    */
     GBL_ERR_DEVICE = 4,      /* HIP runtime error, no device                  */
-    GBL_ERR_OOM = 5
+    GBL_ERR_OOM = 5,
+    GBL_ERR_INTERNAL = 6     /* a C++ exception stopped at the boundary (message in *_last_error) */
 } gbl_status;
 
 /* ------------------------------------------------------------------------- */

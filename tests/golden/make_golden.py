@@ -80,6 +80,8 @@ CASES = {
     "bunny_config1": ("bunny", ov((256, 256), 16, 4), 0, False),
     "bunny_pt_d8": ("bunny", ov((32, 32), 4, 8), 1024, False),
     "cornell_pt": ("cornell", ov((48, 48), 16, 6), 2048, True),
+    # BASELINE configs[2]'s shape: max_ray_depth 16 (148-float records; AUTO picks the wavefront schedule from depth 12), 64 spp
+    "cornell_pt_d16": ("cornell", ov((32, 32), 64, 16), 2048, False),
     "grid_pt": ("grid", ov((48, 48), 4, 5), 1024, True),
     "bunny_ao": ("bunny", ov((48, 48), 4, method="ao", ao=9), 1024, False),
     "bunny_vn_box": ("bunny", ov((48, 48), 9, 5, filt={"type": "box", "width": [0.5, 0.5]}, geometries=VN_GEOMS), 512, False),

@@ -93,3 +93,22 @@ def test_product_never_touches_the_oracle():
                             if needle in line:
                                 stripped = line.strip()
                                 assert stripped.startswith(("//", "#", "*", '"""')) or "oracle/goblin_oracle.cpp" in line, (f, line)
+
+
+def test_integration_binding_compiles_against_the_reference_headers(tmp_path):
+    """INTEGRATION.md's `HipPathTracer : Renderer` is the binding a Goblin maintainer would add: it must at least be
+    well-formed C++ against the reference's own headers and this repository's include/ (flags = oracle/Makefile's)."""
+    import re
+    import subprocess
+    ref = "/root/reference/src"
+    if not os.path.exists(os.path.join(ref, "GoblinRenderer.h")) or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("needs the reference's headers and the HIP runtime API header")
+    with open(os.path.join(REPO, "INTEGRATION.md")) as f:
+        code = re.findall(r"```cpp\n(.*?)```", f.read(), re.S)[0]
+    assert "class HipPathTracer : public Renderer" in code
+    src = tmp_path / "GoblinHipPathtracer.cpp"
+    src.write_text(code)
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-w", "-include", "math.h", "-include", "condition_variable", "-include", "random",
+                        "-Duniform_real=uniform_real_distribution", "-Duniform_int=uniform_int_distribution", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", "-I" + ref, "-I" + os.path.join(REPO, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:4000]

@@ -81,6 +81,55 @@ def test_two_ranks_rebuild_the_film(tmp_path, mode):
         np.testing.assert_allclose(film, whole(100) + whole(101), rtol=2e-5, atol=1e-6)
 
 
+def _bench_rank_main(rank, world, port, out_dir):
+    """bench.py's own timed-region code (run_steps) and work split on two gloo ranks, with the oracle as the renderer."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import bench
+    import oracle_binding as ob
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    gd.init(backend="gloo")
+    scene = gs.load_scene("grid", gs.config_overrides(resolution=(40, 24), spp=4, depth=4))   # configs[3]'s scene, tiny
+    oracle = ob.Oracle(scene)
+    part = gd.shard_for(rank, world, "tiles", base_seed=20261003)                            # bench.py's N > 1 default: strong
+    film = torch.zeros((scene.desc.film.yres, scene.desc.film.xres, 4), dtype=torch.float32)
+    windows = gd.tiles_of(oracle.window(), *part["shard"]) if part["shard"] else [oracle.window()]
+    traced = [0]
+
+    def render():
+        for win in windows:
+            samples = oracle.native_samples(part["seed"], window=win)
+            li, _ = oracle.li_replay(samples)
+            oracle.splat(samples, li, film.numpy())
+            traced[0] += samples.shape[0]
+
+    elapsed, per_step = bench.run_steps(render=render, zero_film=film.zero_, allreduce=lambda: gd.allreduce_film(film), barrier=gd.barrier,
+                                        sync=lambda: None, steps=2, warmup=1, world=world)
+    assert elapsed > 0.0 and per_step is None
+    if rank == 0:
+        np.save(os.path.join(out_dir, "bench_film.npy"), film.numpy())
+        np.save(os.path.join(out_dir, "bench_paths.npy"), np.array([traced[0]]))
+    dist.destroy_process_group()
+
+
+def test_bench_n2_branch_rebuilds_the_one_gpu_film(tmp_path):
+    """bench.py --gpus 2 (strong: interleaved 8x8 tiles, one all-reduce per step) leaves the film a single rank renders."""
+    import oracle_binding as ob
+    world = 2
+    mp.spawn(_bench_rank_main, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    film = np.load(tmp_path / "bench_film.npy")
+    scene = gs.load_scene("grid", gs.config_overrides(resolution=(40, 24), spp=4, depth=4))
+    oracle = ob.Oracle(scene)
+    s = oracle.native_samples(20261003)
+    li, _ = oracle.li_replay(s)
+    np.testing.assert_allclose(film, oracle.splat(s, li), rtol=2e-5, atol=1e-6)     # one step's film: zeroed, traced, reduced
+    # rank 0 traced its half of the tiles in each of the 3 steps (1 warmup + 2 timed)
+    assert 0 < int(np.load(tmp_path / "bench_paths.npy")[0]) < 3 * scene.num_paths()
+
+
 def test_tile_shards_partition_the_window():
     win = (-2, 43, -2, 27)   # ragged: 45 x 29 pixels
     for world in (1, 2, 3, 8):

@@ -38,13 +38,17 @@ def test_random_scene_matches_oracle(seed):
     masks_in_use = any(scene.desc.materials[scene.desc.instances[i].material].type == _abi.GBL_MAT_MASK for i in range(scene.desc.num_instances))
     for bvh in ("host", "device"):
         r = HipPathTracer(scene, 0, bvh=bvh)
-        for schedule in ("megakernel", "wavefront"):
-            li = r.render(seed=rseed, want_li=True, schedule=schedule)["li"].cpu().numpy()
+        for schedule in ("megakernel", "wavefront", "wavepool"):
+            try:
+                li = r.render(seed=rseed, want_li=True, schedule=schedule)["li"].cpu().numpy()
+            except _abi.GoblinError as e:   # the wave-pool kernel refuses scenes with mask / subsurface materials
+                assert schedule == "wavepool" and e.status == _abi.GBL_ERR_UNSUPPORTED, (seed, schedule, str(e))
+                continue
             assert np.isfinite(li).all(), (seed, bvh, schedule)
             flips = helpers.li_mismatch_fraction(li, li_ref)
             rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
             print("seed", seed, bvh, schedule, "flips %.5f relL2 %.2e" % (flips, rel), "mask" if masks_in_use else "")
-            assert flips <= 3e-3 and rel <= 2e-2, (seed, bvh, schedule, flips, rel)
+            assert flips == 0.0 and rel <= 3e-8, (seed, bvh, schedule, flips, rel)   # measured <= 2.3e-9
     # the reference's own sample stream, generated on the device: the oracle's whole-render Film (bit-exact with the
     # compiled reference on these scenes, tests/test_oracle_fuzz.py) is the reference's Film
     ref = o.render(threads=1)["film"]
@@ -52,7 +56,7 @@ def test_random_scene_matches_oracle(seed):
     rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
     print("seed", seed, "stream film relL2 %.2e" % rel)
     np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
-    assert rel <= 1e-5, (seed, rel)
+    assert rel <= 3e-5, (seed, rel)   # measured <= 2.6e-6 (float summation order in the splat)
 
 
 @pytest.mark.parametrize("seed", list(range(6)))
@@ -75,11 +79,11 @@ def test_random_whitted_scene_matches_oracle(seed):
         flips = helpers.li_mismatch_fraction(li, li_ref)
         rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
         print("seed", seed, bvh, "whitted flips %.5f relL2 %.2e" % (flips, rel))
-        assert flips <= 3e-3 and rel <= 2e-2, (seed, bvh, flips, rel)
+        assert flips == 0.0 and rel <= 6e-8, (seed, bvh, flips, rel)   # measured <= 5.1e-9
     ref = o.render(threads=1)["film"]
     film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
     rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
     print("seed", seed, "whitted stream film relL2 %.2e" % rel)
     np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
-    assert rel <= 2e-5, (seed, rel)   # seed 2 sits at 8.6e-6 (summation order over a bright area-light pixel)
+    assert rel <= 6e-5, (seed, rel)   # measured <= 5.9e-6 (seed 2: summation order over a bright area-light pixel)
 

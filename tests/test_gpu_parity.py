@@ -1,15 +1,17 @@
 """GPU parity tests proper: the HIP path (through the C ABI in libgoblin_hip.so)
 against the CPU oracle and the reference-captured golden fixtures.
 
-Tolerances (floating point path):
-  * per-sample Li, replay of identical Sample records: every arithmetic op on the
-    device is IEEE-exact in the reference's order except sinf/cosf/powf, and the
-    BVH differs (SAH vs median split), so the bulk of samples agree to ~1e-6 and a
-    small number "flip" a discrete decision (reflect-vs-refract pick against
-    Fresnel, a hit exactly on a shared edge).  Bar: <= 0.3 % of samples differ by
-    more than 1e-3 relative, and relL2 over all samples <= 2e-2 (flips carry
-    energy in glass scenes).
-  * Film (normalised radiance), same records: relL2 <= 1e-2 at these tiny spp.
+Tolerances (floating point path), each ONE DECADE above what the suite measures on an MI355X
+(gpurun_out/gputest_*.log, round 2):
+  * per-sample Li on identical Sample records: every arithmetic op on the device is IEEE-exact in the reference's order
+    (sinf / cosf restated from glibc, exact-t ties resolved in the reference BVH's visiting order); powf / acosf /
+    atan2f / expf / logf are the device's own (1-2 ulp).  Measured: 0 flipped samples on every fixture (a "flip" =
+    a sample off by more than 1e-3 relative), relL2 over all samples <= 2.2e-7 (subsurface_whitted; 0 exactly on the
+    Lambert / glass / mirror scenes).  Bars: flips == 0, relL2 <= 3e-6.
+  * Film (normalised radiance), same records: float summation order only; measured <= 2.0e-6 (cornell_pt_d16, 64 spp).
+    Bar: 2.5e-5.
+  * Exceptions, written where they apply: the participating medium under AREA lights (test_participating_medium_*,
+    test_stream_mode_with_a_participating_medium: an epsilon-0 shadow segment ends ON the emitter).
 """
 import ctypes as C
 
@@ -25,9 +27,9 @@ from goblin_amd import scene as gs
 
 pytestmark = pytest.mark.gpu
 
-LI_FLIP_TOL = 3e-3
-LI_RELL2_TOL = 2e-2
-FILM_RELL2_TOL = 1e-2
+LI_FLIP_TOL = 0.0
+LI_RELL2_TOL = 3e-6
+FILM_RELL2_TOL = 2.5e-5
 
 
 @pytest.fixture(scope="module")
@@ -37,10 +39,16 @@ def torch():
     return torch
 
 
-@pytest.fixture(params=["wavefront", "megakernel"])
+@pytest.fixture(params=["wavefront", "megakernel", "wavepool"])
 def schedule(request):
-    """Both device schedules run the same arithmetic and must both match the reference."""
+    """The device schedules run the same arithmetic and must each match the reference."""
     return request.param
+
+
+def scene_has_masks(scene):
+    """Materials whose type carries BSDFnullptr: masks, and subsurface materials (BSDFAll) -- DevScene::has_masks."""
+    d = scene.desc
+    return any(d.materials[i].type in (_abi.GBL_MAT_MASK, _abi.GBL_MAT_SUBSURFACE) for i in range(d.num_materials))
 
 
 class _Scheduled:
@@ -54,6 +62,8 @@ class _Scheduled:
 
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
+        if self._schedule == "wavepool" and s.integrator == _abi.GBL_INTEGRATOR_PATH and scene_has_masks(self._t.scene):
+            pytest.skip("mask scenes stay on the megakernel / wavefront schedules (the wave-pool kernel refuses them)")
         kw.setdefault("schedule", "auto" if s.integrator != _abi.GBL_INTEGRATOR_PATH else self._schedule)
         return self._t.render(**kw)
 
@@ -73,7 +83,7 @@ def fake_window(full, n_pixels):
     raise ValueError("no window for %d pixels" % n_pixels)
 
 
-@pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "bunny_vn_box",
+@pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "bunny_vn_box",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
@@ -102,7 +112,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
     assert rel <= LI_RELL2_TOL, (case, rel)
 
 
-@pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
+@pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
                                   "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
@@ -129,7 +139,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     assert rel <= FILM_RELL2_TOL
 
 
-@pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
+@pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
@@ -335,6 +345,33 @@ def test_headline_scene_radiance_is_bit_identical(torch, schedule):
     same_n = (li_n == li_ref).all(axis=1)
     print("bit-identical samples (native)", int(same_n.sum()), "of", same_n.size)
     assert same_n.mean() >= 0.99999
+
+
+def test_auto_schedule_at_config3_depth_is_the_wavefront(golden, torch):
+    """BASELINE configs[2]'s shape (max_ray_depth 16): AUTO resolves to the wavefront schedule from depth
+    GBL_AUTO_WAVEFRONT_DEPTH on; every schedule gives the same per-sample radiance on the reference's records."""
+    from goblin_amd.renderer import HipPathTracer
+    meta, data = golden("cornell_pt_d16")
+    assert meta["overrides"]["render_setting"]["max_ray_depth"] == 16 >= _abi.GBL_AUTO_WAVEFRONT_DEPTH and meta["dims"] == 4 + 7 * 16 + 32
+    scene = gs.load_scene(meta["scene"], meta["overrides"])
+    r = HipPathTracer(scene, 0)
+    seed = 5
+    li = {s: r.render(seed=seed, want_li=True, schedule=s)["li"].cpu().numpy() for s in ("auto", "wavefront", "megakernel", "wavepool")}
+    for s in ("wavefront", "megakernel", "wavepool"):
+        np.testing.assert_array_equal(li["auto"].view(np.uint32), li[s].view(np.uint32))
+
+
+def test_wavefront_without_stream_overlap_keeps_its_stack_backing_in_bounds(torch, monkeypatch):
+    """GBL_WF_NO_OVERLAP=1 serialises the shadow and extension trace launches on one stream; each then takes the full
+    occupancy, and both must stay inside the stack backing (deep BVH: the bunny's stacks spill past the 16 LDS levels)."""
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=6))
+    ref = HipPathTracer(scene, 0).render(seed=11, want_li=True, schedule="wavefront")["li"].cpu().numpy()
+    monkeypatch.setenv("GBL_WF_NO_OVERLAP", "1")
+    r = HipPathTracer(scene, 0)
+    assert r.info.blas_depth + r.info.tlas_depth > 5   # 3 * depth + 2 stack entries > GBL_WF_STACK_LDS
+    got = r.render(seed=11, want_li=True, schedule="wavefront")["li"].cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_window_sharding_equals_whole_render(torch, schedule):

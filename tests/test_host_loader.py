@@ -344,3 +344,17 @@ def test_film_normalize_and_pfm(tmp_path):
     assert _abi.host_lib().gbl_host_write_pfm(p.encode(), rgb.ctypes.data_as(C.c_void_p), 2, 1) == 0
     raw = open(p, "rb").read()
     assert raw.startswith(b"PF\n2 1\n-1.0\n") and len(raw) == len(b"PF\n2 1\n-1.0\n") + 24
+
+
+def test_repeated_json_key_keeps_its_last_value_and_nesting_is_bounded():
+    """The reference's nlohmann DOM parser assigns through operator[] (json.hpp:2899,2987): the last value of a repeated key
+    is the one every later lookup sees.  (Distinct from repeated *names* of geometries / materials, where the first wins.)"""
+    text = json.dumps(minimal(render_setting={"sample_per_pixel": 4}))
+    text = text.replace('"sample_per_pixel": 4', '"sample_per_pixel": 4, "max_ray_depth": 3, "sample_per_pixel": 9', 1)
+    assert text.count('"sample_per_pixel"') == 2
+    s = gs.load_scene_text(text, MODELS)   # keep the Scene alive: desc points into it
+    assert s.desc.setting.sample_per_pixel == 9 and s.desc.setting.max_ray_depth == 3
+    # a pathologically nested file is a parse error, not a stack overflow
+    with pytest.raises(_abi.GoblinError) as e:
+        gs.load_scene_text("[" * 100000, MODELS)
+    assert "nested too deeply" in str(e.value)

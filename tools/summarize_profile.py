@@ -1,46 +1,63 @@
-"""Turn gpurun_out/prof_<tag>/ (tools/profile_gpu.sh) into profiles/<name>_kernel_stats.csv and
-profiles/<name>_pmc.json.  Per-kernel counters are averaged over the un-instrumented launches
-(kernel names without the <.., true> STATS instantiation)."""
-import csv, glob, json, os, shutil, sys
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_gpu.sh) into profiles/<name>_kernel_stats.csv and profiles/<name>.json.
+
+    python tools/summarize_profile.py <tag> <name> [workload description]
+
+Per-kernel counters are averaged over the un-instrumented launches (kernel names without a STATS = true template
+argument are told apart by the caller's kernel tag; every kernel is listed).  The summary records the source stamp of
+the tree it was collected from (goblin_amd/build.py source_stamp): bench.py quotes counters only when the stamp is the
+running tree's.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from goblin_amd import build
+
 tag, name = sys.argv[1], sys.argv[2]
+what = sys.argv[3] if len(sys.argv) > 3 else ""
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles")
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-STEPS = 4   # un-instrumented steps per profiled run (1 warmup + 3 timed)
-summary = {"round": 1, "name": name,
-           "command": "tools/profile_gpu.sh %s (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group, of "
-                      "`python3 bench.py --steps 3 --warmup 1 --no-cpu --schedule ...`)" % tag,
-           "workload": "bunny.json 512x512 256spp depth 8 (BASELINE configs[1])",
-           "kernel_avg_ms": {r["Name"]: round(float(r["AverageNs"]) * 1e-6, 4) for r in rows
-                             if float(r["Percentage"]) > 0.05},
+cmd = open(os.path.join(src, "command.txt")).read().strip().replace(REPO + "/", "") if os.path.exists(os.path.join(src, "command.txt")) else ""
+summary = {"name": name, "source_stamp": build.source_stamp(),
+           "command": "tools/profile_gpu.sh %s %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group)" % (tag, cmd),
+           "workload": what,
+           "kernel_avg_ms": {r["Name"]: round(float(r["AverageNs"]) * 1e-6, 4) for r in rows if float(r["Percentage"]) > 0.05},
            "kernel_calls": {r["Name"]: int(r["Calls"]) for r in rows if float(r["Percentage"]) > 0.05},
+           "kernel_total_ms": {r["Name"]: round(float(r["TotalDurationNs"]) * 1e-6, 3) for r in rows if float(r["Percentage"]) > 0.05},
            "counters_per_launch": {}, "launch_info": {}}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "rocclr" in k or ", true>" in k:
+        if "rocclr" in k or "elementwise" in k:
             continue
         a = acc.setdefault((k, r["Counter_Name"]), [0.0, 0])
-        a[0] += float(r["Counter_Value"]); a[1] += 1
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
         summary["launch_info"][k] = {"grid": int(r["Grid_Size"]), "wg": int(r["Workgroup_Size"]), "lds": int(r["LDS_Block_Size"]),
                                      "scratch": int(r["Scratch_Size"]), "vgpr": int(r["VGPR_Count"]),
                                      "agpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"])}
     for (k, c), (s, n) in acc.items():
         summary["counters_per_launch"].setdefault(k, {})[c] = s / n
         summary["counters_per_launch"][k]["launches"] = n
-tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 for k, c in summary["counters_per_launch"].items():
-    for x in tot:
-        tot[x] += c.get(x, 0.0) * c.get("launches", 0)
+    if k in summary["kernel_avg_ms"]:
+        c["kernel_avg_ms"] = summary["kernel_avg_ms"][k]
     if "TCC_HIT_sum" in c:
         c["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
-summary["hbm_bytes_per_step"] = int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / STEPS)
-summary["hbm_bytes_note"] = ("sum over all kernels of a step of (2*FETCH_SIZE + WRITE_SIZE) KiB; the x2 is the gfx950 correction of "
-                             "MI355X_MICROARCH.md (128-B requests tallied at 64 B), calibrated for wide coalesced reads - the node and "
-                             "triangle gathers here are 16 B per lane and divergent, so the absolute is +-2x")
-json.dump(summary, open(os.path.join(dst, name + "_pmc.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies 128-B read requests at 64 B (x2)
+        c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+        c["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
+json.dump(summary, open(os.path.join(dst, name + ".json"), "w"), indent=1)
+print(json.dumps({k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in summary["counters_per_launch"].items()
+                  if summary["kernel_avg_ms"].get(k, 0) > 0.2}, indent=1))
