@@ -998,6 +998,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         dim3 grid(static_cast<unsigned>(grid64)), block(GBL_BLOCK);
         const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
+        bool pair_candidate = false;   // mask-free path tracing: the paired-query megakernel once the radiance buffer is known to fit
         if (stream_mode) {
             kernel = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_stream(want_stats, ext || want_stats)
                                                         : gbl_kernel_path_stream(want_stats, ext || want_stats);
@@ -1045,6 +1046,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             ra.wp_pool = ctx->wp_pool;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = gbl_kernel_path(replay, want_stats, ext || want_stats);
+            pair_candidate = !sc.has_masks;
         } else {
             kernel = gbl_kernel_ao(replay, want_stats, ext || want_stats);
         }
@@ -1070,6 +1072,14 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         if (sc.volume.on != 0u && !defer) {
             ctx->error = "a scene with a participating medium needs the per-sample radiance buffer: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
+        }
+        if (pair_candidate && defer && getenv("GBL_MK_PAIRED")) {
+            // kernels/pairkernel.h: shadow + extension ray as one job per lane (it writes per-sample radiance only).
+            // Opt-in: 30 % fewer traversal iterations but no faster on config 2 (52.2 against 51.3 ms)
+            kernel = gbl_kernel_pair(replay, want_stats, ext || want_stats);
+            lds = 4 * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         }
         if (wavepool && !defer) {
             ctx->error = "the wave-pool schedule keeps 16 bytes per camera sample of the call: render this window in smaller pieces";

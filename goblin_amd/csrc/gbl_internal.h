@@ -83,6 +83,8 @@ typedef void (*gbl_li_kernel)(DevScene, RenderArgs, float4*);
 // kernels_path.hip: the persistent megakernel and the AO kernel (kernels/render_kernels.h), native / replay samplers
 gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext);
+// kernels_pair.hip: the megakernel that traces a vertex's shadow and extension ray as one job per lane (kernels/pairkernel.h)
+gbl_render_kernel gbl_kernel_pair(bool replay, bool stats, bool ext);
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext);

@@ -361,6 +361,23 @@ def test_auto_schedule_at_config3_depth_is_the_wavefront(golden, torch):
         np.testing.assert_array_equal(li["auto"].view(np.uint32), li[s].view(np.uint32))
 
 
+def test_paired_query_megakernel_is_bit_identical(torch, monkeypatch):
+    """GBL_MK_PAIRED=1 selects kernels/pairkernel.h (a vertex's shadow and extension ray traced as one job per lane, one
+    kind of traversal step per iteration): another order of the same arithmetic."""
+    from goblin_amd.renderer import HipPathTracer
+    for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=8)),
+                     ("cornell", gs.config_overrides(resolution=(48, 48), spp=16, depth=12)),
+                     ("shapes", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
+                     ("textured", gs.config_overrides(resolution=(48, 48), spp=9, depth=5))):
+        scene = gs.load_scene(name, ov)
+        monkeypatch.delenv("GBL_MK_PAIRED", raising=False)
+        ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
+        monkeypatch.setenv("GBL_MK_PAIRED", "1")
+        got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
+        np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
+        np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_wavefront_without_stream_overlap_keeps_its_stack_backing_in_bounds(torch, monkeypatch):
     """GBL_WF_NO_OVERLAP=1 serialises the shadow and extension trace launches on one stream; each then takes the full
     occupancy, and both must stay inside the stack backing (deep BVH: the bunny's stacks spill past the 16 LDS levels)."""

@@ -22,7 +22,7 @@ CONFIGS = {
     "cfg3_64spp": ("cornell", gs.config_overrides(resolution=(1024, 1024), spp=64, depth=16)),
     "cfg4": ("grid", gs.config_overrides(resolution=(1024, 1024), spp=256, depth=8)),
 }
-names = sys.argv[2:] or (["bunny_small", "cornell_small", "grid_small"] if mode == "small" else ["cfg2", "cfg3_64spp", "cfg4"])
+names = [a for a in sys.argv[2:] if not a.startswith("--")] or (["bunny_small", "cornell_small", "grid_small"] if mode == "small" else ["cfg2", "cfg3_64spp", "cfg4"])
 for name in names:
     sc_name, ov = CONFIGS[name]
     scene = gs.load_scene(sc_name, ov)
