@@ -184,8 +184,26 @@ def host_lib():
         lib.gbl_host_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         lib.gbl_host_write_exr.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         lib.gbl_host_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.gbl_host_read_image.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.gbl_host_free_image.argtypes = [C.POINTER(C.c_float)]
+        lib.gbl_host_free_image.restype = None
         _host = lib
     return _host
+
+
+def read_image(path):
+    """Goblin::loadImage through libgoblin_host.so: (H, W, 4) float32."""
+    import numpy as np
+    lib = host_lib()
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_int32(), C.c_int32()
+    st = lib.gbl_host_read_image(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h))
+    if st != GBL_OK:
+        raise GoblinError(st, lib.gbl_host_last_error().decode())
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib.gbl_host_free_image(p)
 
 
 def hip_lib():

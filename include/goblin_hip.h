@@ -322,6 +322,12 @@ gbl_status gbl_host_write_exr(const char* path, const float* rgb, int32_t xres, 
  * extension (.exr, .ppm with optional tone mapping, none/unknown -> <path>.ppm);
  * .pfm is a build-side extra.  May tone-map rgb in place. */
 gbl_status gbl_host_write_image(const char* path, float* rgb, int32_t xres, int32_t yres, int32_t tone_mapping);
+/* Goblin::loadImage (GoblinImageIO.cpp:14-34, 128-144): an .exr file as xres*yres float4, row-major, top row first,
+ * assembled as tinyexr's LoadEXR does (one channel is replicated into all four; otherwise R, G, B must exist and A
+ * defaults to 1).  Single-part scanline files, NONE / RLE / ZIPS / ZIP, HALF / FLOAT channels; anything else is
+ * GBL_ERR_UNSUPPORTED, another extension GBL_ERR_IO like the reference's nullptr.  Free with gbl_host_free_image. */
+gbl_status gbl_host_read_image(const char* path, float** rgba_out, int32_t* xres_out, int32_t* yres_out);
+void gbl_host_free_image(float* rgba);
 
 /* ------------------------------------------------------------------------- */
 /* libgoblin_hip.so : the device integrator.                                  */

@@ -39,6 +39,7 @@
 #include "GoblinLight.h"
 #include "GoblinPathtracer.h"
 #include "GoblinRenderContext.h"
+#include "GoblinImageIO.h"
 #include "GoblinRenderer.h"
 #include "GoblinSampler.h"
 #include "GoblinScene.h"
@@ -220,11 +221,57 @@ void kat(RenderContext* ctx, const std::string& prefix) {
 
 }  // namespace
 
+// image <in.f32> <w> <h> <prefix> <bloom radius> <bloom weight>: the reference's image output path on a given float4 image
+// (GoblinImageIO.cpp): bloom, toneMapping, writeImage (.exr: three HALF channels through tinyexr; .ppm with tone
+// mapping) and loadImage of the .exr it wrote.  imageload <file.exr> <out.f32>: loadImage alone.
+static int image_mode(int argc, char** argv) {
+    std::string mode = argv[1];
+    if (mode == "imageload") {
+        int w = 0, h = 0;
+        Color* c = loadImage(argv[2], &w, &h);
+        if (!c) return 1;
+        std::vector<float> v(reinterpret_cast<float*>(c), reinterpret_cast<float*>(c) + 4 * static_cast<size_t>(w) * h);
+        write_f32(argv[3], v);
+        printf("{\"mode\": \"imageload\", \"width\": %d, \"height\": %d}\n", w, h);
+        return 0;
+    }
+    if (argc < 8) return 2;
+    const int w = atoi(argv[3]), h = atoi(argv[4]);
+    const std::string prefix = argv[5];
+    const float radius = static_cast<float>(atof(argv[6])), weight = static_cast<float>(atof(argv[7]));
+    std::vector<Color> img(static_cast<size_t>(w) * h);
+    FILE* f = fopen(argv[2], "rb");
+    if (!f || fread(img.data(), sizeof(Color), img.size(), f) != img.size()) return 1;
+    fclose(f);
+    auto dump = [&](const std::vector<Color>& c, const std::string& path) {
+        std::vector<float> v(reinterpret_cast<const float*>(c.data()), reinterpret_cast<const float*>(c.data()) + 4 * c.size());
+        write_f32(path, v);
+    };
+    std::vector<Color> a = img;
+    bloom(a.data(), w, h, radius, weight);
+    dump(a, prefix + ".bloom.f32");
+    std::vector<Color> b = img;
+    toneMapping(b.data(), w, h);
+    dump(b, prefix + ".tone.f32");
+    std::vector<Color> c = img;
+    if (!writeImage(prefix + ".exr", c.data(), w, h, false)) return 1;
+    std::vector<Color> d = img;
+    if (!writeImage(prefix + ".ppm", d.data(), w, h, true)) return 1;
+    int lw = 0, lh = 0;
+    Color* back = loadImage(prefix + ".exr", &lw, &lh);
+    if (!back || lw != w || lh != h) return 1;
+    std::vector<Color> e(back, back + static_cast<size_t>(w) * h);
+    dump(e, prefix + ".load.f32");
+    printf("{\"mode\": \"image\", \"width\": %d, \"height\": %d}\n", w, h);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s film|li|kat|time <scene.json> ...\n", argv[0]);
+        fprintf(stderr, "usage: %s film|li|kat|time <scene.json> ... | image <in.f32> <w> <h> <prefix> <radius> <weight> | imageload <file.exr> <out.f32>\n", argv[0]);
         return 2;
     }
+    if (!strcmp(argv[1], "image") || !strcmp(argv[1], "imageload")) return image_mode(argc, argv);
     std::string mode = argv[1], scene_path = argv[2];
     // the loader echoes every parsed parameter to stdout; keep stdout for our JSON line
     FILE* real_stdout = fdopen(dup(fileno(stdout)), "w");
