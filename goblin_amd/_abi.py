@@ -142,7 +142,8 @@ class gbl_info(C.Structure):
 HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "gbl_host_free",
                 "gbl_host_last_error", "gbl_host_sample_window", "gbl_host_round_to_square",
                 "gbl_host_sample_dimension", "gbl_host_sample_dimension_scene", "gbl_host_film_normalize", "gbl_host_write_pfm", "gbl_host_output_path",
-                "gbl_host_bloom", "gbl_host_tone_map", "gbl_host_write_ppm", "gbl_host_write_exr", "gbl_host_write_image"]
+                "gbl_host_bloom", "gbl_host_tone_map", "gbl_host_write_ppm", "gbl_host_write_exr", "gbl_host_write_image",
+                "gbl_host_read_image", "gbl_host_free_image"]
 GBL_CREATE_DEVICE_BVH = 1
 HIP_SYMBOLS = ["gbl_create", "gbl_create_ex", "gbl_update_instances", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
                "gbl_last_error", "gbl_abi_version", "gbl_get_timings", "gbl_selftest_sincos", "gbl_selftest_trace", "gbl_selftest_arith"]
