@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 8
+GBL_ABI_VERSION = 9
 GBL_AUTO_WAVEFRONT_DEPTH, GBL_AUTO_WAVEFRONT_TRIS = 12, 400000   # gbl_schedule AUTO thresholds (goblin_hip.h)
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM, GBL_ERR_INTERNAL = range(7)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
@@ -45,10 +45,18 @@ class gbl_mesh(C.Structure):
 class gbl_texture(C.Structure):
     _fields_ = [("type", C.c_uint32), ("is_float", C.c_uint32), ("value", C.c_float * 3), ("child", C.c_int32 * 2),
                 ("mapping", C.c_uint32), ("uv_scale", C.c_float * 2), ("uv_offset", C.c_float * 2), ("to_tex", gbl_trs),
-                ("filter", C.c_uint32)]
+                ("filter", C.c_uint32), ("image", C.c_int32), ("image_filter", C.c_uint32), ("address", C.c_uint32),
+                ("max_anisotropy", C.c_float)]
 
 
-GBL_TEX_CONSTANT, GBL_TEX_CHECKERBOARD, GBL_TEX_SCALE = 0, 1, 2
+class gbl_image(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32), ("channels", C.c_uint32),
+                ("texel_offset", C.c_uint64)]
+
+
+GBL_TEX_CONSTANT, GBL_TEX_CHECKERBOARD, GBL_TEX_SCALE, GBL_TEX_IMAGE = 0, 1, 2, 3
+GBL_IMAGE_FILTER_NONE, GBL_IMAGE_FILTER_BILINEAR, GBL_IMAGE_FILTER_TRILINEAR, GBL_IMAGE_FILTER_EWA = 0, 1, 2, 3
+GBL_ADDRESS_REPEAT, GBL_ADDRESS_CLAMP, GBL_ADDRESS_BORDER = 0, 1, 2
 GBL_MAT_LAMBERT, GBL_MAT_BLINN, GBL_MAT_TRANSPARENT, GBL_MAT_MIRROR, GBL_MAT_MASK, GBL_MAT_SUBSURFACE = 0, 1, 2, 3, 4, 5
 GBL_MAP_UV, GBL_MAP_SPHERICAL = 0, 1
 
@@ -67,7 +75,7 @@ class gbl_instance(C.Structure):
 class gbl_light(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", C.c_float * 3), ("position", C.c_float * 3),
                 ("direction", C.c_float * 3), ("cos_theta_max", C.c_float), ("cos_falloff_start", C.c_float),
-                ("mesh", C.c_uint32), ("to_world", gbl_trs), ("sample_num", C.c_uint32)]
+                ("mesh", C.c_uint32), ("to_world", gbl_trs), ("sample_num", C.c_uint32), ("image", C.c_int32)]
 
 
 class gbl_camera(C.Structure):
@@ -105,6 +113,8 @@ class gbl_scene_desc(C.Structure):
                 ("num_meshes", C.c_uint32), ("meshes", C.POINTER(gbl_mesh)),
                 ("num_materials", C.c_uint32), ("materials", C.POINTER(gbl_material)),
                 ("num_textures", C.c_uint32), ("textures", C.POINTER(gbl_texture)),
+                ("num_images", C.c_uint32), ("images", C.POINTER(gbl_image)),
+                ("num_texels", C.c_uint64), ("texels", C.POINTER(C.c_float)),
                 ("num_instances", C.c_uint32), ("instances", C.POINTER(gbl_instance)),
                 ("num_lights", C.c_uint32), ("lights", C.POINTER(gbl_light)),
                 ("camera", gbl_camera), ("film", gbl_film), ("setting", gbl_render_setting), ("volume", gbl_volume)]

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HOST_SOURCES = [os.path.join(CSRC, "host", f) for f in ("scene_loader.cpp", "image_io.cpp", "exr_reader.cpp")]
+HOST_SOURCES = [os.path.join(CSRC, "host", f) for f in ("scene_loader.cpp", "image_io.cpp", "exr_reader.cpp", "mipmap.cpp")]
 HOST_DEPS = HOST_SOURCES + [os.path.join(CSRC, "host", "json_lite.h"), os.path.join(CSRC, "abi_guard.h"), os.path.join(REPO, "include", "goblin_hip.h")]
 # libgoblin_hip.so: the host side of the C ABI and one translation unit per kernel family, compiled side by side
 # (a single unit took 3.6 minutes; these take about one on 8 cores, and an edit rebuilds only the units that include

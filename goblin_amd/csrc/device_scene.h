@@ -116,7 +116,18 @@ struct DevTexture {
     uint32_t mapping, filter;
     float uv_scale[2], uv_offset[2];
     float to_tex[12];   // spherical mapping: toTex 3x4
-    float pad;
+    int32_t image;      // type 3 (image): index into DevScene::images; `filter` is then the gbl_image_filter
+    uint32_t address;   // gbl_address_mode
+    float max_aniso;
+    float pad[2];
+};
+
+// One MIPMap<T> (gbl_image): level l is max(1, width >> l) x max(1, height >> l) texels of `channels` floats at
+// texels[offset + level_offset[l]]
+struct DevImage {
+    uint32_t width, height, levels, channels;
+    uint64_t offset;
+    uint32_t level_offset[18];
 };
 
 // one emitting triangle of an area light, light-local space (GeometrySet, GoblinLight.cpp:289-343)
@@ -143,6 +154,9 @@ struct DevLight {
     float radius;           // area: sphere / disk radius
     uint32_t wh_n;          // Whitted quota: roundToSquare(Light::getSamplesNum()) slots of this light's patterns ...
     uint32_t wh_prefix;     // ... and the slots of the lights before it
+    // type 4 (image based light): m / inv = the light's rotation; the radiance MIPMap; its CDF2D (kernels/image.h)
+    int32_t image;
+    uint32_t dist_offset, dist_w, dist_h;   // into DevScene::ibl_dist
     float pad;
 };
 
@@ -196,6 +210,10 @@ struct DevScene {
     const float* light_cdf;       // num_lights + 1, normalised (CDF1D::mCDF)
     const float* light_pick_pdf;  // per light: (f[i] / integral) * dx
     const float* filter_table;    // 256 floats
+    const DevImage* images;       // MIP pyramids (image textures, image based lights) ...
+    const float* texels;          // ... and their texels
+    const float* ewa_lut;         // MIPMap::EWALut, 128 floats
+    const float* ibl_dist;        // the image based lights' CDF2Ds
     int32_t tlas_root;            // child reference of the TLAS root
     int32_t num_instances;
     int32_t num_lights;
@@ -204,6 +222,8 @@ struct DevScene {
     int32_t has_masks;            // some instance carries a mask material: filtered queries + attenuation walks (megakernel only)
     int32_t has_bssrdf;           // some material is a subsurface material: sss_kernel runs ahead of the path kernels
     int32_t wh_slots;             // Whitted quota: sum of the lights' wh_n
+    int32_t has_ibl;              // some light is image based: rays that leave the scene collect Le (evalEnvironmentLight)
+    int32_t pad_scene;
     DevCamera camera;
     DevFilm film;
     DevVolume volume;

@@ -459,6 +459,11 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     if ((st = upload(ctx, packed.light_cdf, &sc.light_cdf)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.light_pick_pdf, &sc.light_pick_pdf)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, ftab, &sc.filter_table)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.images, &sc.images)) != GBL_OK) return bail(st);
+    if ((st = upload_raw(ctx, desc->texels, desc->num_texels, desc->num_texels, &sc.texels)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.ewa_lut, &sc.ewa_lut)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.ibl_dist, &sc.ibl_dist)) != GBL_OK) return bail(st);
+    sc.has_ibl = packed.has_ibl;
     sc.tlas_root = packed.tlas_root;
     sc.num_instances = static_cast<int32_t>(packed.instances.size());
     sc.num_lights = static_cast<int32_t>(packed.lights.size());

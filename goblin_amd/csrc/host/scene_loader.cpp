@@ -384,11 +384,18 @@ struct gbl_host_scene {
     std::vector<gbl_mesh> meshes;
     std::vector<gbl_material> materials;
     std::vector<gbl_texture> textures;
+    std::vector<gbl_image> images;       // MIP pyramids of image textures / image based lights (mipmap.cpp)
+    std::vector<float> texels;
     std::vector<gbl_instance> instances;
     std::vector<gbl_light> lights;
     std::string output_path, default_output_path = "goblin.exr";
     gbl_scene_desc desc;
 };
+
+namespace gbl_host_detail {
+gbl_status load_image(const std::string& path, float** rgba, int32_t* w, int32_t* h);                        // exr_reader.cpp
+gbl_image build_mipmap(std::vector<float>& pool, std::vector<float> level0, int w, int h, int channels);      // mipmap.cpp
+}
 
 namespace {
 
@@ -406,6 +413,9 @@ struct TextureDecl {
     bool filter = false;
     float uv_scale[2] = {1.0f, 1.0f}, uv_offset[2] = {0.0f, 0.0f};
     gbl_trs to_tex;
+    // image (getImageTextureParams, GoblinTexture.cpp:677-732)
+    std::string file, image_filter, address, channel;
+    float gamma = 1.0f, max_anisotropy = 10.0f;
     int order = 0;      // position in the "textures" list: a texture only sees the ones defined before it
     int id = -2;        // -2 unresolved, -1 constant, >= 0 index into gbl_host_scene::textures
 };
@@ -442,6 +452,7 @@ private:
     std::map<std::string, int> material_ids_;  // resolved materials by name
     std::map<std::string, ModelDecl> primitives_;
     std::map<std::string, int> area_lights_;   // name -> light index
+    std::map<std::string, int32_t> image_cache_;
     std::string camera_type_;
 
     std::string resolve(const std::string& f) const {
@@ -617,7 +628,13 @@ private:
             d.texture = p.get_string("texture");
             d.scale_name = p.get_string("scale");
             d.mapping = p.get_string("mapping", "uv");
-            d.filter = p.get_bool("filter", false);
+            d.filter = p.get_bool("filter", false);            // checkerboard: a bool; image: a string (ParamSet keeps types apart)
+            d.file = p.get_string("file");
+            d.image_filter = p.get_string("filter", "nearest");
+            d.address = p.get_string("address", "repeat");
+            d.channel = p.get_string("channel", "All");
+            d.gamma = p.get_float("gamma", 1.0f);
+            d.max_anisotropy = p.get_float("max_anisotropy", 10.0f);
             Vec sc = p.get_vec(p.vec2s, "scale", vec(1.0f, 1.0f));      // UVMapping (getTextureMapping, :599-615)
             Vec of = p.get_vec(p.vec2s, "offset", vec(0.0f, 0.0f));
             for (int i = 0; i < 2; ++i) {
@@ -640,7 +657,32 @@ private:
         if (it == textures_.end() || it->second.order >= before) return fail(GBL_ERR_INVALID, "Texture " + name + " not defined!");
         TextureDecl& d = it->second;
         const std::string& t = d.type;
-        if (t == "image") return fail(GBL_ERR_UNSUPPORTED, "texture type \"image\" is outside the device path");
+        if (t == "image") {
+            if (d.id == -2) {
+                gbl_texture g;
+                memset(&g, 0, sizeof(g));
+                g.type = GBL_TEX_IMAGE;
+                g.is_float = is_float ? 1u : 0u;
+                g.child[0] = g.child[1] = -1;
+                set_mapping(d, &g);
+                g.image_filter = d.image_filter == "bilinear" ? GBL_IMAGE_FILTER_BILINEAR : d.image_filter == "trilinear" ? GBL_IMAGE_FILTER_TRILINEAR
+                                 : d.image_filter == "EWA" ? GBL_IMAGE_FILTER_EWA : GBL_IMAGE_FILTER_NONE;   // "nearest" and the unrecognised-filter fallback
+                g.address = d.address == "clamp" ? GBL_ADDRESS_CLAMP : d.address == "border" ? GBL_ADDRESS_BORDER : GBL_ADDRESS_REPEAT;
+                // createColorImageTexture does not forward max_anisotropy: colour images always get the default (:741-745)
+                g.max_anisotropy = is_float ? d.max_anisotropy : 10.0f;
+                int channel = 4;   // ChannelAll, also the unrecognised-channel fallback
+                if (d.channel == "R") channel = 0;
+                else if (d.channel == "G") channel = 1;
+                else if (d.channel == "B") channel = 2;
+                else if (d.channel == "A") channel = 3;
+                gbl_status st = image_ref(resolve(d.file), is_float, d.gamma, channel, nullptr, &g.image);
+                if (st != GBL_OK) return st;
+                d.id = static_cast<int>(s_->textures.size());
+                s_->textures.push_back(g);
+            }
+            *id = d.id;
+            return GBL_OK;
+        }
         if (t != "checkerboard" && t != "scale") {   // "constant" and the unknown-type fallback (:282-285, :300-303)
             *id = -1;
             if (is_float) constant[0] = constant[1] = constant[2] = d.value;
@@ -651,6 +693,7 @@ private:
             gbl_texture g;
             memset(&g, 0, sizeof(g));
             g.is_float = is_float ? 1u : 0u;
+            g.image = -1;
             gbl_status st;
             float c0[3], c1[3];
             int i0, i1;
@@ -658,17 +701,7 @@ private:
                 g.type = GBL_TEX_CHECKERBOARD;
                 if ((st = texture_ref(is_float, d.texture1, d.order, &i0, c0)) != GBL_OK) return st;
                 if ((st = texture_ref(is_float, d.texture2, d.order, &i1, c1)) != GBL_OK) return st;
-                if (d.mapping == "spherical") {
-                    g.mapping = GBL_MAP_SPHERICAL;
-                } else {   // "uv" and the unknown-mapping fallback: UVMapping((1,1), (0,0)) (:609-613)
-                    g.mapping = GBL_MAP_UV;
-                    const bool known = d.mapping == "uv";
-                    for (int i = 0; i < 2; ++i) {
-                        g.uv_scale[i] = known ? d.uv_scale[i] : 1.0f;
-                        g.uv_offset[i] = known ? d.uv_offset[i] : 0.0f;
-                    }
-                }
-                g.to_tex = d.to_tex;
+                set_mapping(d, &g);
                 g.filter = d.filter ? 1u : 0u;
             } else {
                 g.type = GBL_TEX_SCALE;
@@ -685,6 +718,70 @@ private:
         return GBL_OK;
     }
 
+    // getTextureMapping (GoblinTexture.cpp:599-615)
+    static void set_mapping(const TextureDecl& d, gbl_texture* g) {
+        if (d.mapping == "spherical") {
+            g->mapping = GBL_MAP_SPHERICAL;
+        } else {   // "uv" and the unknown-mapping fallback: UVMapping((1,1), (0,0)) (:609-613)
+            g->mapping = GBL_MAP_UV;
+            const bool known = d.mapping == "uv";
+            for (int i = 0; i < 2; ++i) {
+                g->uv_scale[i] = known ? d.uv_scale[i] : 1.0f;
+                g->uv_offset[i] = known ? d.uv_offset[i] : 0.0f;
+            }
+        }
+        g->to_tex = d.to_tex;
+    }
+
+    // ImageTexture<T>::getMIPMap (GoblinTexture.cpp:458-487) and ImageBasedLight's constructor (GoblinLight.cpp:475-487):
+    // load the file, convert every texel (convertTexel<float / Color>, :489-523; or the light's colour filter), build
+    // the pyramid.  Pyramids are cached by (file, gamma, channel, format) like ImageTexture::imageCache.  A file that
+    // cannot be read is an error here (the reference substitutes a 1 x 1 magenta image and renders on).
+    gbl_status image_ref(const std::string& path, bool is_float, float gamma, int channel, const float* light_filter, int32_t* out) {
+        char key[64];
+        snprintf(key, sizeof(key), "|%d|%d|%.9g|", is_float ? 1 : 0, channel, gamma);
+        std::string k = path + key;
+        if (light_filter) {
+            snprintf(key, sizeof(key), "L%.9g,%.9g,%.9g", light_filter[0], light_filter[1], light_filter[2]);
+            k += key;
+        }
+        auto it = image_cache_.find(k);
+        if (it != image_cache_.end()) {
+            *out = it->second;
+            return GBL_OK;
+        }
+        float* rgba = nullptr;
+        int32_t w = 0, h = 0;
+        gbl_status st = gbl_host_detail::load_image(path, &rgba, &w, &h);
+        if (st != GBL_OK) return st;
+        const size_t n = static_cast<size_t>(w) * h;
+        const int channels = is_float ? 1 : 4;
+        std::vector<float> level0(n * channels);
+        for (size_t i = 0; i < n; ++i) {
+            const float* in = rgba + 4 * i;
+            if (light_filter) {          // buffer[i] *= filter
+                for (int c = 0; c < 3; ++c) level0[4 * i + c] = in[c] * light_filter[c];
+                level0[4 * i + 3] = in[3];
+            } else if (is_float) {
+                const float v = channel == 4 ? 0.212671f * in[0] + 0.715160f * in[1] + 0.072169f * in[2] : in[channel];
+                level0[i] = powf(v, gamma);
+            } else {
+                float c[4] = {in[0], in[1], in[2], in[3]};
+                if (channel != 4) {      // Color(in.<channel>): grey, alpha 1
+                    c[0] = c[1] = c[2] = in[channel];
+                    c[3] = 1.0f;
+                }
+                for (int j = 0; j < 3; ++j) level0[4 * i + j] = gamma == 1.0f ? c[j] : powf(c[j], gamma);
+                level0[4 * i + 3] = c[3];
+            }
+        }
+        free(rgba);
+        s_->images.push_back(gbl_host_detail::build_mipmap(s_->texels, std::move(level0), w, h, channels));
+        *out = static_cast<int32_t>(s_->images.size()) - 1;
+        image_cache_[k] = *out;
+        return GBL_OK;
+    }
+
     int add_constant(bool is_float, const float c[3]) {
         gbl_texture g;
         memset(&g, 0, sizeof(g));
@@ -692,6 +789,7 @@ private:
         g.is_float = is_float ? 1u : 0u;
         for (int i = 0; i < 3; ++i) g.value[i] = c[i];
         g.child[0] = g.child[1] = -1;
+        g.image = -1;
         s_->textures.push_back(g);
         return static_cast<int>(s_->textures.size()) - 1;
     }
@@ -944,8 +1042,16 @@ private:
             lt.sample_num = 1;   // Light::getSamplesNum (GoblinLight.h:124); area lights read "sample_num"
             lt.to_world.orientation[0] = 1.0f;
             lt.to_world.scale[0] = lt.to_world.scale[1] = lt.to_world.scale[2] = 1.0f;
+            lt.image = -1;
             if (type == "ibl") {
-                return fail(GBL_ERR_UNSUPPORTED, "light type \"" + type + "\" is outside the device path");
+                lt.type = GBL_LIGHT_IBL;   // createImageBasedLight, GoblinLight.cpp:681-691
+                Vec F = p.get_vec(p.vec3s, "filter", vec(0, 0, 0));
+                for (int i = 0; i < 3; ++i) lt.color[i] = F.v[i];
+                std::string err;
+                read_orientation(p, lt.to_world.orientation, &err);
+                lt.sample_num = static_cast<uint32_t>(std::max(0, p.get_int("sample_num", 1)));
+                gbl_status st = image_ref(resolve(p.get_string("file")), false, 1.0f, 4, lt.color, &lt.image);
+                if (st != GBL_OK) return st;
             } else if (type == "directional") {
                 lt.type = GBL_LIGHT_DIRECTIONAL;   // createDirectionalLight, GoblinLight.cpp:640-646
                 Vec R = p.get_vec(p.vec3s, "radiance", vec(0, 0, 0));
@@ -1032,6 +1138,10 @@ private:
         d.materials = s_->materials.data();
         d.num_textures = static_cast<uint32_t>(s_->textures.size());
         d.textures = s_->textures.data();
+        d.num_images = static_cast<uint32_t>(s_->images.size());
+        d.images = s_->images.data();
+        d.num_texels = s_->texels.size();
+        d.texels = s_->texels.data();
         d.num_instances = static_cast<uint32_t>(s_->instances.size());
         d.instances = s_->instances.data();
         d.num_lights = static_cast<uint32_t>(s_->lights.size());

@@ -11,6 +11,8 @@
 #include "../device_scene.h"
 #include "trace.h"
 #include "vecmath.h"
+#include "refmath.h"
+#include "image.h"
 
 #define GBL_MAT_LAMBERT 0u
 #define GBL_MAT_BLINN 1u
@@ -22,6 +24,7 @@
 #define GBL_LIGHT_DIRECTIONAL 1u
 #define GBL_LIGHT_SPOT 2u
 #define GBL_LIGHT_AREA 3u
+#define GBL_LIGHT_IBL 4u
 
 struct Frag {
     F3 p, n;      // world position / shading normal
@@ -180,6 +183,34 @@ __device__ __forceinline__ float integrate_checker(float x) {
     float xh = 0.5f * x;
     return floorf(xh) + 2.0f * fmaxf(xh - floorf(xh) - 0.5f, 0.0f);
 }
+// TextureMapping::map (UVMapping / SphericalMapping, GoblinTexture.cpp:296-347)
+__device__ __forceinline__ TexCoord tex_map(const DevTexture& g, const Frag& fr, const TexFrag& tf) {
+    TexCoord tc;
+    if (g.mapping == 1u) {
+        point_to_st(g.to_tex, fr.p, &tc.s, &tc.t);
+        float sdx, tdx, sdy, tdy;
+        point_to_st(g.to_tex, fr.p + tf.dpdx, &sdx, &tdx);
+        point_to_st(g.to_tex, fr.p + tf.dpdy, &sdy, &tdy);
+        float dsdx = sdx - tc.s;
+        if (dsdx > 0.5f) dsdx -= 1.0f;
+        else if (dsdx < -0.5f) dsdx += 1.0f;
+        float dsdy = sdy - tc.s;
+        if (dsdy > 0.5f) dsdy -= 1.0f;
+        else if (dsdy < -0.5f) dsdy += 1.0f;
+        tc.dsdx = dsdx;
+        tc.dsdy = dsdy;
+        tc.dtdx = tdx - tc.t;
+        tc.dtdy = tdy - tc.t;
+    } else {
+        tc.s = g.uv_scale[0] * tf.u + g.uv_offset[0];
+        tc.t = g.uv_scale[1] * tf.v + g.uv_offset[1];
+        tc.dsdx = g.uv_scale[0] * tf.dudx;
+        tc.dtdx = g.uv_scale[1] * tf.dvdx;
+        tc.dsdy = g.uv_scale[0] * tf.dudy;
+        tc.dtdy = g.uv_scale[1] * tf.dvdy;
+    }
+    return tc;
+}
 // Texture<T>::lookup (float textures carry their value in every channel)
 template <int DEPTH>
 __device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& fr, const TexFrag& tf) {
@@ -189,31 +220,15 @@ __device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& f
         return value;   // the packer rejects graphs deeper than GBL_TEX_MAX_DEPTH
     } else {
         if (g.type == 0u) return value;
+        if (g.type == 3u) {   // ImageTexture<T>::lookup: map, then the MIPMap
+            const TexCoord tc = tex_map(g, fr, tf);
+            return mip_lookup(sc, sc.images[g.image], g.is_float != 0u, tc, g.filter, g.address, g.max_aniso);
+        }
         const F3 a = tex_eval<DEPTH - 1>(sc, g.child[0], fr, tf);
         const F3 b = tex_eval<DEPTH - 1>(sc, g.child[1], fr, tf);
         if (g.type == 2u) return a * b.x;   // ScaleTexture: mScale->lookup * mTexture->lookup
-        float s, t, dsdx, dtdx, dsdy, dtdy;
-        if (g.mapping == 1u) {
-            point_to_st(g.to_tex, fr.p, &s, &t);
-            float sdx, tdx, sdy, tdy;
-            point_to_st(g.to_tex, fr.p + tf.dpdx, &sdx, &tdx);
-            point_to_st(g.to_tex, fr.p + tf.dpdy, &sdy, &tdy);
-            dsdx = sdx - s;
-            if (dsdx > 0.5f) dsdx -= 1.0f;
-            else if (dsdx < -0.5f) dsdx += 1.0f;
-            dsdy = sdy - s;
-            if (dsdy > 0.5f) dsdy -= 1.0f;
-            else if (dsdy < -0.5f) dsdy += 1.0f;
-            dtdx = tdx - t;
-            dtdy = tdy - t;
-        } else {
-            s = g.uv_scale[0] * tf.u + g.uv_offset[0];
-            t = g.uv_scale[1] * tf.v + g.uv_offset[1];
-            dsdx = g.uv_scale[0] * tf.dudx;
-            dtdx = g.uv_scale[1] * tf.dvdx;
-            dsdy = g.uv_scale[0] * tf.dudy;
-            dtdy = g.uv_scale[1] * tf.dvdy;
-        }
+        const TexCoord tc = tex_map(g, fr, tf);
+        const float s = tc.s, t = tc.t, dsdx = tc.dsdx, dtdx = tc.dtdx, dsdy = tc.dsdy, dtdy = tc.dtdy;
         const bool first = (static_cast<int>(floorf(s)) + static_cast<int>(floorf(t))) % 2 == 0;
         if (!g.filter) return first ? a : b;
         float ds = fmaxf(fabsf(dsdx), fabsf(dsdy)), dt = fmaxf(fabsf(dtdx), fabsf(dtdy));
@@ -612,6 +627,11 @@ template <bool EXT>
 __device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight& l, F3 p, float epsilon, float u_comp, float u1,
                                              float u2, LightSampleOut& o) {
     F3 color = f3(l.color[0], l.color[1], l.color[2]);
+    if (EXT && l.type == GBL_LIGHT_IBL) {   // ImageBasedLight::sampleL, GoblinLight.cpp:529-555: the shadow ray has no far end
+        o.L = ibl_sample(sc, l, u1, u2, &o.wi, &o.pdf);
+        o.maxt = INFINITY;
+        return;
+    }
     if (EXT && l.type == GBL_LIGHT_DIRECTIONAL) {   // DirectionalLight::sampleL, GoblinLight.cpp:145-154
         o.wi = -f3(l.axis[0], l.axis[1], l.axis[2]);
         o.pdf = 1.0f;
@@ -679,9 +699,33 @@ __device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight&
 // light->pdf(p, wi): 0 for delta lights, AreaLight::pdf otherwise (wi is NOT renormalised in light space)
 template <bool EXT>
 __device__ __forceinline__ float light_pdf(const DevScene& sc, const DevLight& l, F3 p, F3 wi) {
+    if (EXT && l.type == GBL_LIGHT_IBL) return ibl_pdf(sc, l, wi);
     if (l.type != GBL_LIGHT_AREA) return 0.0f;
     if (EXT && l.shape != 0u) return light_shape_pdf(l, xf_point(l.inv, p), xf_vector(l.inv, wi));
     return light_geoset_pdf(sc, l, xf_point(l.inv, p), xf_vector(l.inv, wi));
+}
+
+// Light::isDelta (GoblinLight.h:116, :296, :346): every light but the area and the image based ones
+template <bool EXT>
+__device__ __forceinline__ bool light_is_delta(const DevLight& l) {
+    return l.type != GBL_LIGHT_AREA && !(EXT && l.type == GBL_LIGHT_IBL);
+}
+// light->Le(ray) of a ray that left the scene: Black but for an image based light (GoblinLight.h:76, GoblinLight.cpp:520-527)
+template <bool EXT>
+__device__ __forceinline__ F3 light_le_escaped(const DevScene& sc, const DevLight& l, F3 dir) {
+    if (EXT && l.type == GBL_LIGHT_IBL) return ibl_le(sc, l, dir);
+    return f3(0.0f, 0.0f, 0.0f);
+}
+// Scene::evalEnvironmentLight (GoblinScene.cpp:89-95): the sum over every light
+template <bool EXT>
+__device__ __forceinline__ F3 environment_le(const DevScene& sc, F3 dir) {
+    F3 L = f3(0.0f, 0.0f, 0.0f);
+    if (EXT && sc.has_ibl != 0)
+        for (int i = 0; i < sc.num_lights; ++i) {
+            const F3 le = light_le_escaped<EXT>(sc, sc.lights[i], dir);
+            L = f3(L.x + le.x, L.y + le.y, L.z + le.z);
+        }
+    return L;
 }
 
 // Intersection::Le(out): the hit instance's area light, one-sided

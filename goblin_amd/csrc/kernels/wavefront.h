@@ -333,6 +333,10 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             }
             if (ps.bounce < 0) {
                 if (!got) {
+                    if (EXT) {   // Li += scene->evalEnvironmentLight(ray), GoblinPathtracer.cpp:61-65
+                        const F3 le = environment_le<EXT>(sc, ps.d);
+                        ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                    }
                     finished = true;
                 } else {
                     F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
@@ -354,6 +358,12 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                         F3 term = EXT ? div(ps.f * mis_tr * le * ps.cosw * ps.fw, ps.bsdf_pdf) : div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
                         ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
                     }
+                } else if (EXT && mis_inst < 0 && sc.has_ibl != 0) {
+                    // the sampled direction left the scene: Ld += f * tr * light->Le(r) * fWeight / bsdfPdf (:157-161).  A slot
+                    // that only waited for its shadow ray (f == 0, no extension ray) adds 0 here.
+                    const F3 le = light_le_escaped<EXT>(sc, sc.lights[ps.light], ps.d);
+                    const F3 term = div(ps.f * mis_tr * le * ps.fw, ps.bsdf_pdf);
+                    ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
                 }
                 F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
                 ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                 shadow_d = ls.wi;
                 shadow_maxt = ls.maxt;
                 float lw = 1.0f;
-                if (light.type != GBL_LIGHT_AREA) {
+                if (light_is_delta<EXT>(light)) {
                     contrib = div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);
                 } else {
                     float bp = EXT ? rmat_pdf(rmat, fr.n, wo, ls.wi) : mat_pdf(*mat, fr.n, wo, ls.wi);
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                 if (masks) {   // the shadow kernel multiplies the attenuation in, in the reference's order
                     sh_f4 = make_float4(f.x, f.y, f.z, absdot(fr.n, ls.wi));
                     sh_L4 = make_float4(ls.L.x, ls.L.y, ls.L.z, lw);
-                    contrib = f3(ls.pdf, light.type == GBL_LIGHT_AREA ? 1.0f : 0.0f, 0.0f);
+                    contrib = f3(ls.pdf, light_is_delta<EXT>(light) ? 0.0f : 1.0f, 0.0f);
                 }
             }
         }

@@ -270,7 +270,11 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WP_WAVES) void wp_kernel(DevScene sc
                     }
                     if (ps.bounce < 0) {
                         if (!got) {
-                            finished = true;   // no image based light on this path: evalEnvironmentLight == 0
+                            if (EXT) {   // Li += scene->evalEnvironmentLight(ray), GoblinPathtracer.cpp:61-65
+                                const F3 le = environment_le<EXT>(sc, ps.d);
+                                ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                            }
+                            finished = true;
                         } else {
                             F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
                             ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
@@ -288,6 +292,12 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WP_WAVES) void wp_kernel(DevScene sc
                                 F3 term = EXT ? div(ps.f * f3(1.0f, 1.0f, 1.0f) * le * ps.cosw * ps.fw, ps.bsdf_pdf) : div(ps.f * le * ps.cosw * ps.fw, ps.bsdf_pdf);
                                 ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
                             }
+                        } else if (EXT && !got && sc.has_ibl != 0) {
+                            // the sampled direction left the scene: Ld += f * tr * light->Le(r) * fWeight / bsdfPdf (:157-161).  A job that only
+                            // carried its shadow ray (f == 0, no extension ray) adds 0 here.
+                            const F3 le = light_le_escaped<EXT>(sc, sc.lights[ps.light], ps.d);
+                            const F3 term = div(ps.f * le * ps.fw, ps.bsdf_pdf);
+                            ps.Ld = f3(ps.Ld.x + term.x, ps.Ld.y + term.y, ps.Ld.z + term.z);
                         }
                         F3 add = div(ps.throughput * ps.Ld, ps.pick_pdf);
                         ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(GBL_BLOCK, GBL_WP_WAVES) void wp_kernel(DevScene sc
                         need_shadow = true;
                         shadow_d = ls.wi;
                         shadow_maxt = ls.maxt;
-                        if (light.type != GBL_LIGHT_AREA) {
+                        if (light_is_delta<EXT>(light)) {
                             contrib = div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);
                         } else {
                             float bp = EXT ? rmat_pdf(rmat, fr.n, wo, ls.wi) : mat_pdf(*mat, fr.n, wo, ls.wi);

@@ -58,7 +58,7 @@ __device__ __forceinline__ F3 wh_estimate_ld(const DevScene& sc, const Frag& fr,
             Hit dummy;
             if (STATS) cnt.shadow += 1;
             if (!trace<true, STATS, true>(sc, fr.p, ls.wi, fr.eps, ls.maxt, stk, dummy, cnt)) {
-                if (light.type != GBL_LIGHT_AREA) return div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);   // isDelta(): no MIS
+                if (light_is_delta<true>(light)) return div(f * ls.L * absdot(fr.n, ls.wi), ls.pdf);   // isDelta(): no MIS
                 const float bp = rmat_pdf(rmat, fr.n, wo, ls.wi);
                 const float lw = power_heuristic(ls.pdf, bp);
                 const F3 t = div(f * ls.L * absdot(fr.n, ls.wi) * lw, ls.pdf);
@@ -96,7 +96,11 @@ __device__ __forceinline__ F3 wh_estimate_ld(const DevScene& sc, const Frag& fr,
                     Ld = f3(Ld.x + t.x, Ld.y + t.y, Ld.z + t.z);
                 }
             }
-        }   // a miss adds light->Le(r), Black for every light on this path
+        } else if (sc.has_ibl != 0) {   // the radiance contribution from IBL: Ld += f * light->Le(r) * fWeight / bsdfPdf (:558-561)
+            const F3 le = light_le_escaped<true>(sc, light, wi);
+            const F3 t = div(f * le * fw, pdf);
+            Ld = f3(Ld.x + t.x, Ld.y + t.y, Ld.z + t.z);
+        }
     }
     return Ld;
 }
@@ -232,6 +236,10 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
                     descend = true;
                 }
             }
+        } else {
+            // get image based lighting if the ray didn't hit anything: Li += scene->evalEnvironmentLight(ray) (GoblinWhitted.cpp:40-43)
+            const F3 le = environment_le<true>(sc, d);
+            ret = f3(0.0f + le.x, 0.0f + le.y, 0.0f + le.z);
         }
         if (descend) continue;
         // ---- hand `ret` to the parents until one of them has another child to trace

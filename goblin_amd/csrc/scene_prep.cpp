@@ -453,6 +453,7 @@ int texture_depth(const gbl_scene_desc* d, int32_t id, int guard) {
     if (id < 0 || static_cast<uint32_t>(id) >= d->num_textures || guard > 64) return -1;
     const gbl_texture& g = d->textures[id];
     if (g.type == GBL_TEX_CONSTANT) return 0;
+    if (g.type == GBL_TEX_IMAGE) return 1;   // a leaf with a lookup of its own
     int a = texture_depth(d, g.child[0], guard + 1), b = texture_depth(d, g.child[1], guard + 1);
     if (a < 0 || b < 0) return -1;
     return 1 + std::max(a, b);
@@ -826,12 +827,50 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         }
     }
 
+    // ---- images: the pyramids arrive built (gbl_image); the device wants every level's offset
+    out->images.resize(d->num_images);
+    for (uint32_t i = 0; i < d->num_images; ++i) {
+        const gbl_image& gi = d->images[i];
+        DevImage& di = out->images[i];
+        memset(&di, 0, sizeof(di));
+        if (gi.width == 0 || gi.height == 0 || (gi.width & (gi.width - 1)) || (gi.height & (gi.height - 1)) || (gi.channels != 1 && gi.channels != 4) ||
+            gi.levels == 0 || gi.levels > 18) {
+            *err = "image " + std::to_string(i) + ": sides must be powers of two, channels 1 or 4, at most 18 levels";
+            return GBL_ERR_INVALID;
+        }
+        di.width = gi.width;
+        di.height = gi.height;
+        di.levels = gi.levels;
+        di.channels = gi.channels;
+        di.offset = gi.texel_offset;
+        uint64_t off = 0;
+        for (uint32_t l = 0; l < gi.levels; ++l) {
+            di.level_offset[l] = static_cast<uint32_t>(off);
+            off += static_cast<uint64_t>(std::max(1u, gi.width >> l)) * std::max(1u, gi.height >> l) * gi.channels;
+        }
+        if (gi.texel_offset + off > d->num_texels || off >= (1ull << 32)) {
+            *err = "image " + std::to_string(i) + ": texels out of range";
+            return GBL_ERR_INVALID;
+        }
+    }
+    // MIPMap<T>::initEWALut (GoblinTexture.cpp:262-271)
+    out->ewa_lut.resize(128);
+    for (int i = 0; i < 128; ++i) {
+        const float r2 = static_cast<float>(i) / static_cast<float>(128 - 1);
+        out->ewa_lut[i] = expf(-2.0f * r2) - expf(-2.0f);
+    }
+
     // ---- textures
     out->textures.resize(d->num_textures);
     for (uint32_t i = 0; i < d->num_textures; ++i) {
         const gbl_texture& g = d->textures[i];
-        if (g.type > GBL_TEX_SCALE || g.mapping > GBL_MAP_SPHERICAL) {
+        if (g.type > GBL_TEX_IMAGE || g.mapping > GBL_MAP_SPHERICAL) {
             *err = "unknown texture or mapping type";
+            return GBL_ERR_INVALID;
+        }
+        if (g.type == GBL_TEX_IMAGE && (g.image < 0 || static_cast<uint32_t>(g.image) >= d->num_images || g.image_filter > GBL_IMAGE_FILTER_EWA ||
+                                        g.address > GBL_ADDRESS_BORDER || d->images[g.image].channels != (g.is_float ? 1u : 4u))) {
+            *err = "image texture " + std::to_string(i) + ": bad image index, filter, address mode or channel count";
             return GBL_ERR_INVALID;
         }
         DevTexture& t = out->textures[i];
@@ -842,12 +881,15 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         t.child[0] = g.child[0];
         t.child[1] = g.child[1];
         t.mapping = g.mapping;
-        t.filter = g.filter;
+        t.filter = g.type == GBL_TEX_IMAGE ? g.image_filter : g.filter;
+        t.image = g.type == GBL_TEX_IMAGE ? g.image : -1;
+        t.address = g.address;
+        t.max_aniso = g.max_anisotropy;
         for (int k = 0; k < 2; ++k) {
             t.uv_scale[k] = g.uv_scale[k];
             t.uv_offset[k] = g.uv_offset[k];
         }
-        if (g.type == GBL_TEX_CHECKERBOARD && g.mapping == GBL_MAP_SPHERICAL) {
+        if ((g.type == GBL_TEX_CHECKERBOARD || g.type == GBL_TEX_IMAGE) && g.mapping == GBL_MAP_SPHERICAL) {
             Trs tt = compose(g.to_tex.position, g.to_tex.orientation, g.to_tex.scale);   // SphericalMapping::mToTex
             store3x4(tt.m, t.to_tex);
         }
@@ -1000,6 +1042,100 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             }
             float world_area = sum * (gl.to_world.scale[0] * gl.to_world.scale[1]);
             pr = dl.color[0] * kPi * world_area; pg = dl.color[1] * kPi * world_area; pb = dl.color[2] * kPi * world_area;
+        } else if (gl.type == GBL_LIGHT_IBL) {
+            // ImageBasedLight's constructor (GoblinLight.cpp:464-508)
+            if (gl.image < 0 || static_cast<uint32_t>(gl.image) >= d->num_images || d->images[gl.image].channels != 4) {
+                *err = "image based light " + std::to_string(i) + ": bad image index";
+                return GBL_ERR_INVALID;
+            }
+            out->extended = 1;
+            out->has_ibl = 1;
+            dl.image = gl.image;
+            // mToWorld.rotateX(-PI / 2); rotateY(-PI / 2); setOrientation(orientation * mToWorld.getOrientation())
+            struct Q { float w, x, y, z; };
+            auto qmul = [](const Q& a, const Q& b) {   // GoblinQuaternion.h:45-48
+                const float d3 = a.x * b.x + a.y * b.y + a.z * b.z;
+                Q r;
+                r.w = a.w * b.w - d3;
+                r.x = a.w * b.x + b.w * a.x + (a.y * b.z - a.z * b.y);
+                r.y = a.w * b.y + b.w * a.y + (a.z * b.x - a.x * b.z);
+                r.z = a.w * b.z + b.w * a.z + (a.x * b.y - a.y * b.x);
+                return r;
+            };
+            auto qnorm = [](const Q& q) {              // normalize(Quaternion), GoblinQuaternion.cpp:94-100
+                const float inv = 1.0f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+                Q r = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+                return r;
+            };
+            auto axis_angle = [](int axis, float angle) {   // Quaternion(axis, angle), GoblinQuaternion.cpp:9-15 (unit axes)
+                const float t = angle * 0.5f, st = sinf(t);
+                Q r = {cosf(t), axis == 0 ? 1.0f * st : 0.0f * st, axis == 1 ? 1.0f * st : 0.0f * st, 0.0f * st};
+                return r;
+            };
+            Q q = {1.0f, 0.0f, 0.0f, 0.0f};
+            q = qnorm(qmul(axis_angle(0, -0.5f * kPi), q));
+            q = qnorm(qmul(axis_angle(1, -0.5f * kPi), q));
+            const Q given = {gl.to_world.orientation[0], gl.to_world.orientation[1], gl.to_world.orientation[2], gl.to_world.orientation[3]};
+            q = qmul(given, q);
+            const float qq[4] = {q.w, q.x, q.y, q.z}, one[3] = {1.0f, 1.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
+            Trs t = compose(zero, qq, one);
+            store3x4(t.m, dl.m);
+            store3x4(t.inv, dl.inv);
+            const DevImage& im = out->images[gl.image];
+            auto texel = [&](uint32_t level, int s, int tt, int c) {   // AddressRepeat
+                const int w = static_cast<int>(std::max(1u, im.width >> level)), h = static_cast<int>(std::max(1u, im.height >> level));
+                s %= w; tt %= h;
+                if (s < 0) s += w;
+                if (tt < 0) tt += h;
+                return d->texels[im.offset + im.level_offset[level] + (static_cast<size_t>(tt) * w + s) * 4 + c];
+            };
+            // mAverageRadiance = mRadiance->lookup(maxLevel, 0, 0): the bilinear lookup of the 1 x 1 level
+            const uint32_t max_level = im.levels - 1;
+            float avg[3];
+            {
+                const int w = static_cast<int>(std::max(1u, im.width >> max_level)), h = static_cast<int>(std::max(1u, im.height >> max_level));
+                const float s_res = 0.0f * w - 0.5f, t_res = 0.0f * h - 0.5f;
+                const int s0 = static_cast<int>(floorf(s_res)), t0 = static_cast<int>(floorf(t_res));
+                const float ds = s_res - static_cast<float>(s0), dt = t_res - static_cast<float>(t0);
+                for (int c = 0; c < 3; ++c)
+                    avg[c] = (1.0f - ds) * (1.0f - dt) * texel(max_level, s0, t0, c) + (ds) * (1.0f - dt) * texel(max_level, s0 + 1, t0, c) +
+                             (1.0f - ds) * (dt)*texel(max_level, s0, t0 + 1, c) + (ds) * (dt)*texel(max_level, s0 + 1, t0 + 1, c);
+            }
+            // the sampling distribution: luminance * sin(theta) of level max(0, maxLevel - 8), as a CDF2D
+            const uint32_t dl_level = im.levels > 9 ? max_level - 8 : 0;
+            const int dw = static_cast<int>(std::max(1u, im.width >> dl_level)), dh = static_cast<int>(std::max(1u, im.height >> dl_level));
+            dl.dist_offset = static_cast<uint32_t>(out->ibl_dist.size());
+            dl.dist_w = static_cast<uint32_t>(dw);
+            dl.dist_h = static_cast<uint32_t>(dh);
+            auto cdf1d = [](const std::vector<float>& f, std::vector<float>* out_block) {   // CDF1D::init; block = func[n], cdf[n + 1], integral
+                const size_t n = f.size();
+                const float dx = 1.0f / n;
+                std::vector<float> cdf(n + 1, 0.0f);
+                for (size_t k = 1; k < n + 1; ++k) cdf[k] = cdf[k - 1] + (f[k - 1] * dx);
+                const float integral = cdf[n];
+                for (size_t k = 1; k < n + 1; ++k) cdf[k] /= integral;
+                out_block->insert(out_block->end(), f.begin(), f.end());
+                out_block->insert(out_block->end(), cdf.begin(), cdf.end());
+                out_block->push_back(integral);
+                return integral;
+            };
+            std::vector<float> rows_block, row_integrals;
+            for (int r = 0; r < dh; ++r) {
+                const float sin_theta = sinf((static_cast<float>(r) + 0.5f) / static_cast<float>(dh) * kPi);
+                std::vector<float> f(dw);
+                for (int c = 0; c < dw; ++c)
+                    f[c] = (0.212671f * texel(dl_level, c, r, 0) + 0.715160f * texel(dl_level, c, r, 1) + 0.072169f * texel(dl_level, c, r, 2)) * sin_theta;
+                row_integrals.push_back(cdf1d(f, &rows_block));
+            }
+            std::vector<float> marginal_block;
+            cdf1d(row_integrals, &marginal_block);
+            out->ibl_dist.insert(out->ibl_dist.end(), marginal_block.begin(), marginal_block.end());
+            out->ibl_dist.insert(out->ibl_dist.end(), rows_block.begin(), rows_block.end());
+            // ImageBasedLight::power (:606-613): mAverageRadiance * PI * (4 PI r^2) over the scene's bounding sphere
+            float dx = scene_bound.hi[0] - scene_bound.lo[0], dy = scene_bound.hi[1] - scene_bound.lo[1], dz = scene_bound.hi[2] - scene_bound.lo[2];
+            float radius = std::sqrt(dx * dx + dy * dy + dz * dz);
+            float a = 4.0f * kPi * radius * radius;
+            pr = avg[0] * kPi * a; pg = avg[1] * kPi * a; pb = avg[2] * kPi * a;
         } else if (gl.type == GBL_LIGHT_POINT) {
             float s = 4.0f * kPi;
             pr = dl.color[0] * s; pg = dl.color[1] * s; pb = dl.color[2] * s;

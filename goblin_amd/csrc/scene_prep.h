@@ -17,6 +17,9 @@ struct PackedScene {
     std::vector<DevInstance> instances;
     std::vector<DevMaterial> materials;
     std::vector<DevTexture> textures;
+    std::vector<DevImage> images;
+    std::vector<float> ewa_lut, ibl_dist;
+    int32_t has_ibl = 0;
     std::vector<DevLight> lights;
     std::vector<DevLightTri> light_tris;
     std::vector<float> light_cdf, light_pick_pdf;

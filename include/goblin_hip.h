@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 8
+#define GBL_ABI_VERSION 9
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -87,16 +87,40 @@ typedef enum gbl_material_type {
 typedef enum gbl_texture_type {
     GBL_TEX_CONSTANT = 0,     /* ConstantTexture,   GoblinTexture.cpp:349-354, 617-625 */
     GBL_TEX_CHECKERBOARD = 1, /* CheckboardTexture, GoblinTexture.cpp:356-416, 627-647 */
-    GBL_TEX_SCALE = 2         /* ScaleTexture,      GoblinTexture.cpp:418-425, 649-665 */
+    GBL_TEX_SCALE = 2,        /* ScaleTexture,      GoblinTexture.cpp:418-425, 649-665 */
+    GBL_TEX_IMAGE = 3         /* ImageTexture over a MIPMap, GoblinTexture.cpp:428-470, 40-291, 667-745 */
 } gbl_texture_type;
+
+typedef enum gbl_image_filter {   /* "filter" of an image texture (GoblinTexture.cpp:687-700); MIPMap<T>::lookup :78-97 */
+    GBL_IMAGE_FILTER_NONE = 0,      /* "nearest": bilinear at level 0 (lookupNearest, :99-102) */
+    GBL_IMAGE_FILTER_BILINEAR = 1,  /* one level, rounded from the footprint width (:104-110) */
+    GBL_IMAGE_FILTER_TRILINEAR = 2, /* two levels blended (:112-127) */
+    GBL_IMAGE_FILTER_EWA = 3        /* elliptically weighted average (:129-258) */
+} gbl_image_filter;
+
+typedef enum gbl_address_mode {   /* ImageBuffer<T>::texel, GoblinTexture.cpp:10-38 */
+    GBL_ADDRESS_REPEAT = 0,
+    GBL_ADDRESS_CLAMP = 1,   /* as written there: t is clamped from s (:15) */
+    GBL_ADDRESS_BORDER = 2
+} gbl_address_mode;
+
+/* One MIPMap<T> (GoblinTexture.cpp:40-68): the image a texture or an image based light reads, already converted
+ * (ImageTexture::convertTexel: channel pick and gamma, :489-523; the light's colour filter, GoblinLight.cpp:483-485),
+ * resized to powers of two and reduced level by level with resizeImage's gaussian (:531-597).  Texels are
+ * `channels` floats each (1 for float textures, 4 rgba otherwise), level 0 first, each level row-major. */
+typedef struct gbl_image {
+    uint32_t width, height;   /* level 0 */
+    uint32_t levels;          /* floor(max(log2 w, log2 h)) + 1; level l is max(1, w >> l) x max(1, h >> l) */
+    uint32_t channels;
+    uint64_t texel_offset;    /* in floats, into gbl_scene_desc.texels */
+} gbl_image;
 
 typedef enum gbl_mapping_type {
     GBL_MAP_UV = 0,       /* UVMapping,        GoblinTexture.cpp:293-304 */
     GBL_MAP_SPHERICAL = 1 /* SphericalMapping, GoblinTexture.cpp:306-347 */
 } gbl_mapping_type;
 
-/* One texture of the scene's "textures" list ("format": color | float).  Image
- * textures are not on the device path. */
+/* One texture of the scene's "textures" list ("format": color | float). */
 typedef struct gbl_texture {
     uint32_t type;       /* gbl_texture_type                                            */
     uint32_t is_float;   /* "format" == "float"                                         */
@@ -108,6 +132,11 @@ typedef struct gbl_texture {
     float uv_offset[2];  /* uv mapping "offset" (default 0, 0)                          */
     gbl_trs to_tex;      /* spherical mapping: getTransform(params)                     */
     uint32_t filter;     /* checkerboard "filter" (bool, default false)                 */
+    /* image textures (getImageTextureParams, GoblinTexture.cpp:677-732); mapping / uv_* / to_tex as above */
+    int32_t image;          /* index into gbl_scene_desc.images, -1 otherwise                 */
+    uint32_t image_filter;  /* gbl_image_filter                                                */
+    uint32_t address;       /* gbl_address_mode                                                */
+    float max_anisotropy;   /* "max_anisotropy" (default 10; colour image textures always use the default, :741-745) */
 } gbl_texture;
 
 /* Materials.  Each texture slot is either a constant (tex_* == -1: the value is
@@ -150,7 +179,8 @@ typedef enum gbl_light_type {
     GBL_LIGHT_POINT = 0,       /* GoblinLight.cpp:78-134  */
     GBL_LIGHT_DIRECTIONAL = 1, /* GoblinLight.cpp:136-210 */
     GBL_LIGHT_SPOT = 2,        /* GoblinLight.cpp:212-287 */
-    GBL_LIGHT_AREA = 3   /* GoblinLight.cpp:345-461 */
+    GBL_LIGHT_AREA = 3,  /* GoblinLight.cpp:345-461 */
+    GBL_LIGHT_IBL = 4    /* ImageBasedLight, GoblinLight.cpp:464-629 */
 } gbl_light_type;
 
 typedef struct gbl_light {
@@ -162,8 +192,11 @@ typedef struct gbl_light {
     float cos_falloff_start; /* spot                                           */
     uint32_t mesh;           /* area: emitting geometry                        */
     gbl_trs to_world;        /* area                                           */
-    uint32_t sample_num;     /* area: "sample_num" (default 1) = Light::getSamplesNum, read by the Whitted
+    uint32_t sample_num;     /* area / ibl: "sample_num" (default 1) = Light::getSamplesNum, read by the Whitted
                               * renderer's per-light quota (GoblinLight.cpp:675, GoblinWhitted.cpp:60-66); 1 for the rest */
+    int32_t image;           /* ibl: the radiance map's MIPMap (already multiplied by "filter"), index into images;
+                              * to_world.orientation holds "orientation" as given (the constructor's rotateX / rotateY
+                              * pre-rotation is applied by gbl_create, GoblinLight.cpp:470-474) */
 } gbl_light;
 
 typedef enum gbl_camera_type {
@@ -259,6 +292,10 @@ typedef struct gbl_scene_desc {
     const gbl_material* materials;
     uint32_t num_textures;
     const gbl_texture* textures; /* only the non-constant ones materials reach */
+    uint32_t num_images;
+    const gbl_image* images;     /* MIP pyramids of image textures and image based lights */
+    uint64_t num_texels;         /* floats */
+    const float* texels;
     uint32_t num_instances;
     const gbl_instance* instances; /* in SceneCache::getInstances() order */
     uint32_t num_lights;

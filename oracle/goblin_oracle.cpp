@@ -444,6 +444,7 @@ struct Light {
     uint32_t mesh;
     Xform xf;
     AreaGeo geo;
+    int image = -1;   // ImageBasedLight: mRadiance (index into orc_scene::images); its CDF2D is orc_scene::ibl_rows / ibl_marginal
 };
 
 // CDF1D, GoblinSampler.cpp:309-342
@@ -465,6 +466,14 @@ struct Cdf {
         if (pdf) *pdf = (f[off] / integral) * dx;
         return off;
     }
+    float sample_continuous(float u, float* pdf, int* index) const {   // CDF1D::sampleContinuous, :344-356
+        auto lb = std::lower_bound(cdf.begin(), cdf.end(), u);
+        int off = std::max(0, static_cast<int>(lb - cdf.begin() - 1));
+        float d = (u - cdf[off]) / (cdf[off + 1] - cdf[off]);
+        if (pdf) *pdf = f[off] / integral;
+        if (index) *index = off;
+        return (static_cast<float>(off) + d) / f.size();
+    }
 };
 
 }  // namespace
@@ -476,6 +485,11 @@ struct orc_scene {
     std::vector<gbl_material> materials;
     std::vector<gbl_texture> textures;
     std::vector<Xform> tex_xf;   // SphericalMapping::mToTex per texture
+    std::vector<gbl_image> images;   // MIP pyramids (built by the scene front end exactly as MIPMap's constructor does)
+    std::vector<float> texels;
+    std::vector<float> ewa_lut;      // MIPMap<T>::EWALut
+    std::vector<Cdf> ibl_marginal;               // per light (image based lights only): CDF2D::mMarginalDist ...
+    std::vector<std::vector<Cdf>> ibl_rows;      // ... and mConditionalDist
     bool has_masks = false;
     std::vector<uint32_t> light_samples;   // Light::getSamplesNum per light (the Whitted renderer's quota)
     // HomogeneousVolumeRegion (GoblinVolume.h:72-112)
@@ -505,6 +519,12 @@ struct orc_scene {
     float filter_table[256];
     int window[4];
 };
+
+namespace {
+// MIPMap lookups (defined with the textures below; the scene constructor's image based light needs them)
+Col mip_level(const orc_scene* sc, const gbl_image& im, int level, float s, float t, uint32_t mode);
+inline void level_dims(const gbl_image& im, int level, int* w, int* h, size_t* off);
+}  // namespace
 
 namespace {
 
@@ -703,6 +723,13 @@ void prepare(orc_scene* s) {
     }
     s->materials.assign(d.materials, d.materials + d.num_materials);
     s->textures.assign(d.textures, d.textures + d.num_textures);
+    s->images.assign(d.images, d.images + d.num_images);
+    s->texels.assign(d.texels, d.texels + d.num_texels);
+    s->ewa_lut.resize(128);   // MIPMap<T>::initEWALut, GoblinTexture.cpp:262-271
+    for (size_t i = 0; i < 128; ++i) {
+        float r2 = float(i) / float(128 - 1);
+        s->ewa_lut[i] = expf(-2.0f * r2) - expf(-2.0f);
+    }
     s->tex_xf.resize(d.num_textures);
     for (uint32_t i = 0; i < d.num_textures; ++i)
         s->tex_xf[i].set(d.textures[i].to_tex.position, d.textures[i].to_tex.orientation, d.textures[i].to_tex.scale);
@@ -742,6 +769,8 @@ void prepare(orc_scene* s) {
     for (uint32_t i = 0; i < d.num_lights; ++i) s->light_samples[i] = d.lights[i].sample_num;
     std::vector<float> powers;
     s->light_power_rgb.clear();
+    s->ibl_marginal.resize(d.num_lights);
+    s->ibl_rows.resize(d.num_lights);
     for (uint32_t i = 0; i < d.num_lights; ++i) {
         const gbl_light& gl = d.lights[i];
         Light& l = s->lights[i];
@@ -802,6 +831,59 @@ void prepare(orc_scene* s) {
             // AreaLight::power, GoblinLight.cpp:446-455
             float world_area = l.geo.sum_area * (l.xf.scale.x * l.xf.scale.y);
             power = l.color * PI * world_area;
+        } else if (gl.type == GBL_LIGHT_IBL) {
+            // ImageBasedLight's constructor (GoblinLight.cpp:464-508): the frame, the average radiance, the CDF2D
+            l.image = gl.image;
+            struct Q { float w, x, y, z; };
+            auto qmul = [](const Q& a, const Q& b) {   // GoblinQuaternion.h:45-48
+                float d3 = a.x * b.x + a.y * b.y + a.z * b.z;
+                Q r;
+                r.w = a.w * b.w - d3;
+                r.x = a.w * b.x + b.w * a.x + (a.y * b.z - a.z * b.y);
+                r.y = a.w * b.y + b.w * a.y + (a.z * b.x - a.x * b.z);
+                r.z = a.w * b.z + b.w * a.z + (a.x * b.y - a.y * b.x);
+                return r;
+            };
+            auto qnorm = [](const Q& q) {   // normalize(Quaternion), GoblinQuaternion.cpp:94-100
+                float inv = 1.0f / std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+                Q r = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+                return r;
+            };
+            auto axis_angle = [](int axis, float angle) {   // Quaternion(unit axis, angle), GoblinQuaternion.cpp:9-15
+                float t = angle * 0.5f, st = std::sin(t);
+                Q r = {std::cos(t), axis == 0 ? 1.0f * st : 0.0f * st, axis == 1 ? 1.0f * st : 0.0f * st, 0.0f * st};
+                return r;
+            };
+            Q q = {1.0f, 0.0f, 0.0f, 0.0f};
+            q = qnorm(qmul(axis_angle(0, -0.5f * PI), q));   // mToWorld.rotateX(-0.5f * PI)
+            q = qnorm(qmul(axis_angle(1, -0.5f * PI), q));   // mToWorld.rotateY(-0.5f * PI)
+            Q given = {gl.to_world.orientation[0], gl.to_world.orientation[1], gl.to_world.orientation[2], gl.to_world.orientation[3]};
+            q = qmul(given, q);                              // setOrientation(orientation * mToWorld.getOrientation())
+            float qq[4] = {q.w, q.x, q.y, q.z}, one[3] = {1.0f, 1.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
+            l.xf.set(zero, qq, one);
+            const gbl_image& im = s->images[gl.image];
+            int max_level = static_cast<int>(im.levels) - 1;
+            Col average = mip_level(s, im, max_level, 0.0f, 0.0f, GBL_ADDRESS_REPEAT);
+            int dist_level = std::max(0, max_level - 8);
+            int dw, dh;
+            size_t off;
+            level_dims(im, dist_level, &dw, &dh, &off);
+            std::vector<float> row_integrals;
+            s->ibl_rows[i].resize(dh);
+            for (int r = 0; r < dh; ++r) {
+                float sin_theta = std::sin(((float)r + 0.5f) / (float)dh * PI);
+                std::vector<float> f(dw);
+                for (int cc = 0; cc < dw; ++cc) {
+                    const float* px = s->texels.data() + off + (static_cast<size_t>(r) * dw + cc) * 4;
+                    f[cc] = luminance(Col(px[0], px[1], px[2])) * sin_theta;
+                }
+                s->ibl_rows[i][r].init(f);
+                row_integrals.push_back(s->ibl_rows[i][r].integral);
+            }
+            s->ibl_marginal[i].init(row_integrals);
+            // ImageBasedLight::power (:606-613)
+            float radius = length(s->tlas.bounds.hi - s->tlas.bounds.lo);
+            power = average * PI * (4.0f * PI * radius * radius);
         } else {
             power = 4.0f * PI * l.color;   // PointLight::power, GoblinLight.cpp:132-134
         }
@@ -1300,9 +1382,139 @@ inline float integrate_checker(float x) {   // GoblinTexture.cpp:371-375
     float x_half = 0.5f * x;
     return std::floor(x_half) + 2.0f * std::max(x_half - std::floor(x_half) - 0.5f, 0.0f);
 }
+// ---- MIPMap<T> (GoblinTexture.cpp:40-291).  The levels come built (gbl_image); T = float is kept in .r of a Col.
+inline void level_dims(const gbl_image& im, int level, int* w, int* h, size_t* off) {   // (declared above)
+    size_t o = 0;
+    for (int l = 0; l < level; ++l) o += static_cast<size_t>(std::max(1u, im.width >> l)) * std::max(1u, im.height >> l) * im.channels;
+    *w = static_cast<int>(std::max(1u, im.width >> level));
+    *h = static_cast<int>(std::max(1u, im.height >> level));
+    *off = static_cast<size_t>(im.texel_offset) + o;
+}
+Col image_texel(const orc_scene* sc, const gbl_image& im, int level, int s, int t, uint32_t mode) {   // ImageBuffer<T>::texel, :10-38
+    int w, h;
+    size_t off;
+    level_dims(im, level, &w, &h, &off);
+    if (mode == GBL_ADDRESS_CLAMP) {
+        s = std::min(std::max(s, 0), w - 1);
+        t = std::min(std::max(s, 0), h - 1);   // sic: clamp(s, 0, height - 1), :15
+    } else if (mode == GBL_ADDRESS_BORDER) {
+        if (s < 0 || t < 0 || s >= w || t >= h) return Col(0.0f);
+    } else {
+        s = s % w;
+        t = t % h;
+        if (s < 0) s += w;
+        if (t < 0) t += h;
+    }
+    const float* p = sc->texels.data() + off + (static_cast<size_t>(t) * w + s) * im.channels;
+    if (im.channels == 1) return Col(p[0], p[0], p[0]);
+    return Col(p[0], p[1], p[2]);
+}
+Col mip_level(const orc_scene* sc, const gbl_image& im, int level, float s, float t, uint32_t mode) {   // MIPMap<T>::lookup(level, ...), :276-291
+    // (the reference clamps to [0, levels] and reads mPyramid[levels] out of bounds at the top: clamped to the last level here)
+    level = std::min(std::max(level, 0), static_cast<int>(im.levels) - 1);
+    int w, h;
+    size_t off;
+    level_dims(im, level, &w, &h, &off);
+    float s_res = s * w - 0.5f, t_res = t * h - 0.5f;
+    int s0 = floor_int(s_res), t0 = floor_int(t_res);
+    float ds = s_res - (float)s0, dt = t_res - (float)t0;
+    return (1.0f - ds) * (1.0f - dt) * image_texel(sc, im, level, s0, t0, mode) + (ds) * (1.0f - dt) * image_texel(sc, im, level, s0 + 1, t0, mode) +
+           (1.0f - ds) * (dt)*image_texel(sc, im, level, s0, t0 + 1, mode) + (ds) * (dt)*image_texel(sc, im, level, s0 + 1, t0 + 1, mode);
+}
+Col mip_trilinear(const orc_scene* sc, const gbl_image& im, float s, float t, float width, uint32_t mode) {   // :112-127
+    int levels = static_cast<int>(im.levels);
+    float level = levels - 1 + log2f(std::max(width, 1e-8f));
+    int il = floor_int(level);
+    if (il < 0) return mip_level(sc, im, 0, s, t, mode);
+    if (il >= levels - 1) return mip_level(sc, im, levels - 1, s, t, mode);
+    float delta = level - (float)il;
+    return (1.0f - delta) * mip_level(sc, im, il, s, t, mode) + (delta)*mip_level(sc, im, il + 1, s, t, mode);
+}
+Col mip_ewa_level(const orc_scene* sc, const gbl_image& im, bool is_float, int level, float s, float t, float A, float B, float C, uint32_t mode) {   // :181-259
+    int w, h;
+    size_t off;
+    level_dims(im, level, &w, &h, &off);
+    float s_res = (float)w, t_res = (float)h;
+    s = s * w - 0.5f;
+    t = t * h - 0.5f;
+    A = A / (s_res * s_res);
+    B = B / (s_res * t_res);
+    C = C / (t_res * t_res);
+    float inv_det = 1.0f / (-B * B + 4.0f * A * C);
+    float off_s = 2.0f * sqrtf(C * inv_det), off_t = 2.0f * sqrtf(A * inv_det);
+    int s0 = static_cast<int>(ceilf(s - off_s)), s1 = floor_int(s + off_s), t0 = static_cast<int>(ceilf(t - off_t)), t1 = floor_int(t + off_t);
+    float weight_sum = 0.0f;
+    Col result(0.0f);
+    for (int is = s0; is <= s1; ++is) {
+        for (int it = t0; it <= t1; ++it) {
+            float ss = is - s, tt = it - t;
+            float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+            if (r2 <= 1.0f) {
+                size_t li = std::min((size_t)floor_int(r2 * 128), (size_t)127);
+                float weight = sc->ewa_lut[li];
+                result += weight * image_texel(sc, im, level, is, it, mode);
+                weight_sum += weight;
+            }
+        }
+    }
+    if (weight_sum > 0.0f) {
+        if (is_float) return Col(result.r / weight_sum, result.g / weight_sum, result.b / weight_sum);   // float /= float
+        return result / weight_sum;                                                                        // Color /= float: times 1 / s
+    }
+    return image_texel(sc, im, level, (int)s, (int)t, mode);
+}
+Col mip_lookup(const orc_scene* sc, const gbl_image& im, bool is_float, const TexCoord& tc, uint32_t filter, uint32_t mode, float max_aniso) {   // :78-97
+    if (filter == GBL_IMAGE_FILTER_BILINEAR) {
+        float width = std::max(std::max(std::fabs(tc.dsdx), std::fabs(tc.dtdx)), std::max(std::fabs(tc.dsdy), std::fabs(tc.dtdy)));
+        float level = static_cast<int>(im.levels) - 1 + log2f(std::max(width, 1e-8f));
+        return mip_level(sc, im, floor_int(level + 0.5f), tc.s, tc.t, mode);
+    }
+    if (filter == GBL_IMAGE_FILTER_TRILINEAR) {
+        float width = std::max(std::max(std::fabs(tc.dsdx), std::fabs(tc.dtdx)), std::max(std::fabs(tc.dsdy), std::fabs(tc.dtdy)));
+        return mip_trilinear(sc, im, tc.s, tc.t, width, mode);
+    }
+    if (filter == GBL_IMAGE_FILTER_EWA) {   // lookupEWA, :129-179
+        float ds0 = tc.dsdx, dt0 = tc.dtdx, ds1 = tc.dsdy, dt1 = tc.dtdy;
+        float major = sqrtf(ds0 * ds0 + dt0 * dt0), minor = sqrtf(ds1 * ds1 + dt1 * dt1);
+        if (major < minor) {
+            std::swap(ds0, ds1);
+            std::swap(dt0, dt1);
+            std::swap(major, minor);
+        }
+        if (minor * max_aniso < major && minor > 0.0f) {
+            float scale = major / (minor * max_aniso);
+            minor *= scale;
+            ds1 *= scale;
+            dt1 *= scale;
+        }
+        float A = dt0 * dt0 + dt1 * dt1;
+        float B = -2.0f * (ds0 * dt0 + ds1 * dt1);
+        float C = ds0 * ds0 + ds1 * ds1;
+        float F = A * C - 0.25f * B * B;
+        if (minor == 0.0f || F <= 0.0f) return mip_trilinear(sc, im, tc.s, tc.t, minor, mode);
+        float inv_f = 1.0f / F;
+        A *= inv_f;
+        B *= inv_f;
+        C *= inv_f;
+        int levels = static_cast<int>(im.levels);
+        float level = levels - 1 + log2f(minor);
+        int il = floor_int(level);
+        if (il < 0) return mip_level(sc, im, 0, tc.s, tc.t, mode);
+        if (il >= levels - 1) return mip_level(sc, im, levels - 1, tc.s, tc.t, mode);
+        float delta = level - (float)il;
+        return (1.0f - delta) * mip_ewa_level(sc, im, is_float, il, tc.s, tc.t, A, B, C, mode) +
+               (delta)*mip_ewa_level(sc, im, is_float, il + 1, tc.s, tc.t, A, B, C, mode);
+    }
+    return mip_level(sc, im, 0, tc.s, tc.t, mode);   // FilterNone: lookupNearest = the bilinear lookup of level 0 (:99-102)
+}
+
 // Texture<T>::lookup for T = Color (is_float == 0) and T = float (value in .r)
 Col tex_lookup(const orc_scene* sc, int id, const Frag& f) {
     const gbl_texture& g = sc->textures[id];
+    if (g.type == GBL_TEX_IMAGE) {   // ImageTexture<T>::lookup, :452-456
+        TexCoord tc = tex_map(sc, id, f);
+        return mip_lookup(sc, sc->images[g.image], g.is_float != 0, tc, g.image_filter, g.address, g.max_anisotropy);
+    }
     if (g.type == GBL_TEX_CONSTANT) return g.is_float ? Col(g.value[0], g.value[0], g.value[0]) : Col(g.value[0], g.value[1], g.value[2]);
     if (g.type == GBL_TEX_SCALE) {   // mScale->lookup(f) * mTexture->lookup(f), :421-425
         float sc_v = tex_lookup(sc, g.child[1], f).r;
@@ -1761,6 +1973,22 @@ Col light_sample(const orc_scene* s, int li, V3 p, float epsilon, float u_comp, 
         shadow->maxt = length(ps - p) - epsilon;
         return dot(ns, -*wi) > 0.0f ? l.color : BLACK;   // AreaLight::L, :368-371
     }
+    if (l.type == GBL_LIGHT_IBL) {   // ImageBasedLight::sampleL, :529-555
+        float pdf_row, pdf_col;
+        int row;
+        float v = s->ibl_marginal[li].sample_continuous(u2, &pdf_row, &row);   // CDF2D::sampleContinuous, GoblinSampler.cpp:378-390
+        float u = s->ibl_rows[li][row].sample_continuous(u1, &pdf_col, nullptr);
+        float pdf_st = pdf_row * pdf_col;
+        float theta = v * PI, phi = u * TWO_PI;
+        float cos_theta = std::cos(theta), sin_theta = std::sin(theta), cos_phi = std::cos(phi), sin_phi = std::sin(phi);
+        *wi = l.xf.on_vector(V3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+        *pdf = pdf_st / (TWO_PI * PI * sin_theta);   // (the sinTheta == 0 guard before it is overwritten)
+        shadow->o = p;
+        shadow->d = *wi;
+        shadow->mint = epsilon;
+        shadow->maxt = INF;
+        return mip_level(s, s->images[l.image], 0, u, v, GBL_ADDRESS_REPEAT);
+    }
     if (l.type == GBL_LIGHT_DIRECTIONAL) {   // DirectionalLight::sampleL, :145-154 (maxt stays the Ray default)
         *wi = -l.spot_axis;
         *pdf = 1.0f;
@@ -1782,12 +2010,49 @@ Col light_sample(const orc_scene* s, int li, V3 p, float epsilon, float u_comp, 
     if (l.type == GBL_LIGHT_SPOT) return spot_falloff(l, -(*wi)) * l.color / d2;
     return l.color / d2;
 }
+inline float spherical_theta(V3 v) { return std::acos(std::min(std::max(v.z, -1.0f), 1.0f)); }   // GoblinUtils.h:142-149
+inline float spherical_phi(V3 v) {
+    float phi = std::atan2(v.y, v.x);
+    return phi < 0.0f ? phi + TWO_PI : phi;
+}
 float light_pdf(const orc_scene* s, int li, V3 p, V3 wi) {   // Light::pdf default 0 ; AreaLight::pdf :457-461
     const Light& l = s->lights[li];
+    if (l.type == GBL_LIGHT_IBL) {   // ImageBasedLight::pdf, :615-628 ; CDF2D::pdf, GoblinSampler.cpp:392-405
+        V3 w = l.xf.invert_vector(wi);
+        float theta = spherical_theta(w);
+        float sin_theta = std::sin(theta);
+        if (sin_theta == 0.0f) return 0.0f;
+        float phi = spherical_phi(w);
+        float u = phi * INV_TWOPI, v = theta * INV_PI;
+        const Cdf& mg = s->ibl_marginal[li];
+        int rows = static_cast<int>(mg.f.size());
+        int row = std::min(std::max(floor_int(rows * v), 0), rows - 1);
+        const Cdf& rw = s->ibl_rows[li][row];
+        int cols = static_cast<int>(rw.f.size());
+        int col = std::min(std::max(floor_int(cols * u), 0), cols - 1);
+        float integral = mg.integral * rw.integral;
+        if (integral == 0.0f) return 0.0f;
+        float pdf = mg.f[row] * rw.f[col] / integral;
+        return pdf / (TWO_PI * PI * sin_theta);
+    }
     if (l.type != GBL_LIGHT_AREA) return 0.0f;
     return geoset_pdf(s, l, l.xf.invert_point(p), l.xf.invert_vector(wi));
 }
-inline bool light_is_delta(const Light& l) { return l.type != GBL_LIGHT_AREA; }
+inline bool light_is_delta(const Light& l) { return l.type != GBL_LIGHT_AREA && l.type != GBL_LIGHT_IBL; }   // GoblinLight.h:116, :296, :346
+// light->Le(ray): Black but for an image based light (GoblinLight.h:76, GoblinLight.cpp:520-527)
+Col light_le_escaped(const orc_scene* s, int li, V3 dir) {
+    const Light& l = s->lights[li];
+    if (l.type != GBL_LIGHT_IBL) return BLACK;
+    V3 w = l.xf.invert_vector(dir);
+    float theta = spherical_theta(w), phi = spherical_phi(w);
+    return mip_level(s, s->images[l.image], 0, phi * INV_TWOPI, theta * INV_PI, GBL_ADDRESS_REPEAT);
+}
+// Scene::evalEnvironmentLight, GoblinScene.cpp:89-95
+Col environment_le(const orc_scene* s, V3 dir) {
+    Col L(0.0f);
+    for (size_t i = 0; i < s->lights.size(); ++i) L += light_le_escaped(s, static_cast<int>(i), dir);
+    return L;
+}
 
 // Intersection::Le, GoblinPrimitive.cpp:8-14
 Col hit_Le(const orc_scene* s, const Hit& h, V3 out_dir) {
@@ -2378,7 +2643,10 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
     hit.frag.dpdv = V3(0, 0, 0);
     const bool primary_hit = scene_intersect(s, ray, &hit, &c->cnt);
     c->primary_maxt = ray.maxt;
-    if (!primary_hit) return Li;   // no IBL lights on this path: evalEnvironmentLight = 0
+    if (!primary_hit) {   // get image based lighting if the ray didn't hit anything (:61-65)
+        Li += environment_le(s, ray.d);
+        return Li;
+    }
     Li += hit_Le(s, hit, -ray.d);
     Li += l_subsurface(c, hit, -ray.d, rec);   // :69 -- before computeUVDifferential, so its lookups see zero differentials
     Ray cur = ray;
@@ -2452,6 +2720,8 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
                 if (lhit && s->instances[lh.instance].area_light == light) {
                     Col Le = hit_Le(s, lh, -wi);
                     if (Le != BLACK) Ld += f * tr * Le * absdot(wi, n) * fw / bsdf_pdf;
+                } else if (!lhit) {
+                    Ld += f * tr * light_le_escaped(s, light, r.d) * fw / bsdf_pdf;   // the radiance contribution from IBL (:157-161)
                 }
                 Li += throughput * Ld / pick_pdf;
                 throughput *= f * absdot(wi, n) / bsdf_pdf;
@@ -2477,7 +2747,7 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
             } else {
                 draw_bsdf_sample(c);
                 Col tr = eval_attenuation(c, r);
-                (void)tr;   // light->Le(r) is Black for every light on this path (IBL only)
+                Ld += f * tr * light_le_escaped(s, light, r.d) * fw / bsdf_pdf;   // the radiance contribution from IBL (:157-161)
             }
             Li += throughput * Ld / pick_pdf;
             throughput *= f * absdot(wi, n) / bsdf_pdf;
@@ -2584,7 +2854,9 @@ Col estimate_ld(LiCtx* c, V3 wo, float epsilon, const Hit& hit, const ResolvedMa
                 Col Le = hit_Le(s, lh, -wi);
                 if (Le != BLACK) Ld += f * Le * absdot(wi, n) * fw / bsdf_pdf;
             }
-        }   // else: light->Le(r) is Black for every light on this path (IBL only)
+        } else {
+            Ld += f * light_le_escaped(s, light, r.d) * fw / bsdf_pdf;   // the radiance contribution from IBL (GoblinRenderer.cpp:558-561)
+        }
     }
     return Ld;
 }
@@ -2622,7 +2894,10 @@ Col whitted_li(LiCtx* c, const Ray& ray_in, const float* rec, const RayDiff* dif
     hit.frag.dpdv = V3(0, 0, 0);
     const bool primary_hit = scene_intersect(s, ray, &hit, &c->cnt);
     if (depth == 0) c->primary_maxt = ray.maxt;
-    if (!primary_hit) return Li;   // evalEnvironmentLight = 0 on this path
+    if (!primary_hit) {   // get image based lighting if the ray didn't hit anything (GoblinWhitted.cpp:40-43)
+        Li += environment_le(s, ray.d);
+        return Li;
+    }
     compute_uv_differential(&hit.frag, diff);
     Li += hit_Le(s, hit, -ray.d);
     // Lsubsurface with the fragment's differentials in place (GoblinWhitted.cpp:22-27: after computeUVDifferential, at every

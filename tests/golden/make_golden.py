@@ -119,6 +119,12 @@ CASES = {
     # mask materials under the Whitted renderer: opaque to every query; the BSDFnullptr lobe only shows up in estimateLd's
     # BSDF sample (straight through, towards an area light); masked mirror / glass answer the specular requests times alpha
     "masked_whitted": ("masked", ov((48, 48), 4, 3, method="whitted"), 1024, False),
+    # SURVEY 8f rank 3, the last of it: image textures (MIPMap: nearest / bilinear / trilinear / EWA, repeat / clamp / border,
+    # gamma, channel picks, uv and spherical mapping, colour and float formats) and the image based light (Le of escaping
+    # rays, sampleL through its CDF2D, pdf, the two IBL branches of PathTracer::Li; estimateLd's under Whitted)
+    "imagetex_pt": ("imagetex", ov((64, 64), 9, 5), 2048, False),
+    "ibl_pt": ("ibl", ov((64, 64), 9, 5), 2048, False),
+    "ibl_whitted": ("ibl", ov((48, 48), 4, 3, method="whitted"), 1024, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }
 
@@ -129,9 +135,10 @@ def absolute_scene(scene, overrides, path):
         doc = json.load(f)
     gs._merge(doc, overrides)
     doc.setdefault("render_setting", {})["thread_num"] = 1
-    for g in doc.get("geometries", []):
-        if "file" in g:
-            g["file"] = os.path.join(os.path.dirname(src), g["file"])
+    for section in ("geometries", "textures", "lights"):   # meshes, image textures, environment maps
+        for g in doc.get(section, []):
+            if "file" in g:
+                g["file"] = os.path.join(os.path.dirname(src), g["file"])
     with open(path, "w") as f:
         json.dump(doc, f)
 

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_ctypes_mirror_has_the_c_layout(tmp_path):
-    structs = ["gbl_trs", "gbl_mesh", "gbl_material", "gbl_instance", "gbl_light", "gbl_camera", "gbl_film", "gbl_volume",
+    structs = ["gbl_trs", "gbl_mesh", "gbl_texture", "gbl_image", "gbl_material", "gbl_instance", "gbl_light", "gbl_camera", "gbl_film", "gbl_volume",
                "gbl_render_setting", "gbl_scene_desc", "gbl_render_params", "gbl_stats", "gbl_info"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "goblin_hip.h"\nint main(void){\n' +
