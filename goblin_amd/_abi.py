@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: 
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM", 6: "GBL_ERR_INTERNAL"}
 
 GBL_MAT_LAMBERT, GBL_MAT_BLINN, GBL_MAT_TRANSPARENT, GBL_MAT_MIRROR = range(4)
-GBL_LIGHT_POINT, GBL_LIGHT_DIRECTIONAL, GBL_LIGHT_SPOT, GBL_LIGHT_AREA = 0, 1, 2, 3
+GBL_LIGHT_POINT, GBL_LIGHT_DIRECTIONAL, GBL_LIGHT_SPOT, GBL_LIGHT_AREA, GBL_LIGHT_IBL = 0, 1, 2, 3, 4
 GBL_SHAPE_MESH, GBL_SHAPE_SPHERE, GBL_SHAPE_DISK = 0, 1, 2
 GBL_CAMERA_PERSPECTIVE, GBL_CAMERA_ORTHOGRAPHIC = 0, 1
 GBL_FILTER_BOX, GBL_FILTER_TRIANGLE, GBL_FILTER_GAUSSIAN, GBL_FILTER_MITCHELL = range(4)

@@ -464,6 +464,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     if ((st = upload(ctx, packed.ewa_lut, &sc.ewa_lut)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.ibl_dist, &sc.ibl_dist)) != GBL_OK) return bail(st);
     sc.has_ibl = packed.has_ibl;
+    ctx->has_images = desc->num_images > 0;
     sc.tlas_root = packed.tlas_root;
     sc.num_instances = static_cast<int32_t>(packed.instances.size());
     sc.num_lights = static_cast<int32_t>(packed.lights.size());
@@ -816,8 +817,12 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         return GBL_ERR_UNSUPPORTED;
     }
     bool wavepool = p->schedule == GBL_SCHEDULE_WAVEPOOL;
-    if (wavepool && (!wf_capable || stream_mode || sc.has_masks)) {
-        ctx->error = "the wave-pool schedule covers the path tracer on mask-free scenes under the native and replay samplers";
+    // (image textures / image based lights: their MIPMap lookups are out-of-line calls (kernels/image.h), and the lean
+    //  native instantiation of the wave-pool kernel came out with different radiance on imagetex.json -- 14 % of the samples
+    //  -- while its replay and instrumented instantiations, and every other schedule, match the oracle; until that is
+    //  understood the schedule refuses such scenes rather than render them differently)
+    if (wavepool && (!wf_capable || stream_mode || sc.has_masks || ctx->has_images)) {
+        ctx->error = "the wave-pool schedule covers the path tracer on scenes without mask materials, image textures or image based lights, under the native and replay samplers";
         return GBL_ERR_UNSUPPORTED;
     }
     // the wave-pool kernel writes per-sample radiance only (no LDS film tile): a call whose radiance buffer exceeds the

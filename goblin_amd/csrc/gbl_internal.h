@@ -59,6 +59,7 @@ struct gbl_ctx {
     uint32_t tlas_capacity = 0;
     int blas_depth = 0;
     bool has_directional = false;
+    bool has_images = false;     // the scene holds MIP pyramids (image textures / image based lights)
     uint32_t* wf_host_flags = nullptr;   // pinned
     // ring of event triples for gbl_get_timings
     static const int kTimingRing = 64;

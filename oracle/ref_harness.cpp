@@ -43,6 +43,7 @@
 #include "GoblinRenderer.h"
 #include "GoblinSampler.h"
 #include "GoblinScene.h"
+#include "GoblinTexture.h"
 #include "GoblinThreadLocalStorage.h"
 #include "GoblinThreadPool.h"
 #include "GoblinWhitted.h"
@@ -235,6 +236,23 @@ static int image_mode(int argc, char** argv) {
         printf("{\"mode\": \"imageload\", \"width\": %d, \"height\": %d}\n", w, h);
         return 0;
     }
+    if (mode == "mipmap") {   // mipmap <file.exr> <out.f32>: MIPMap<Color>'s levels, level 0 first, each row-major float4
+        int w = 0, h = 0;
+        Color* c = loadImage(argv[2], &w, &h);
+        if (!c) return 1;
+        Color* copy = new Color[static_cast<size_t>(w) * h];
+        memcpy(copy, c, sizeof(Color) * static_cast<size_t>(w) * h);
+        MIPMap<Color> mip(copy, w, h);
+        std::vector<float> all;
+        for (int l = 0; l < mip.getLevelsNum(); ++l) {
+            const ImageBuffer<Color>* b = mip.getImageBuffer(l);
+            const float* p = reinterpret_cast<const float*>(b->image);
+            all.insert(all.end(), p, p + 4 * static_cast<size_t>(b->width) * b->height);
+        }
+        write_f32(argv[3], all);
+        printf("{\"mode\": \"mipmap\", \"width\": %d, \"height\": %d, \"levels\": %d}\n", mip.getWidth(), mip.getHeight(), mip.getLevelsNum());
+        return 0;
+    }
     if (argc < 8) return 2;
     const int w = atoi(argv[3]), h = atoi(argv[4]);
     const std::string prefix = argv[5];
@@ -271,7 +289,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s film|li|kat|time <scene.json> ... | image <in.f32> <w> <h> <prefix> <radius> <weight> | imageload <file.exr> <out.f32>\n", argv[0]);
         return 2;
     }
-    if (!strcmp(argv[1], "image") || !strcmp(argv[1], "imageload")) return image_mode(argc, argv);
+    if (!strcmp(argv[1], "image") || !strcmp(argv[1], "imageload") || !strcmp(argv[1], "mipmap")) return image_mode(argc, argv);
     std::string mode = argv[1], scene_path = argv[2];
     // the loader echoes every parsed parameter to stdout; keep stdout for our JSON line
     FILE* real_stdout = fdopen(dup(fileno(stdout)), "w");

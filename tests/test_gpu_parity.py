@@ -46,9 +46,10 @@ def schedule(request):
 
 
 def scene_has_masks(scene):
-    """Materials whose type carries BSDFnullptr: masks, and subsurface materials (BSDFAll) -- DevScene::has_masks."""
+    """What the wave-pool kernel refuses: materials whose type carries BSDFnullptr -- masks, and subsurface materials
+    (BSDFAll), DevScene::has_masks -- and scenes with image textures / image based lights."""
     d = scene.desc
-    return any(d.materials[i].type in (_abi.GBL_MAT_MASK, _abi.GBL_MAT_SUBSURFACE) for i in range(d.num_materials))
+    return d.num_images > 0 or any(d.materials[i].type in (_abi.GBL_MAT_MASK, _abi.GBL_MAT_SUBSURFACE) for i in range(d.num_materials))
 
 
 class _Scheduled:
@@ -63,7 +64,7 @@ class _Scheduled:
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
         if self._schedule == "wavepool" and s.integrator == _abi.GBL_INTEGRATOR_PATH and scene_has_masks(self._t.scene):
-            pytest.skip("mask scenes stay on the megakernel / wavefront schedules (the wave-pool kernel refuses them)")
+            pytest.skip("the wave-pool kernel refuses this scene (masks / subsurface / images): megakernel and wavefront cover it")
         kw.setdefault("schedule", "auto" if s.integrator != _abi.GBL_INTEGRATOR_PATH else self._schedule)
         return self._t.render(**kw)
 
@@ -85,7 +86,8 @@ def fake_window(full, n_pixels):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "bunny_vn_box",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted"])
+                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
+                                  "imagetex_pt", "ibl_pt", "ibl_whitted"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -114,7 +116,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted"])
+                                  "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted", "imagetex_pt", "ibl_pt", "ibl_whitted"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -122,7 +124,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
     scene = gs.load_scene(meta["scene"], meta["overrides"])
     o = ob.Oracle(scene)
     res = o.render(threads=1, want_samples=True)
-    np.testing.assert_allclose(res["film"], data["film"], rtol=1e-5, atol=1e-6)   # the oracle pin itself
+    np.testing.assert_allclose(res["film"], data["film"], rtol=1e-5, atol=1e-6)   # the oracle pin itself (tests/test_oracle_vs_reference.py)
     idx = helpers.tile_order_index(o.window(), meta["spp"])
     samples = res["samples"][idx]
     r = make_renderer(scene, schedule)
@@ -141,7 +143,8 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
-                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted"])
+                                  "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
+                                  "imagetex_pt", "ibl_pt", "ibl_whitted"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
     """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
     Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators
@@ -260,6 +263,9 @@ def test_stream_mode_shards_and_windows(torch):
     ("masked", gs.config_overrides(resolution=(40, 40), spp=9, depth=6)),
     ("whitted", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
     ("subsurface", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
+    ("imagetex", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
+    ("ibl", gs.config_overrides(resolution=(40, 40), spp=9, depth=5)),
+    ("ibl", gs.config_overrides(resolution=(32, 32), spp=9, depth=3, method="whitted")),
     ("subsurface", gs.config_overrides(resolution=(32, 32), spp=9, depth=3, method="whitted")),
     ("masked", gs.config_overrides(resolution=(32, 32), spp=9, depth=3, method="whitted")),
     ("subsurface", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=4),

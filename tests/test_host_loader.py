@@ -75,14 +75,55 @@ def test_render_methods():
 def test_out_of_scope_features_fail_loudly():
     cases = [
         minimal(volume={"type": "heterogeneous", "density_grid": "x.vol"}),
-        minimal(lights=[{"type": "ibl", "name": "e", "file": "x.exr"}]),
         minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
-        minimal(textures=[{"name": "w", "type": "image", "file": "x.png"}]),
     ]
     for doc in cases:
         with pytest.raises(_abi.GoblinError) as e:
             load(doc)
         assert e.value.status == _abi.GBL_ERR_UNSUPPORTED, doc
+
+
+def test_image_textures_and_image_based_light():
+    """getImageTextureParams (GoblinTexture.cpp:677-732) and createImageBasedLight (GoblinLight.cpp:681-691): defaults,
+    fallbacks, the pyramid MIPMap's constructor builds (48 x 32 -> 64 x 32, 7 levels), per-format texel layout, the cache."""
+    tex = [{"format": "color", "name": "w", "type": "image", "file": "images/tiles.exr"},
+           {"format": "color", "name": "w2", "type": "image", "file": "images/tiles.exr", "filter": "EWA", "address": "border", "scale": [2.0, 3.0],
+            "max_anisotropy": 4.0},
+           {"format": "float", "name": "e", "type": "image", "file": "images/tiles.exr", "filter": "trilinear", "address": "clamp", "channel": "B",
+            "gamma": 2.0, "max_anisotropy": 4.0},
+           {"format": "float", "name": "odd", "type": "image", "file": "images/tiles.exr", "filter": "sharp", "address": "mirror", "channel": "luma"}]
+    mats = [{"name": "m", "type": "blinn", "Kg": "w", "exponent": "e"}, {"name": "m2", "type": "blinn", "Kg": "w2", "exponent": "odd"}]
+    prims = [{"type": "model", "name": "mq", "geometry": "q", "material": "m"}, {"type": "instance", "name": "i0", "model": "mq"},
+             {"type": "model", "name": "mq2", "geometry": "q", "material": "m2"}, {"type": "instance", "name": "i1", "model": "mq2"}]
+    s = load(minimal(textures=tex, materials=mats, primitives=prims,
+                     lights=[{"type": "ibl", "name": "sky", "file": "images/env.exr", "filter": [1.0, 0.5, 0.25], "sample_num": 4},
+                             {"type": "ibl", "name": "dark", "file": "images/env.exr"}]))
+    d = s.desc
+    by_mat = {i: d.materials[d.instances[i].material] for i in range(2)}
+    w, e = d.textures[by_mat[0].tex_color], d.textures[by_mat[0].tex_exponent]
+    w2, odd = d.textures[by_mat[1].tex_color], d.textures[by_mat[1].tex_exponent]
+    assert w.type == _abi.GBL_TEX_IMAGE and (w.image_filter, w.address, w.mapping) == (_abi.GBL_IMAGE_FILTER_NONE, _abi.GBL_ADDRESS_REPEAT, _abi.GBL_MAP_UV)
+    assert (w2.image_filter, w2.address) == (_abi.GBL_IMAGE_FILTER_EWA, _abi.GBL_ADDRESS_BORDER) and list(w2.uv_scale) == [2.0, 3.0]
+    assert w2.max_anisotropy == 10.0 and e.max_anisotropy == 4.0     # createColorImageTexture does not forward it (:741-745)
+    assert w2.image == w.image                                        # same file, gamma, channel: one MIPMap (ImageTexture::imageCache)
+    assert (e.image_filter, e.address, e.is_float) == (_abi.GBL_IMAGE_FILTER_TRILINEAR, _abi.GBL_ADDRESS_CLAMP, 1)
+    assert (odd.image_filter, odd.address) == (_abi.GBL_IMAGE_FILTER_NONE, _abi.GBL_ADDRESS_REPEAT)   # unrecognised strings fall back
+    img, fimg = d.images[w.image], d.images[e.image]
+    assert (img.width, img.height, img.levels, img.channels) == (64, 32, 7, 4) and (fimg.width, fimg.height, fimg.levels, fimg.channels) == (64, 32, 7, 1)
+    texels = np.ctypeslib.as_array(d.texels, shape=(d.num_texels,))
+    n = sum(max(1, 64 >> l) * max(1, 32 >> l) for l in range(7))
+    assert fimg.texel_offset + n <= d.num_texels and img.texel_offset + 4 * n <= d.num_texels
+    src = _abi.read_image(os.path.join(MODELS, "images", "tiles.exr"))
+    assert src.shape == (32, 48, 4)                                   # not powers of two: resized up before level 0
+    assert d.num_lights == 2 and d.lights[0].type == _abi.GBL_LIGHT_IBL and d.lights[0].sample_num == 4 and d.lights[1].sample_num == 1
+    assert list(d.lights[0].color) == [1.0, 0.5, 0.25] and list(d.lights[1].color) == [0.0, 0.0, 0.0]   # "filter" defaults to black
+    sky = d.images[d.lights[0].image]
+    env = _abi.read_image(os.path.join(MODELS, "images", "env.exr"))
+    lvl0 = texels[sky.texel_offset:sky.texel_offset + 4 * 64 * 32].reshape(32, 64, 4)
+    np.testing.assert_array_equal(lvl0[..., :3], env[..., :3] * np.array([1.0, 0.5, 0.25], np.float32))   # buffer[i] *= filter
+    with pytest.raises(_abi.GoblinError) as err:   # a missing image is an error here (the reference renders magenta)
+        load(minimal(textures=[{"format": "color", "name": "w", "type": "image", "file": "images/none.exr"}]))
+    assert err.value.status == _abi.GBL_ERR_IO
 
 
 def test_shapes_cameras_and_directional_light():
