@@ -19,6 +19,9 @@
 #ifndef GBL_PT_WAVES
 #define GBL_PT_WAVES 3
 #endif
+#ifndef GBL_EXT_WAVES
+#define GBL_EXT_WAVES 2         // waves per SIMD the EXT instantiations of the persistent kernels are compiled for (256 registers)
+#endif
 #define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
 #define GBL_STREAM_LDS_WORDS 640   // GBL_SAMPLES_STREAM: 624 mt19937 state words + cursor, padded (kernels/stream.h)
 #define GBL_WHITTED_MAX_DEPTH 12   // frames of the Whitted kernel's explicit recursion (kernels/whitted.h)

@@ -1099,6 +1099,14 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             ctx->error = "GBL_SAMPLES_STREAM keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
         }
+        if (!wavepool) {
+            // the persistent grid is what is resident: registers may allow fewer workgroups per CU than LDS does (EXT builds)
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kernel), GBL_BLOCK, lds) == hipSuccess && occ >= 1) {
+                grid64 = std::max<uint64_t>(1, std::min<uint64_t>(grid64, static_cast<uint64_t>(ctx->num_cus) * occ));
+                if (!stream_mode) grid = dim3(static_cast<unsigned>(grid64));   // (stream mode sized its scratch for the original grid)
+            }
+        }
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(tev[1], stream));

@@ -18,11 +18,25 @@
 
 #define GBL_EWA_LUT_SIZE 128
 
+// What the lookups read of the scene, BY VALUE: the out-of-line functions below must not take `const DevScene&` -- that
+// would force the kernel's argument block into per-lane scratch and turn every scene pointer load of the whole kernel
+// into a scratch access (measured: the EXT kernels ran 1.5x slower on scenes without a single image).
+struct ImgCtx {
+    const float* texels;
+    const float* ewa_lut;
+    const DevImage* images;
+    const float* ibl_dist;
+};
+__device__ __forceinline__ ImgCtx img_ctx(const DevScene& sc) {
+    ImgCtx c = {sc.texels, sc.ewa_lut, sc.images, sc.ibl_dist};
+    return c;
+}
+
 __device__ __forceinline__ int img_floor(float f) { return static_cast<int>(floorf(f)); }
 __device__ __forceinline__ int img_ceil(float f) { return static_cast<int>(ceilf(f)); }
 
 // ImageBuffer<T>::texel of level `level`
-__device__ __forceinline__ F3 image_texel(const DevScene& sc, const DevImage& im, int level, int s, int t, uint32_t mode) {
+__device__ __forceinline__ F3 image_texel(const ImgCtx sc, const DevImage& im, int level, int s, int t, uint32_t mode) {
     const int w = max(1, static_cast<int>(im.width >> level)), h = max(1, static_cast<int>(im.height >> level));
     if (mode == 1u) {   // AddressClamp, as written: t is clamped from s
         s = min(max(s, 0), w - 1);
@@ -45,7 +59,7 @@ __device__ __forceinline__ F3 image_texel(const DevScene& sc, const DevImage& im
 }
 
 // MIPMap<T>::lookup(level, s, t, m)
-__device__ __forceinline__ F3 mip_level(const DevScene& sc, const DevImage& im, int level, float s, float t, uint32_t mode) {
+__device__ __forceinline__ F3 mip_level(const ImgCtx sc, const DevImage& im, int level, float s, float t, uint32_t mode) {
     level = min(max(level, 0), static_cast<int>(im.levels) - 1);
     const int w = max(1, static_cast<int>(im.width >> level)), h = max(1, static_cast<int>(im.height >> level));
     const float s_res = s * w - 0.5f, t_res = t * h - 0.5f;
@@ -55,7 +69,7 @@ __device__ __forceinline__ F3 mip_level(const DevScene& sc, const DevImage& im, 
            (1.0f - ds) * (dt)*image_texel(sc, im, level, s0, t0 + 1, mode) + (ds) * (dt)*image_texel(sc, im, level, s0 + 1, t0 + 1, mode);
 }
 
-__device__ __forceinline__ F3 mip_trilinear(const DevScene& sc, const DevImage& im, float s, float t, float width, uint32_t mode) {
+__device__ __forceinline__ F3 mip_trilinear(const ImgCtx sc, const DevImage& im, float s, float t, float width, uint32_t mode) {
     const int levels = static_cast<int>(im.levels);
     const float level = levels - 1 + log2f(fmaxf(width, 1e-8f));
     const int il = img_floor(level);
@@ -66,7 +80,7 @@ __device__ __forceinline__ F3 mip_trilinear(const DevScene& sc, const DevImage& 
 }
 
 // MIPMap<T>::EWA
-__device__ __forceinline__ F3 mip_ewa_level(const DevScene& sc, const DevImage& im, bool is_float, int level, float s, float t, float A, float B, float C,
+__device__ __forceinline__ F3 mip_ewa_level(const ImgCtx sc, const DevImage& im, bool is_float, int level, float s, float t, float A, float B, float C,
                                    uint32_t mode) {
     const int w = max(1, static_cast<int>(im.width >> level)), h = max(1, static_cast<int>(im.height >> level));
     const float s_res = static_cast<float>(w), t_res = static_cast<float>(h);
@@ -109,7 +123,8 @@ struct TexCoord {
 // MIPMap<T>::lookup(tc, filter, address).  Out of line on purpose: a material evaluates up to four texture slots, each a
 // graph two levels deep, in every kernel -- inlined, the EWA loops multiplied the kernels' code (and the build time) many
 // times over for a path only image-textured scenes take.
-__device__ __attribute__((noinline)) F3 mip_lookup(const DevScene& sc, const DevImage& im, bool is_float, const TexCoord& tc, uint32_t filter, uint32_t mode, float max_aniso) {
+__device__ __attribute__((noinline)) F3 mip_lookup(const ImgCtx sc, const DevImage* imp, bool is_float, const TexCoord tc, uint32_t filter, uint32_t mode, float max_aniso) {
+    const DevImage& im = *imp;
     if (filter == 1u) {   // bilinear: one level, rounded
         const float width = fmaxf(fmaxf(fabsf(tc.dsdx), fabsf(tc.dtdx)), fmaxf(fabsf(tc.dsdy), fabsf(tc.dtdy)));
         const float level = static_cast<int>(im.levels) - 1 + log2f(fmaxf(width, 1e-8f));
@@ -176,8 +191,8 @@ __device__ __forceinline__ float cdf1d_sample(const float* cdf, const float* fun
 
 // layout of an IBL's distribution in DevScene::ibl_dist (floats), W x H = the level the reference builds it from:
 //   marginal: func[H], cdf[H + 1], integral        rows r: func[W], cdf[W + 1], integral
-__device__ __forceinline__ const float* ibl_marginal(const DevScene& sc, const DevLight& l) { return sc.ibl_dist + l.dist_offset; }
-__device__ __forceinline__ const float* ibl_row(const DevScene& sc, const DevLight& l, int row) {
+__device__ __forceinline__ const float* ibl_marginal(const ImgCtx sc, const DevLight& l) { return sc.ibl_dist + l.dist_offset; }
+__device__ __forceinline__ const float* ibl_row(const ImgCtx sc, const DevLight& l, int row) {
     return sc.ibl_dist + l.dist_offset + (2 * l.dist_h + 2) + static_cast<size_t>(row) * (2 * l.dist_w + 2);
 }
 
@@ -188,14 +203,20 @@ __device__ __forceinline__ float spherical_phi(F3 v) {
 }
 
 // ImageBasedLight::Le(ray): mRadiance->lookup(0, phi / 2pi, theta / pi) of the direction in the light's frame
-__device__ __attribute__((noinline)) F3 ibl_le(const DevScene& sc, const DevLight& l, F3 dir) {
+__device__ __attribute__((noinline)) F3 ibl_le(const ImgCtx sc, const DevLight* lp, F3 dir) {
+    const DevLight& l = *lp;
     const F3 w = xf_vector(l.inv, dir);
     const float s = spherical_phi(w) * GBL_INV_TWOPI, t = spherical_theta(w) * GBL_INV_PI;
     return mip_level(sc, sc.images[l.image], 0, s, t, 0u);
 }
 
 // ImageBasedLight::sampleL
-__device__ __attribute__((noinline)) F3 ibl_sample(const DevScene& sc, const DevLight& l, float u1, float u2, F3* wi, float* pdf) {
+__device__ __attribute__((noinline)) float4 ibl_sample(const ImgCtx sc, const DevLight* lp, float u1, float u2, F3* wi_out) {
+    const DevLight& l = *lp;
+    F3 wi_v;
+    float pdf_v;
+    F3* wi = &wi_v;
+    float* pdf = &pdf_v;
     const float* mg = ibl_marginal(sc, l);
     float pdf_row, pdf_col;
     int row, col;
@@ -207,11 +228,14 @@ __device__ __attribute__((noinline)) F3 ibl_sample(const DevScene& sc, const Dev
     const float cos_theta = gbl_cosf(theta), sin_theta = gbl_sinf(theta), cos_phi = gbl_cosf(phi), sin_phi = gbl_sinf(phi);
     *wi = xf_vector(l.m, f3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
     *pdf = pdf_st / (GBL_TWO_PI * GBL_PI * sin_theta);   // (the sinTheta == 0 guard above it is overwritten, :540-543)
-    return mip_level(sc, sc.images[l.image], 0, u, v, 0u);
+    const F3 L = mip_level(sc, sc.images[l.image], 0, u, v, 0u);
+    *wi_out = wi_v;
+    return make_float4(L.x, L.y, L.z, pdf_v);   // radiance, pdf
 }
 
 // ImageBasedLight::pdf
-__device__ __attribute__((noinline)) float ibl_pdf(const DevScene& sc, const DevLight& l, F3 wi) {
+__device__ __attribute__((noinline)) float ibl_pdf(const ImgCtx sc, const DevLight* lp, F3 wi) {
+    const DevLight& l = *lp;
     const F3 w = xf_vector(l.inv, wi);
     const float theta = spherical_theta(w);
     const float sin_theta = gbl_sinf(theta);

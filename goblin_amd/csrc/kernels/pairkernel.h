@@ -156,7 +156,9 @@ __device__ __forceinline__ void trace_pair(const DevScene& sc, bool has_shadow, 
 }
 
 template <bool REPLAY, bool STATS, bool EXT>
-__global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void pair_trace_kernel(DevScene sc, RenderArgs ra) {
+// (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
+//  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
+__global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void pair_trace_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(smem);
     uint32_t* stack = ctrl + 4;

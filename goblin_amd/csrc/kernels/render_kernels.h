@@ -336,7 +336,9 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 // STREAM (implies REPLAY): the records are the reference's own, generated per pixel from the tile's mt19937
 // (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
 template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false>
-__global__ __launch_bounds__(GBL_BLOCK, GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
+// (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
+//  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
+__global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);

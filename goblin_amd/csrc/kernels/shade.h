@@ -222,7 +222,7 @@ __device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& f
         if (g.type == 0u) return value;
         if (g.type == 3u) {   // ImageTexture<T>::lookup: map, then the MIPMap
             const TexCoord tc = tex_map(g, fr, tf);
-            return mip_lookup(sc, sc.images[g.image], g.is_float != 0u, tc, g.filter, g.address, g.max_aniso);
+            return mip_lookup(img_ctx(sc), sc.images + g.image, g.is_float != 0u, tc, g.filter, g.address, g.max_aniso);
         }
         const F3 a = tex_eval<DEPTH - 1>(sc, g.child[0], fr, tf);
         const F3 b = tex_eval<DEPTH - 1>(sc, g.child[1], fr, tf);
@@ -628,7 +628,9 @@ __device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight&
                                              float u2, LightSampleOut& o) {
     F3 color = f3(l.color[0], l.color[1], l.color[2]);
     if (EXT && l.type == GBL_LIGHT_IBL) {   // ImageBasedLight::sampleL, GoblinLight.cpp:529-555: the shadow ray has no far end
-        o.L = ibl_sample(sc, l, u1, u2, &o.wi, &o.pdf);
+        const float4 r = ibl_sample(img_ctx(sc), &l, u1, u2, &o.wi);
+        o.L = f3(r.x, r.y, r.z);
+        o.pdf = r.w;
         o.maxt = INFINITY;
         return;
     }
@@ -699,7 +701,7 @@ __device__ __forceinline__ void light_sample(const DevScene& sc, const DevLight&
 // light->pdf(p, wi): 0 for delta lights, AreaLight::pdf otherwise (wi is NOT renormalised in light space)
 template <bool EXT>
 __device__ __forceinline__ float light_pdf(const DevScene& sc, const DevLight& l, F3 p, F3 wi) {
-    if (EXT && l.type == GBL_LIGHT_IBL) return ibl_pdf(sc, l, wi);
+    if (EXT && l.type == GBL_LIGHT_IBL) return ibl_pdf(img_ctx(sc), &l, wi);
     if (l.type != GBL_LIGHT_AREA) return 0.0f;
     if (EXT && l.shape != 0u) return light_shape_pdf(l, xf_point(l.inv, p), xf_vector(l.inv, wi));
     return light_geoset_pdf(sc, l, xf_point(l.inv, p), xf_vector(l.inv, wi));
@@ -713,7 +715,7 @@ __device__ __forceinline__ bool light_is_delta(const DevLight& l) {
 // light->Le(ray) of a ray that left the scene: Black but for an image based light (GoblinLight.h:76, GoblinLight.cpp:520-527)
 template <bool EXT>
 __device__ __forceinline__ F3 light_le_escaped(const DevScene& sc, const DevLight& l, F3 dir) {
-    if (EXT && l.type == GBL_LIGHT_IBL) return ibl_le(sc, l, dir);
+    if (EXT && l.type == GBL_LIGHT_IBL) return ibl_le(img_ctx(sc), &l, dir);
     return f3(0.0f, 0.0f, 0.0f);
 }
 // Scene::evalEnvironmentLight (GoblinScene.cpp:89-95): the sum over every light

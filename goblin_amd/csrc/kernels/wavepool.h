@@ -98,7 +98,7 @@ __device__ __forceinline__ void wp_stu(uint4* p, uint4 v) {
 __device__ __forceinline__ uint32_t wp_bcast_first(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 
 template <bool REPLAY, bool STATS, bool EXT>
-__global__ __launch_bounds__(GBL_BLOCK, GBL_WP_WAVES) void wp_kernel(DevScene sc, RenderArgs ra) {
+__global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_WP_WAVES) void wp_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem);
     const LdsStack stk = {gbl_as_lds(lds + threadIdx.x)};
