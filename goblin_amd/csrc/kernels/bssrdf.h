@@ -24,7 +24,7 @@
 
 __device__ __forceinline__ F3 sss_div(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }   // Color / Color
 __device__ __forceinline__ F3 sss_sqrt(F3 c) { return f3(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z)); }
-__device__ __forceinline__ F3 sss_exp(F3 c) { return f3(expf(c.x), expf(c.y), expf(c.z)); }
+__device__ __forceinline__ F3 sss_exp(F3 c) { return f3(gbl_expf(c.x), gbl_expf(c.y), gbl_expf(c.z)); }
 __device__ __forceinline__ float sss_clamp0(float f) { return f < 0.0f ? 0.0f : (f > INFINITY ? INFINITY : f); }
 __device__ __forceinline__ float sss_luminance(F3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
 
@@ -58,7 +58,7 @@ __device__ __forceinline__ F3 bssrdf_rd(const DevMaterial& m, float d2) {
 __device__ __forceinline__ float phase_hg(F3 wi, F3 wo, float g) {
     if (g < 1e-3f) return 0.25f * GBL_INV_PI;
     float cos_theta = dot(wi, wo);
-    return 0.25f * GBL_INV_PI * (1.0f - g * g) / powf(1.0f + g * g - 2.0f * g * cos_theta, 1.5f);
+    return 0.25f * GBL_INV_PI * (1.0f - g * g) / gbl_powf(1.0f + g * g - 2.0f * g * cos_theta, 1.5f);
 }
 // Goblin::specularRefract(wo, n, etai, etat), GoblinMaterial.cpp:418-434
 __device__ __forceinline__ F3 refract_dir(F3 wo, F3 n, float etai, float etat) {
@@ -69,12 +69,12 @@ __device__ __forceinline__ F3 refract_dir(F3 wo, F3 n, float etai, float etat) {
 // gaussianSample2DPdf on the disc of radius rmax (GoblinSampler.h:194-204) and of a point projected on the plane
 // through `center` with normal N (GoblinSampler.cpp:645-657)
 __device__ __forceinline__ float gaussian_pdf_2d(float x, float y, float falloff, float rmax) {
-    return (GBL_INV_PI * falloff * expf(-falloff * (x * x + y * y))) / (1.0f - expf(-falloff * rmax * rmax));
+    return (GBL_INV_PI * falloff * gbl_expf(-falloff * (x * x + y * y))) / (1.0f - gbl_expf(-falloff * rmax * rmax));
 }
 __device__ __forceinline__ float gaussian_pdf_proj(F3 center, F3 sample, F3 N, float falloff, float rmax) {
     F3 d = sample - center;
     F3 projected = d - N * dot(d, N);
-    return (GBL_INV_PI * falloff * expf(-falloff * sqlen(projected))) / (1.0f - expf(-falloff * rmax * rmax));
+    return (GBL_INV_PI * falloff * gbl_expf(-falloff * sqlen(projected))) / (1.0f - gbl_expf(-falloff * rmax * rmax));
 }
 
 #define SSS_U_AXIS 0
@@ -172,9 +172,9 @@ __device__ __forceinline__ F3 l_bssrdf_single(const DevScene& sc, const RenderAr
     for (int i = 0; i < ra.bssrdf_n; ++i) {
         const SssSample bs = sss_sample<REPLAY>(ra, src, static_cast<uint32_t>(i));
         if (STATS) cnt.dims += 8;
-        const float d = -logf(bs.single) / falloff;              // exponentialSample
+        const float d = -gbl_logf(bs.single) / falloff;              // exponentialSample
         const F3 p_sample = pwo + d * wo_refract;
-        const float sample_pdf = falloff * expf(-falloff * d);   // exponentialPdf
+        const float sample_pdf = falloff * gbl_expf(-falloff * d);   // exponentialPdf
         float pick_pdf;
         const int li = sss_pick_light(sc, bs.pick_light, &pick_pdf);
         LightSampleOut ls;
@@ -219,12 +219,12 @@ __device__ __forceinline__ F3 l_bssrdf_diffusion(const DevScene& sc, const Rende
     const float Ft = 1.0f - fresnel_dielectric(coso, 1.0f, eta);
     const float sigma_tr = sss_luminance(bssrdf_sigma_tr(mo));
     const float skip_ratio = 0.01f;
-    const float rmax = sqrtf(logf(skip_ratio) / -sigma_tr);
+    const float rmax = sqrtf(gbl_logf(skip_ratio) / -sigma_tr);
     F3 Lm = f3(0, 0, 0);
     for (int i = 0; i < ra.bssrdf_n; ++i) {
         const SssSample bs = sss_sample<REPLAY>(ra, src, static_cast<uint32_t>(i));
         // BSSRDF::sampleProbeRay (GoblinMaterial.cpp:129-164): a gaussian disc sample, probed along N, U or V (2 : 1 : 1)
-        const float r = sqrtf(logf(1.0f - bs.disc0 * (1.0f - expf(-sigma_tr * rmax * rmax))) / -sigma_tr);
+        const float r = sqrtf(gbl_logf(1.0f - bs.disc0 * (1.0f - gbl_expf(-sigma_tr * rmax * rmax))) / -sigma_tr);
         const float theta = GBL_TWO_PI * bs.disc1;
         const float sx = r * gbl_cosf(theta), sy = r * gbl_sinf(theta);
         const float half_len = sqrtf(rmax * rmax - (sx * sx + sy * sy));

@@ -66,7 +66,7 @@ __device__ __forceinline__ F3 vol_transmittance(const DevVolume& v, F3 o, F3 d, 
     if (!vol_intersect(v, o, d, mint, maxt, &tmin, &tmax)) return f3(1.0f, 1.0f, 1.0f);
     const float len = length((o + tmax * d) - (o + tmin * d));
     const F3 tau = len * f3(v.attenuation[0], v.attenuation[1], v.attenuation[2]);
-    return f3(expf(-tau.x), expf(-tau.y), expf(-tau.z));
+    return f3(gbl_expf(-tau.x), gbl_expf(-tau.y), gbl_expf(-tau.z));
 }
 
 // Light::samplePosition (GoblinLight.cpp:101-108, 161-175, 239-244, 396-409)
@@ -152,14 +152,14 @@ __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mi
         const float delta = dot(p_light - o, d);
         const float a = tmin - delta, b = tmax - delta;
         const float D = length(p_light - (o + delta * d));
-        const float theta_a = atan2f(a, D), theta_b = atan2f(b, D);
+        const float theta_a = gbl_atan2f(a, D), theta_b = gbl_atan2f(b, D);
         const float ue = rnd.f();
-        const float te = D * tanf((1 - ue) * theta_a + ue * theta_b);           // equiAngularSample
+        const float te = D * gbl_tanf((1 - ue) * theta_a + ue * theta_b);           // equiAngularSample
         const float pdf_te = D / ((theta_b - theta_a) * (D * D + te * te));    // equiAngularPdf
         const F3 p_e = o + (delta + te) * d;
         const bool in_e = vol_contains(vol, p_e);
         const F3 sigma_te = in_e ? att : zero, scatter_e = in_e ? sca : zero;
-        const F3 tr_e = f3(expf(-sigma_te.x * (te - a)), expf(-sigma_te.y * (te - a)), expf(-sigma_te.z * (te - a)));
+        const F3 tr_e = f3(gbl_expf(-sigma_te.x * (te - a)), gbl_expf(-sigma_te.y * (te - a)), gbl_expf(-sigma_te.z * (te - a)));
         {
             LightSampleOut ls;
             light_sample<true>(sc, light, p_e, 0.0f, e_comp, e_u1, e_u2, ls);
@@ -170,7 +170,7 @@ __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mi
                     const F3 Ld = div(tr_light * ls.L, pick_pdf * ls.pdf);
                     const float phase = in_e ? phase_hg(d, ls.wi, vol.g) : 0.0f;   // VolumeRegion::phase
                     const float sig = sss_luminance(sigma_te);
-                    const float pdf_td = sig / (expf(sig * (te - a)) - expf(sig * (te - b)));   // exponentialPdf(t, sigma, a, b)
+                    const float pdf_td = sig / (gbl_expf(sig * (te - a)) - gbl_expf(sig * (te - b)));   // exponentialPdf(t, sigma, a, b)
                     const float mis = power_heuristic(pdf_te, pdf_td);
                     const F3 t = div(mis * tr_e * scatter_e * phase * Ld, pdf_te);
                     Lv = f3(Lv.x + t.x, Lv.y + t.y, Lv.z + t.z);
@@ -181,10 +181,10 @@ __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mi
         const F3 sigma_td = vol_contains(vol, o + (0.5f * (tmin + tmax)) * d) ? att : zero;
         const float ud = rnd.f();
         const float sig_d = sss_luminance(sigma_td);
-        const float td = a - logf(1.0f - ud * (1.0f - expf(sig_d * (a - b)))) / sig_d;   // exponentialSample(u, sigma, a, b)
-        const float pdf_td = sig_d / (expf(sig_d * (td - a)) - expf(sig_d * (td - b)));
+        const float td = a - gbl_logf(1.0f - ud * (1.0f - gbl_expf(sig_d * (a - b)))) / sig_d;   // exponentialSample(u, sigma, a, b)
+        const float pdf_td = sig_d / (gbl_expf(sig_d * (td - a)) - gbl_expf(sig_d * (td - b)));
         const F3 p_d = o + (delta + td) * d;
-        const F3 tr_d = f3(expf(-sigma_td.x * (td - a)), expf(-sigma_td.y * (td - a)), expf(-sigma_td.z * (td - a)));
+        const F3 tr_d = f3(gbl_expf(-sigma_td.x * (td - a)), gbl_expf(-sigma_td.y * (td - a)), gbl_expf(-sigma_td.z * (td - a)));
         const bool in_d = vol_contains(vol, p_d);
         const F3 scatter_d = in_d ? sca : zero;
         const float d_comp = rnd.f(), d_u1 = rnd.f(), d_u2 = rnd.f();   // LightSample lsDistance(rng)

@@ -54,12 +54,12 @@ __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, 
         F3 nrm = ip->shape == 1u ? normalize(pos) : f3(0.0f, 0.0f, 1.0f);
         F3 dpdu = f3(-GBL_TWO_PI * pos.y, GBL_TWO_PI * pos.x, 0.0f);
         if (want_tex) {
-            float phi = atan2f(pos.y, pos.x);
+            float phi = gbl_atan2f(pos.y, pos.x);
             if (phi < 0.0f) phi += GBL_TWO_PI;
             tf->u = phi * GBL_INV_TWOPI;
             F3 dpdv;
             if (ip->shape == 1u) {
-                float theta = acosf(pos.z / ip->radius);
+                float theta = gbl_acosf(pos.z / ip->radius);
                 tf->v = theta * GBL_INV_PI;
                 float inv_r = 1.0f / sqrtf(pos.x * pos.x + pos.y * pos.y);
                 float cos_phi = pos.x * inv_r, sin_phi = pos.y * inv_r;
@@ -173,8 +173,8 @@ __device__ __forceinline__ void uv_differential(const Frag& fr, TexFrag& tf, boo
 // SphericalMapping::pointToST, GoblinTexture.cpp:339-347
 __device__ __forceinline__ void point_to_st(const float* to_tex, F3 p, float* s, float* t) {
     F3 v = normalize(xf_point(to_tex, p) - f3(0.0f, 0.0f, 0.0f));
-    float theta = acosf(fminf(fmaxf(v.z, -1.0f), 1.0f));
-    float phi = atan2f(v.y, v.x);
+    float theta = gbl_acosf(fminf(fmaxf(v.z, -1.0f), 1.0f));
+    float phi = gbl_atan2f(v.y, v.x);
     phi = phi < 0.0f ? phi + GBL_TWO_PI : phi;
     *s = phi * GBL_INV_TWOPI;
     *t = theta * GBL_INV_PI;
@@ -314,7 +314,7 @@ __device__ __forceinline__ F3 blinn_bsdf(const DevMaterial& m, F3 n, F3 wo, F3 w
     F3 wh = normalize(wo + wi);
     float cosh = absdot(n, wh);
     float e = m.exponent;
-    float D = (e + 2.0f) * GBL_INV_TWOPI * powf(cosh, e);
+    float D = (e + 2.0f) * GBL_INV_TWOPI * gbl_powf_inline(cosh, e);
     float wo_wh = absdot(wo, wh);
     float G = fminf(1.0f, fminf(2.0f * cosh * coso / wo_wh, 2.0f * cosh * cosi / wo_wh));
     float F = m.k > 0.0f ? fresnel_conductor(wo_wh, m.index, m.k) : fresnel_dielectric(wo_wh, 1.0f, m.index);
@@ -326,7 +326,7 @@ __device__ __forceinline__ float blinn_pdf(const DevMaterial& m, F3 n, F3 wo, F3
     F3 wh = normalize(wo + wi);
     float cos_h = absdot(wh, n);
     float e = m.exponent;
-    return (e + 1.0f) * powf(cos_h, e) / (GBL_TWO_PI * 4.0f * dot(wo, wh));
+    return (e + 1.0f) * gbl_powf_inline(cos_h, e) / (GBL_TWO_PI * 4.0f * dot(wo, wh));
 }
 
 // material->bsdf(fragment, wo, wi)
@@ -362,7 +362,7 @@ __device__ __forceinline__ F3 mat_sample(const DevMaterial& m, const Frag& fr, F
     }
     if (m.type == GBL_MAT_BLINN) {
         float e = m.exponent;
-        float cos_t = powf(u1, 1.0f / (e + 1.0f));
+        float cos_t = gbl_powf_inline(u1, 1.0f / (e + 1.0f));
         float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
         float phi = u2 * GBL_TWO_PI;
         F3 wh_local = f3(sin_t * gbl_cosf(phi), sin_t * gbl_sinf(phi), cos_t);

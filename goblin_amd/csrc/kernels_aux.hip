@@ -218,6 +218,39 @@ gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, floa
     return gbl_guard([&] { return gbl_selftest_arith_impl(ctx, a, b, out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
 }
 
+// out[i] = fn(a[i] [, b[i]]) with fn of gbl_libm_fn, from kernels/refmath.h
+__global__ void selftest_libm_kernel(int fn, const float* a, const float* b, float* out, uint64_t n) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b ? b[i] : 0.0f;
+    float r = 0.0f;
+    switch (fn) {
+        case GBL_LIBM_EXPF: r = gbl_expf(x); break;
+        case GBL_LIBM_LOGF: r = gbl_logf(x); break;
+        case GBL_LIBM_LOG2F: r = gbl_log2f(x); break;
+        case GBL_LIBM_POWF: r = gbl_powf(x, y); break;
+        case GBL_LIBM_ATANF: r = gbl_atanf(x); break;
+        case GBL_LIBM_ATAN2F: r = gbl_atan2f(x, y); break;
+        case GBL_LIBM_TANF: r = gbl_tanf(x); break;
+        case GBL_LIBM_ACOSF: r = gbl_acosf(x); break;
+        default: break;
+    }
+    out[i] = r;
+}
+static gbl_status gbl_selftest_libm_impl(gbl_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n) {
+    if (!ctx || !a || !out || fn < 0 || fn > GBL_LIBM_ACOSF) return GBL_ERR_INVALID;
+    if ((fn == GBL_LIBM_POWF || fn == GBL_LIBM_ATAN2F) && !b) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return GBL_OK;
+    hipLaunchKernelGGL(selftest_libm_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, fn, a, b, out, n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GBL_OK;
+}
+gbl_status gbl_selftest_libm(gbl_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n) {
+    return gbl_guard([&] { return gbl_selftest_libm_impl(ctx, fn, a, b, out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
+}
+
 static gbl_status gbl_selftest_sincos_impl(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {
     if (!ctx || !in || !sin_out || !cos_out) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

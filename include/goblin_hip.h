@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 9
+#define GBL_ABI_VERSION 10
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -514,6 +514,14 @@ gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, co
 
 /* Self-test hook: the device's sinf / cosf (glibc's algorithm restated, kernels/refmath.h) on n device floats. */
 gbl_status gbl_selftest_sincos(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n);
+/* Self-test hook: out[i] = fn(a[i] [, b[i]]) on n device floats, fn one of the libm functions the reference's sampling code
+ * passes through (exp / log / log2 / pow / atan / atan2 / tan / acos on floats: glibc's algorithms restated, kernels/refmath.h).
+ * b may be NULL for the one-argument functions. */
+typedef enum gbl_libm_fn {
+    GBL_LIBM_EXPF = 0, GBL_LIBM_LOGF = 1, GBL_LIBM_LOG2F = 2, GBL_LIBM_POWF = 3,
+    GBL_LIBM_ATANF = 4, GBL_LIBM_ATAN2F = 5, GBL_LIBM_TANF = 6, GBL_LIBM_ACOSF = 7
+} gbl_libm_fn;
+gbl_status gbl_selftest_libm(gbl_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 /* Self-test hook: out[4 i ..] = {sqrtf(a), a / b, 1 / a, normalize(a, b, 0.5).x} on n device floats -- the basic
  * operations must round like the host's for per-sample radiance to be bit-identical with the reference. */
 gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, float* out, uint64_t n);

@@ -48,7 +48,7 @@ def test_random_scene_matches_oracle(seed):
             flips = helpers.li_mismatch_fraction(li, li_ref)
             rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
             print("seed", seed, bvh, schedule, "flips %.5f relL2 %.2e" % (flips, rel), "mask" if masks_in_use else "")
-            assert flips == 0.0 and rel <= 3e-8, (seed, bvh, schedule, flips, rel)   # measured <= 2.3e-9
+            assert flips == 0.0 and rel == 0.0, (seed, bvh, schedule, flips, rel)   # bit-identical radiance (libm restated, refmath.h)
     # the reference's own sample stream, generated on the device: the oracle's whole-render Film (bit-exact with the
     # compiled reference on these scenes, tests/test_oracle_fuzz.py) is the reference's Film
     ref = o.render(threads=1)["film"]
@@ -79,7 +79,7 @@ def test_random_whitted_scene_matches_oracle(seed):
         flips = helpers.li_mismatch_fraction(li, li_ref)
         rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
         print("seed", seed, bvh, "whitted flips %.5f relL2 %.2e" % (flips, rel))
-        assert flips == 0.0 and rel <= 6e-8, (seed, bvh, flips, rel)   # measured <= 5.1e-9
+        assert flips == 0.0 and rel == 0.0, (seed, bvh, flips, rel)   # bit-identical radiance
     ref = o.render(threads=1)["film"]
     film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
     rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
