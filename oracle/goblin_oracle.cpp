@@ -3517,6 +3517,21 @@ int32_t orc_render(const orc_scene* s, const gbl_render_setting* rs, int32_t thr
     return 0;
 }
 
+// MIPMap<T>::lookup of image `image` of the scene for n queries {s, t, dsdx, dtdx, dsdy, dtdy} -> n x {r, g, b, a}
+// (the checker of tests/test_oracle_vs_reference.py's lookup-level comparison with the compiled reference)
+int32_t orc_mip_lookup(const orc_scene* s, uint32_t image, int32_t is_float, const float* queries, uint64_t n, uint32_t filter, uint32_t mode,
+                       float max_aniso, float* out) {
+    if (!s || image >= s->images.size() || !queries || !out) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        TexCoord tc;
+        tc.s = queries[6 * i], tc.t = queries[6 * i + 1];
+        tc.dsdx = queries[6 * i + 2], tc.dtdx = queries[6 * i + 3], tc.dsdy = queries[6 * i + 4], tc.dtdy = queries[6 * i + 5];
+        const Col c = mip_lookup(s, s->images[image], is_float != 0, tc, filter, mode, max_aniso);
+        out[4 * i] = c.r, out[4 * i + 1] = c.g, out[4 * i + 2] = c.b, out[4 * i + 3] = c.a;
+    }
+    return 0;
+}
+
 int32_t orc_hardware_threads(void) { return static_cast<int32_t>(std::thread::hardware_concurrency()); }
 
 }  // extern "C"

@@ -253,6 +253,33 @@ static int image_mode(int argc, char** argv) {
         printf("{\"mode\": \"mipmap\", \"width\": %d, \"height\": %d, \"levels\": %d}\n", mip.getWidth(), mip.getHeight(), mip.getLevelsNum());
         return 0;
     }
+    if (mode == "miplookup") {   // miplookup <file.exr> <queries.f32> <out.f32> <filter 0-3> <address 0-2> <max anisotropy>: MIPMap<Color>::lookup
+        if (argc < 8) return 2;      // of n queries {s, t, dsdx, dtdx, dsdy, dtdy} -> n float4
+        int w = 0, h = 0;
+        Color* c = loadImage(argv[2], &w, &h);
+        if (!c) return 1;
+        MIPMap<Color> mip(c, w, h, static_cast<float>(atof(argv[7])));
+        FILE* f = fopen(argv[3], "rb");
+        if (!f) return 1;
+        fseek(f, 0, SEEK_END);
+        const size_t n = static_cast<size_t>(ftell(f)) / (6 * sizeof(float));
+        fseek(f, 0, SEEK_SET);
+        std::vector<float> q(6 * n), out(4 * n);
+        if (fread(q.data(), sizeof(float), q.size(), f) != q.size()) return 1;
+        fclose(f);
+        const FilterType filters[] = {FilterNone, FilterBilinear, FilterTrilinear, FilterEWA};
+        const AddressMode modes[] = {AddressRepeat, AddressClamp, AddressBorder};
+        for (size_t i = 0; i < n; ++i) {
+            TextureCoordinate tc;
+            tc.st = Vector2(q[6 * i], q[6 * i + 1]);
+            tc.dsdx = q[6 * i + 2], tc.dtdx = q[6 * i + 3], tc.dsdy = q[6 * i + 4], tc.dtdy = q[6 * i + 5];
+            const Color r = mip.lookup(tc, filters[atoi(argv[5])], modes[atoi(argv[6])]);
+            out[4 * i] = r.r, out[4 * i + 1] = r.g, out[4 * i + 2] = r.b, out[4 * i + 3] = r.a;
+        }
+        write_f32(argv[4], out);
+        printf("{\"mode\": \"miplookup\", \"n\": %zu}\n", n);
+        return 0;
+    }
     if (argc < 8) return 2;
     const int w = atoi(argv[3]), h = atoi(argv[4]);
     const std::string prefix = argv[5];
@@ -289,7 +316,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s film|li|kat|time <scene.json> ... | image <in.f32> <w> <h> <prefix> <radius> <weight> | imageload <file.exr> <out.f32>\n", argv[0]);
         return 2;
     }
-    if (!strcmp(argv[1], "image") || !strcmp(argv[1], "imageload") || !strcmp(argv[1], "mipmap")) return image_mode(argc, argv);
+    if (!strcmp(argv[1], "image") || !strcmp(argv[1], "imageload") || !strcmp(argv[1], "mipmap") || !strcmp(argv[1], "miplookup")) return image_mode(argc, argv);
     std::string mode = argv[1], scene_path = argv[2];
     // the loader echoes every parsed parameter to stdout; keep stdout for our JSON line
     FILE* real_stdout = fdopen(dup(fileno(stdout)), "w");

@@ -67,6 +67,8 @@ def lib():
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
                                  C.POINTER(orc_counters)]
         L.orc_hardware_threads.restype = C.c_int32
+        L.orc_mip_lookup.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_mip_lookup.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -113,6 +115,14 @@ class Oracle:
     def camera_ray(self, x, y):
         out = np.zeros(8, np.float32)
         lib().orc_camera_ray(self.h, x, y, _ptr(out))
+        return out
+
+    def mip_lookup(self, image, queries, filter, mode, max_aniso=10.0, is_float=False):
+        """MIPMap<T>::lookup of the scene's image `image` for n x {s, t, dsdx, dtdx, dsdy, dtdy} -> n x rgba."""
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, 6)
+        out = np.zeros((q.shape[0], 4), np.float32)
+        if lib().orc_mip_lookup(self.h, image, int(is_float), _ptr(q), q.shape[0], filter, mode, max_aniso, _ptr(out)) != 0:
+            raise RuntimeError("orc_mip_lookup failed")
         return out
 
     def light_power(self):
