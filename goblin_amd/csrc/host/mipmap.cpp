@@ -27,6 +27,12 @@ inline uint32_t round_up_pow2(uint32_t n) {
     n |= n >> 16;
     return n + 1;
 }
+// Goblin::log2 (GoblinUtils.h:84-87), not libm's: logf times a float 1 / ln 2 -- so the level count of a power-of-two side is
+// whatever that product floors to, as in the reference
+inline float goblin_log2(float n) {
+    static const float inv_log2 = 1.0f / logf(2.0f);
+    return logf(n) * inv_log2;
+}
 inline float gaussian(float x, float w, float falloff = 2.0f) { return std::max(0.0f, expf(-falloff * x * x) - expf(-falloff * w * w)); }
 
 // resizeImage<T>, GoblinTexture.cpp:531-597
@@ -86,7 +92,7 @@ gbl_image build_mipmap(std::vector<float>& pool, std::vector<float> level0, int 
     img.width = static_cast<uint32_t>(w);
     img.height = static_cast<uint32_t>(h);
     img.channels = static_cast<uint32_t>(channels);
-    img.levels = static_cast<uint32_t>(floor_int(std::max(log2f(static_cast<float>(w)), log2f(static_cast<float>(h)))) + 1);
+    img.levels = static_cast<uint32_t>(floor_int(std::max(goblin_log2(static_cast<float>(w)), goblin_log2(static_cast<float>(h)))) + 1);
     img.texel_offset = pool.size();
     std::vector<float> cur = std::move(level0);
     int cw = w, ch = h;

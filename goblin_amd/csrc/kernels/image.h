@@ -71,7 +71,7 @@ __device__ __forceinline__ F3 mip_level(const ImgCtx sc, const DevImage& im, int
 
 __device__ __forceinline__ F3 mip_trilinear(const ImgCtx sc, const DevImage& im, float s, float t, float width, uint32_t mode) {
     const int levels = static_cast<int>(im.levels);
-    const float level = levels - 1 + gbl_log2f(fmaxf(width, 1e-8f));
+    const float level = levels - 1 + gbl_ref_log2(fmaxf(width, 1e-8f));
     const int il = img_floor(level);
     if (il < 0) return mip_level(sc, im, 0, s, t, mode);
     if (il >= levels - 1) return mip_level(sc, im, levels - 1, s, t, mode);
@@ -127,7 +127,7 @@ __device__ __attribute__((noinline)) F3 mip_lookup(const ImgCtx sc, const DevIma
     const DevImage& im = *imp;
     if (filter == 1u) {   // bilinear: one level, rounded
         const float width = fmaxf(fmaxf(fabsf(tc.dsdx), fabsf(tc.dtdx)), fmaxf(fabsf(tc.dsdy), fabsf(tc.dtdy)));
-        const float level = static_cast<int>(im.levels) - 1 + gbl_log2f(fmaxf(width, 1e-8f));
+        const float level = static_cast<int>(im.levels) - 1 + gbl_ref_log2(fmaxf(width, 1e-8f));
         return mip_level(sc, im, img_floor(level + 0.5f), tc.s, tc.t, mode);
     }
     if (filter == 2u) {
@@ -158,7 +158,7 @@ __device__ __attribute__((noinline)) F3 mip_lookup(const ImgCtx sc, const DevIma
         B *= inv_f;
         C *= inv_f;
         const int levels = static_cast<int>(im.levels);
-        const float level = levels - 1 + gbl_log2f(minor);
+        const float level = levels - 1 + gbl_ref_log2(minor);
         const int il = img_floor(level);
         if (il < 0) return mip_level(sc, im, 0, tc.s, tc.t, mode);
         if (il >= levels - 1) return mip_level(sc, im, levels - 1, tc.s, tc.t, mode);

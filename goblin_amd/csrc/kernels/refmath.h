@@ -461,3 +461,9 @@ GBL_HD float gbl_powf_inline(float x, float y) {
     return static_cast<float>(e);
 }
 GBL_HD_CALL float gbl_powf(float x, float y) { return gbl_powf_inline(x, y); }
+// Goblin::log2 (GoblinUtils.h:84-87) -- the reference's namespace shadows libm's log2 with logf(n) * (1.0f / logf(2.0f)); the
+// MIPMap's level selection goes through this one.  logf(2.0f) = 0x1.62e43p-1 in glibc.
+GBL_HD float gbl_ref_log2(float n) {
+    const float inv_log2 = 1.0f / 0x1.62e43p-1f;
+    return gbl_logf(n) * inv_log2;
+}

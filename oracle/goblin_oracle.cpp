@@ -1382,6 +1382,11 @@ inline float integrate_checker(float x) {   // GoblinTexture.cpp:371-375
     float x_half = 0.5f * x;
     return std::floor(x_half) + 2.0f * std::max(x_half - std::floor(x_half) - 0.5f, 0.0f);
 }
+// The reference's own log2 (GoblinUtils.h:84-87; the Goblin namespace shadows libm's): logf times a float 1 / ln 2.
+inline float goblin_log2(float n) {
+    static const float inv_log2 = 1.0f / logf(2.0f);
+    return logf(n) * inv_log2;
+}
 // ---- MIPMap<T> (GoblinTexture.cpp:40-291).  The levels come built (gbl_image); T = float is kept in .r of a Col.
 inline void level_dims(const gbl_image& im, int level, int* w, int* h, size_t* off) {   // (declared above)
     size_t o = 0;
@@ -1423,7 +1428,7 @@ Col mip_level(const orc_scene* sc, const gbl_image& im, int level, float s, floa
 }
 Col mip_trilinear(const orc_scene* sc, const gbl_image& im, float s, float t, float width, uint32_t mode) {   // :112-127
     int levels = static_cast<int>(im.levels);
-    float level = levels - 1 + log2f(std::max(width, 1e-8f));
+    float level = levels - 1 + goblin_log2(std::max(width, 1e-8f));
     int il = floor_int(level);
     if (il < 0) return mip_level(sc, im, 0, s, t, mode);
     if (il >= levels - 1) return mip_level(sc, im, levels - 1, s, t, mode);
@@ -1466,7 +1471,7 @@ Col mip_ewa_level(const orc_scene* sc, const gbl_image& im, bool is_float, int l
 Col mip_lookup(const orc_scene* sc, const gbl_image& im, bool is_float, const TexCoord& tc, uint32_t filter, uint32_t mode, float max_aniso) {   // :78-97
     if (filter == GBL_IMAGE_FILTER_BILINEAR) {
         float width = std::max(std::max(std::fabs(tc.dsdx), std::fabs(tc.dtdx)), std::max(std::fabs(tc.dsdy), std::fabs(tc.dtdy)));
-        float level = static_cast<int>(im.levels) - 1 + log2f(std::max(width, 1e-8f));
+        float level = static_cast<int>(im.levels) - 1 + goblin_log2(std::max(width, 1e-8f));
         return mip_level(sc, im, floor_int(level + 0.5f), tc.s, tc.t, mode);
     }
     if (filter == GBL_IMAGE_FILTER_TRILINEAR) {
@@ -1497,7 +1502,7 @@ Col mip_lookup(const orc_scene* sc, const gbl_image& im, bool is_float, const Te
         B *= inv_f;
         C *= inv_f;
         int levels = static_cast<int>(im.levels);
-        float level = levels - 1 + log2f(minor);
+        float level = levels - 1 + goblin_log2(minor);
         int il = floor_int(level);
         if (il < 0) return mip_level(sc, im, 0, tc.s, tc.t, mode);
         if (il >= levels - 1) return mip_level(sc, im, levels - 1, tc.s, tc.t, mode);
