@@ -143,6 +143,12 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
     return ctx->li_budget;
 }
 
+// Experiment switch of the megakernel's workgroup-level tracing (kernels/blocktrace.h)
+static bool block_trace_wanted() {
+    const char* e = getenv("GBL_MK_BLOCKTRACE");
+    return e != nullptr && atoi(e) != 0;
+}
+
 // Stack levels of the wavefront trace kernels beyond the LDS part: one column per thread of the largest persistent
 // trace grid (8 workgroups per CU).  Re-made when an instance edit deepens the TLAS.
 gbl_status wf_ensure_spill(gbl_ctx* ctx) {
@@ -1091,6 +1097,20 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             if (lds > 64 * 1024)
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         }
+        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted()) {
+            // kernels/blocktrace.h: the workgroup traces its rays in rounds and packs the survivors into fewer waves
+            kernel = gbl_kernel_path_block(replay, want_stats, ext || want_stats);
+            gbl_status sst = wf_ensure_spill(ctx);
+            if (sst != GBL_OK) return sst;
+            ra.bt_spill = ctx->wf_spill;
+            lds = sizeof(float) * (4 * tp * tp + 256) + 4 * sizeof(uint32_t) +
+                  static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t) +
+                  static_cast<size_t>(gbl_block_trace_lds_words()) * sizeof(uint32_t);
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * 8);   // (the occupancy query below trims it; the stack backing holds 8 per CU)
+            grid = dim3(static_cast<unsigned>(grid64));
+        }
         if (wavepool && !defer) {
             ctx->error = "the wave-pool schedule keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
@@ -1107,6 +1127,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 if (!stream_mode) grid = dim3(static_cast<unsigned>(grid64));   // (stream mode sized its scratch for the original grid)
             }
         }
+        ra.bt_spill_stride = static_cast<uint32_t>(grid64 * GBL_BLOCK);
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(tev[1], stream));

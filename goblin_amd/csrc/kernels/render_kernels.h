@@ -22,6 +22,7 @@
 #include "bssrdf.h"
 #include "medium.h"
 #include "trace.h"
+#include "blocktrace.h"
 #include "vecmath.h"
 
 struct ItemInfo {
@@ -335,7 +336,9 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 
 // STREAM (implies REPLAY): the records are the reference's own, generated per pixel from the tile's mt19937
 // (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false>
+// BT: the extension and the shadow ray of a vertex are traced by the whole workgroup together (kernels/blocktrace.h: rounds of a
+// few node visits, the surviving rays packed into as few waves as hold them in between); everything else is unchanged.
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
@@ -345,7 +348,25 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
-    const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
+    static_assert(!(BT && STREAM), "workgroup-level tracing is built for the native / replay samplers");
+    BlockXch bx = {};
+    uint32_t bt_phase = 0;
+    if constexpr (BT) {   // LDS: ... | stacks: min(stack_entries, GBL_WF_STACK_LDS) levels | exchange area (blocktrace.h)
+        const int lds_levels = sc.stack_entries < GBL_WF_STACK_LDS ? sc.stack_entries : GBL_WF_STACK_LDS;
+        bx.stack = gbl_as_lds(stack);
+        bx.state = gbl_as_lds(stack + lds_levels * GBL_BLOCK);
+        bx.owner = bx.state + GBL_BT_STATE_WORDS * GBL_BLOCK;
+        bx.ctrl = bx.owner + GBL_BT_OWNER_WORDS * GBL_BLOCK;
+        bx.spill = gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK);
+        bx.spill_stride = ra.bt_spill_stride;
+    }
+    typedef typename std::conditional<BT, SplitStack, LdsStack>::type PathStack;
+    PathStack stk;
+    if constexpr (BT) {
+        stk = bt_stack(bx, threadIdx.x);
+    } else {
+        stk.p = gbl_as_lds(stack + threadIdx.x);
+    }
     for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     StreamCtx scx = {};
     StreamLayout slay = {};
@@ -471,12 +492,21 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     exhausted = true;
                 }
             }
-            if (__ballot(active) == 0ull) break;
+            if (!BT && __ballot(active) == 0ull) break;
 
             bool finished = false;
             Hit hit;
             bool got = false;
-            if (active) {
+            if constexpr (BT) {
+                // (the workgroup leaves the loop together: "some wave still has a path in flight" rides on the trace's first barrier)
+                bool any_active = false;
+                const bool want = active && sc.num_lights != 0;
+                got = trace_block<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, bx, hit, cnt, GBL_FILTER_NONE, bt_phase,
+                                                                        active, &any_active);
+                if (!any_active) break;
+                if (active && !want) finished = true;
+                if (STATS && want) cnt.ext += 1;
+            } else if (active) {
                 if (sc.num_lights == 0) {
                     finished = true;   // PathTracer::Li returns Black without lights (:53-56)
                 } else {
@@ -635,11 +665,18 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 }
             }
             // ---- shadow query (any-hit)
+            bool bt_occluded = false;
+            if constexpr (BT) {
+                Hit dummy;
+                bt_occluded = trace_block<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, bx, dummy, cnt,
+                                                                  (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE, bt_phase, false, nullptr);
+            }
             if (need_shadow) {
                 Hit dummy;
                 const bool masks = EXT && sc.has_masks != 0;
-                bool occluded = trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
-                                                        masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
+                bool occluded = BT ? bt_occluded
+                                   : trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
+                                                             masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 if (STATS) cnt.shadow += 1;
                 if (!occluded && masks) {
                     F3 tr = eval_attenuation<STATS>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, cnt);
