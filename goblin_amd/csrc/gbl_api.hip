@@ -144,9 +144,9 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
 }
 
 // Experiment switch of the megakernel's workgroup-level tracing (kernels/blocktrace.h)
-static bool block_trace_wanted() {
+static int block_trace_wanted() {   // 1: blocktrace.h, 2: rayexchange.h
     const char* e = getenv("GBL_MK_BLOCKTRACE");
-    return e != nullptr && atoi(e) != 0;
+    return e != nullptr ? atoi(e) : 0;
 }
 
 // Stack levels of the wavefront trace kernels beyond the LDS part: one column per thread of the largest persistent
@@ -1098,14 +1098,16 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         }
         if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted()) {
-            // kernels/blocktrace.h: the workgroup traces its rays in rounds and packs the survivors into fewer waves
-            kernel = gbl_kernel_path_block(replay, want_stats, ext || want_stats);
+            // kernels/blocktrace.h: the workgroup traces its rays in rounds and packs the survivors into fewer waves;
+            // kernels/rayexchange.h (2): the waves hand their long rays to one another through LDS, no barriers
+            const bool exchange = block_trace_wanted() == 2;
+            kernel = exchange ? gbl_kernel_path_exchange(replay, want_stats, ext || want_stats) : gbl_kernel_path_block(replay, want_stats, ext || want_stats);
             gbl_status sst = wf_ensure_spill(ctx);
             if (sst != GBL_OK) return sst;
             ra.bt_spill = ctx->wf_spill;
             lds = sizeof(float) * (4 * tp * tp + 256) + 4 * sizeof(uint32_t) +
                   static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t) +
-                  static_cast<size_t>(gbl_block_trace_lds_words()) * sizeof(uint32_t);
+                  static_cast<size_t>(exchange ? gbl_ray_exchange_lds_words() : gbl_block_trace_lds_words()) * sizeof(uint32_t);
             if (lds > 64 * 1024)
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
             grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * 8);   // (the occupancy query below trims it; the stack backing holds 8 per CU)

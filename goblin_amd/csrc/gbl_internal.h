@@ -89,6 +89,9 @@ gbl_render_kernel gbl_kernel_pair(bool replay, bool stats, bool ext);
 // kernels_block.hip: the megakernel whose workgroups trace their rays together (kernels/blocktrace.h)
 gbl_render_kernel gbl_kernel_path_block(bool replay, bool stats, bool ext);
 uint32_t gbl_block_trace_lds_words(void);   // LDS words of the exchange area, behind the stacks
+// kernels_exchange.hip: the megakernel whose waves hand their long rays to one another through LDS (kernels/rayexchange.h)
+gbl_render_kernel gbl_kernel_path_exchange(bool replay, bool stats, bool ext);
+uint32_t gbl_ray_exchange_lds_words(void);
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext);

@@ -23,6 +23,7 @@
 #include "medium.h"
 #include "trace.h"
 #include "blocktrace.h"
+#include "rayexchange.h"
 #include "vecmath.h"
 
 struct ItemInfo {
@@ -338,7 +339,9 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 // (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
 // BT: the extension and the shadow ray of a vertex are traced by the whole workgroup together (kernels/blocktrace.h: rounds of a
 // few node visits, the surviving rays packed into as few waves as hold them in between); everything else is unchanged.
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false>
+// RX: the same two rays go through the workgroup's ray exchange instead (kernels/rayexchange.h: no barriers; the waves hand
+// their long rays to one another through LDS and help with whatever waits there while their own results are out).
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false, bool RX = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
@@ -360,9 +363,25 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
         bx.spill = gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK);
         bx.spill_stride = ra.bt_spill_stride;
     }
-    typedef typename std::conditional<BT, SplitStack, LdsStack>::type PathStack;
+    static_assert(!(RX && (STREAM || BT)), "the ray exchange is built for the native / replay samplers");
+    RayXch rx = {};
+    if constexpr (RX) {   // LDS: ... | stacks: min(stack_entries, GBL_WF_STACK_LDS) levels | records | owner columns | flags | ring | counters
+        const int lds_levels = sc.stack_entries < GBL_WF_STACK_LDS ? sc.stack_entries : GBL_WF_STACK_LDS;
+        rx.stack = gbl_as_lds(stack);
+        rx.rec = gbl_as_lds(stack + lds_levels * GBL_BLOCK);
+        rx.own = rx.rec + GBL_RX_REC_WORDS * GBL_BLOCK;
+        rx.flag = rx.own + GBL_RX_OWN_WORDS * GBL_BLOCK;
+        rx.ring = rx.flag + GBL_BLOCK;
+        rx.ctl = rx.ring + GBL_BLOCK;
+        rx.spill = gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK);
+        rx.spill_stride = ra.bt_spill_stride;
+        rx_init(rx);
+    }
+    typedef typename std::conditional<BT || RX, SplitStack, LdsStack>::type PathStack;
     PathStack stk;
-    if constexpr (BT) {
+    if constexpr (RX) {
+        stk = rx_stack(rx, threadIdx.x);
+    } else if constexpr (BT) {
         stk = bt_stack(bx, threadIdx.x);
     } else {
         stk.p = gbl_as_lds(stack + threadIdx.x);
@@ -504,6 +523,11 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 got = trace_block<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, bx, hit, cnt, GBL_FILTER_NONE, bt_phase,
                                                                         active, &any_active);
                 if (!any_active) break;
+                if (active && !want) finished = true;
+                if (STATS && want) cnt.ext += 1;
+            } else if constexpr (RX) {
+                const bool want = active && sc.num_lights != 0;
+                got = trace_rx<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, rx, hit, cnt, GBL_FILTER_NONE);
                 if (active && !want) finished = true;
                 if (STATS && want) cnt.ext += 1;
             } else if (active) {
@@ -671,10 +695,17 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 bt_occluded = trace_block<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, bx, dummy, cnt,
                                                                   (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE, bt_phase, false, nullptr);
             }
+            if constexpr (RX) {
+                if (__ballot(need_shadow) != 0ull) {
+                    Hit dummy;
+                    bt_occluded = trace_rx<true, STATS, EXT, REPLAY || STATS>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, rx, dummy, cnt,
+                                                                               (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
+                }
+            }
             if (need_shadow) {
                 Hit dummy;
                 const bool masks = EXT && sc.has_masks != 0;
-                bool occluded = BT ? bt_occluded
+                bool occluded = (BT || RX) ? bt_occluded
                                    : trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
                                                              masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 if (STATS) cnt.shadow += 1;

@@ -7,7 +7,7 @@ for depth in (1, 2, 3, 8):
     scene = gs.load_scene("bunny", gs.config_overrides(resolution=(64, 64), spp=16, depth=depth))
     os.environ.pop("GBL_MK_BLOCKTRACE", None)
     a = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
-    os.environ["GBL_MK_BLOCKTRACE"] = "1"
+    os.environ["GBL_MK_BLOCKTRACE"] = sys.argv[1] if len(sys.argv) > 1 else "1"
     b = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
     bad = np.flatnonzero(np.any(a != b, axis=1))
     print("depth", depth, "differ", bad.size, "of", a.shape[0], "mean", a[:, :3].mean(), b[:, :3].mean())
