@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 10
+GBL_ABI_VERSION = 11
 GBL_AUTO_WAVEFRONT_DEPTH, GBL_AUTO_WAVEFRONT_TRIS = 12, 400000   # gbl_schedule AUTO thresholds (goblin_hip.h)
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM, GBL_ERR_INTERNAL = range(7)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
@@ -99,10 +99,11 @@ class gbl_render_setting(C.Structure):
 class gbl_volume(C.Structure):
     _fields_ = [("type", C.c_uint32), ("attenuation", C.c_float * 3), ("albedo", C.c_float * 3), ("emission", C.c_float * 3),
                 ("g", C.c_float), ("sample_num", C.c_int32), ("box_min", C.c_float * 3), ("box_max", C.c_float * 3),
-                ("to_world", gbl_trs)]
+                ("to_world", gbl_trs), ("step_size", C.c_float), ("grid", C.c_int32 * 3), ("grid_channels", C.c_int32),
+                ("density", C.POINTER(C.c_float))]
 
 
-GBL_VOLUME_NONE, GBL_VOLUME_HOMOGENEOUS = 0, 1
+GBL_VOLUME_NONE, GBL_VOLUME_HOMOGENEOUS, GBL_VOLUME_HETEROGENEOUS = 0, 1, 2
 
 
 class gbl_scene_desc(C.Structure):

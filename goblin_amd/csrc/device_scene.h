@@ -175,7 +175,13 @@ struct DevVolume {
     float m[12], inv[12];
     float bound_center[3];  // Scene::getBoundingSphere: centre of the scene bound ...
     float bound_radius;     // ... and its full diagonal (GoblinBBox.h:51-54)
-    float pad[2];
+    // HeterogeneousVolumeRegion (GoblinVolume.cpp:283-341): sigma_t from DevScene::vol_density, ray marched
+    uint32_t hetero;
+    float step;             // ray marching step (world units)
+    float albedo[3];
+    int32_t nx, ny, nz, nch;
+    float normalize[3];     // VolumeGrid::mNormalizeTerm: 1 / (box extent)
+    float pad[3];
 };
 
 struct DevCamera {
@@ -217,6 +223,7 @@ struct DevScene {
     const float* texels;          // ... and their texels
     const float* ewa_lut;         // MIPMap::EWALut, 128 floats
     const float* ibl_dist;        // the image based lights' CDF2Ds
+    const float* vol_density;     // heterogeneous medium: data[((z * ny + y) * nx + x) * nch + c]
     int32_t tlas_root;            // child reference of the TLAS root
     int32_t num_instances;
     int32_t num_lights;

@@ -469,6 +469,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     if ((st = upload_raw(ctx, desc->texels, desc->num_texels, desc->num_texels, &sc.texels)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.ewa_lut, &sc.ewa_lut)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.ibl_dist, &sc.ibl_dist)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.vol_density, &sc.vol_density)) != GBL_OK) return bail(st);
     sc.has_ibl = packed.has_ibl;
     ctx->has_images = desc->num_images > 0;
     sc.tlas_root = packed.tlas_root;
@@ -763,6 +764,12 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         return GBL_ERR_UNSUPPORTED;
     }
     const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY || stream_mode;
+    if (stream_mode && sc.volume.on != 0u && sc.volume.hetero != 0u) {
+        // the stream sampler lays a pixel's medium draws out ahead of time (9 per light sample); the ray marcher's count
+        // depends on what it meets (HeterogeneousVolumeRegion::transmittance, Renderer::Lv, GoblinRenderer.cpp:397-445)
+        ctx->error = "GBL_SAMPLES_STREAM does not cover a heterogeneous medium (data-dependent number of random numbers per sample): use the native or replay sampler";
+        return GBL_ERR_UNSUPPORTED;
+    }
     if (stream_mode) {
         if (p->schedule == GBL_SCHEDULE_WAVEFRONT) {
             ctx->error = "GBL_SAMPLES_STREAM runs on the megakernel schedule";

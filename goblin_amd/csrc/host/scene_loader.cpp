@@ -388,6 +388,7 @@ struct gbl_host_scene {
     std::vector<float> texels;
     std::vector<gbl_instance> instances;
     std::vector<gbl_light> lights;
+    std::vector<float> density;          // heterogeneous volume: the .vol file's voxels
     std::string output_path, default_output_path = "goblin.exr";
     gbl_scene_desc desc;
 };
@@ -472,8 +473,7 @@ private:
         const gbl_json::Value* node = root_.find("volume");
         if (!node) return GBL_OK;
         Params p(node);
-        if (p.get_string("type") == "heterogeneous")
-            return fail(GBL_ERR_UNSUPPORTED, "heterogeneous volumes (density grid files) are outside the device path");
+        if (p.get_string("type") == "heterogeneous") return read_heterogeneous_volume(p, v);
         v.type = GBL_VOLUME_HOMOGENEOUS;   // "homogeneous" and the unknown-type fallback
         const Vec att = p.get_vec(p.vec3s, "attenuation", vec(0, 0, 0)), alb = p.get_vec(p.vec3s, "albedo", vec(0, 0, 0)),
                   emi = p.get_vec(p.vec3s, "emission", vec(0, 0, 0)), lo = p.get_vec(p.vec3s, "box_min", vec(0, 0, 0)),
@@ -487,6 +487,50 @@ private:
         }
         v.g = p.get_float("g", 0.0f);
         v.sample_num = p.get_int("sample_num", 5);
+        read_trs(p, &v.to_world);
+        return GBL_OK;
+    }
+
+    // createHeterogeneousVolume (GoblinVolume.cpp:362-384) + loadVolFile (:222-257): Mitsuba's .vol grid, float32 encoding
+    // only -- any other encoding, an invalid header or a missing file falls back to the reference's one-cell grid of
+    // density 1 on [-1, 1]^3.
+    gbl_status read_heterogeneous_volume(Params& p, gbl_volume& v) {
+        v.type = GBL_VOLUME_HETEROGENEOUS;
+        int32_t nx = 1, ny = 1, nz = 1, nch = 1;
+        float lo[3] = {-1.0f, -1.0f, -1.0f}, hi[3] = {1.0f, 1.0f, 1.0f};
+        s_->density.assign(1, 1.0f);
+        const std::string path = resolve(p.get_string("density_grid"));
+        if (FILE* f = fopen(path.c_str(), "rb")) {
+            struct Header {   // VolHeader, GoblinVolume.cpp:68-133 (48 bytes)
+                char sig[4];
+                int32_t encoding, nx, ny, nz, nch;
+                float lo[3], hi[3];
+            } h;
+            static_assert(sizeof(Header) == 48, ".vol header");
+            if (fread(&h, sizeof(h), 1, f) == 1 && h.sig[0] == 'V' && h.sig[1] == 'O' && h.sig[2] == 'L' && (h.nch == 1 || h.nch == 3) && h.nx > 0 &&
+                h.ny > 0 && h.nz > 0 && h.encoding == 1) {
+                const size_t n = static_cast<size_t>(h.nx) * h.ny * h.nz * h.nch;
+                std::vector<float> data(n, 0.0f);
+                const size_t got = fread(data.data(), sizeof(float), n, f);   // (a short file leaves the tail as the reference's
+                (void)got;                                                     //  uninitialised buffer would: zeros here)
+                s_->density.swap(data);
+                nx = h.nx, ny = h.ny, nz = h.nz, nch = h.nch;
+                for (int i = 0; i < 3; ++i) lo[i] = h.lo[i], hi[i] = h.hi[i];
+            }
+            fclose(f);
+        }
+        const Vec alb = p.get_vec(p.vec3s, "albedo", vec(0, 0, 0));
+        for (int i = 0; i < 3; ++i) {
+            v.albedo[i] = alb.v[i];
+            v.box_min[i] = lo[i];
+            v.box_max[i] = hi[i];
+        }
+        v.g = p.get_float("g", 0.0f);
+        v.step_size = p.get_float("step_size", 0.1f);
+        v.sample_num = p.get_int("sample_num", 5);
+        v.grid[0] = nx, v.grid[1] = ny, v.grid[2] = nz;
+        v.grid_channels = nch;
+        v.density = s_->density.data();
         read_trs(p, &v.to_world);
         return GBL_OK;
     }

@@ -60,9 +60,60 @@ __device__ __forceinline__ bool vol_contains(const DevVolume& v, F3 p) {
     const F3 q = xf_point(v.inv, p);
     return v.lo[0] <= q.x && q.x <= v.hi[0] && v.lo[1] <= q.y && q.y <= v.hi[1] && v.lo[2] <= q.z && q.z <= v.hi[2];
 }
-// HomogeneousVolumeRegion::transmittance: Beer's law over the segment inside the box
-__device__ __forceinline__ F3 vol_transmittance(const DevVolume& v, F3 o, F3 d, float mint, float maxt) {
+// VolumeGrid::getVoxel / eval (GoblinVolume.cpp:148-196): trilinear interpolation of the density grid at a point of the
+// region's own space.  (As written there the index scale is  normalize * n - 0.5: the half-cell shift multiplies.)
+__device__ __forceinline__ F3 grid_voxel(const DevVolume& v, const float* density, int x, int y, int z) {
+    if (x < 0 || x >= v.nx || y < 0 || y >= v.ny || z < 0 || z >= v.nz) return f3(0.0f, 0.0f, 0.0f);
+    if (v.nch == 1) {
+        const float c = density[z * v.nx * v.ny + y * v.nx + x];
+        return f3(c, c, c);
+    }
+    const int off = 3 * (z * v.nx * v.ny + y * v.nx + x);
+    return f3(density[off], density[off + 1], density[off + 2]);
+}
+__device__ __forceinline__ F3 f3_lerp(float t, F3 a, F3 b) { return (1.0f - t) * a + t * b; }   // lerp<T>, GoblinUtils.h:109-112
+__device__ __noinline__ F3 grid_eval(const DevVolume& v, const float* density, F3 p_local) {
+    F3 f = f3(p_local.x - v.lo[0], p_local.y - v.lo[1], p_local.z - v.lo[2]);
+    f.x *= v.normalize[0] * v.nx - 0.5f;
+    f.y *= v.normalize[1] * v.ny - 0.5f;
+    f.z *= v.normalize[2] * v.nz - 0.5f;
+    const int ix = static_cast<int>(floorf(f.x)), iy = static_cast<int>(floorf(f.y)), iz = static_cast<int>(floorf(f.z));
+    const float dx = f.x - ix, dy = f.y - iy, dz = f.z - iz;
+    const F3 d00 = f3_lerp(dx, grid_voxel(v, density, ix, iy, iz), grid_voxel(v, density, ix + 1, iy, iz));
+    const F3 d10 = f3_lerp(dx, grid_voxel(v, density, ix, iy + 1, iz), grid_voxel(v, density, ix + 1, iy + 1, iz));
+    const F3 d01 = f3_lerp(dx, grid_voxel(v, density, ix, iy, iz + 1), grid_voxel(v, density, ix + 1, iy, iz + 1));
+    const F3 d11 = f3_lerp(dx, grid_voxel(v, density, ix, iy + 1, iz + 1), grid_voxel(v, density, ix + 1, iy + 1, iz + 1));
+    return f3_lerp(dz, f3_lerp(dy, d00, d10), f3_lerp(dy, d01, d11));
+}
+// HeterogeneousVolumeRegion::getAttenuation (:313-321)
+__device__ __forceinline__ F3 hetero_attenuation(const DevScene& sc, F3 p) {
+    const DevVolume& v = sc.volume;
+    const F3 q = xf_point(v.inv, p);
+    const bool inside = v.lo[0] <= q.x && q.x <= v.hi[0] && v.lo[1] <= q.y && q.y <= v.hi[1] && v.lo[2] <= q.z && q.z <= v.hi[2];
+    return inside ? grid_eval(v, sc.vol_density, q) : f3(0.0f, 0.0f, 0.0f);
+}
+// HomogeneousVolumeRegion::transmittance (GoblinVolume.cpp:25-36): Beer's law over the segment inside the box, no random
+// number.  HeterogeneousVolumeRegion::transmittance (:323-341): a jittered ray march -- one random number -- and BLACK,
+// not white, for a ray that misses the region.
+__device__ __forceinline__ F3 vol_transmittance(const DevScene& sc, F3 o, F3 d, float mint, float maxt, VolRand& rnd) {
+    const DevVolume& v = sc.volume;
     float tmin, tmax;
+    if (v.hetero != 0u) {
+        if (!vol_intersect(v, o, d, mint, maxt, &tmin, &tmax)) return f3(0.0f, 0.0f, 0.0f);
+        const float step = v.step;
+        float t = tmin;
+        const float jitter = rnd.f() * step;
+        F3 tau = jitter * hetero_attenuation(sc, o + t * d);
+        t += jitter;
+        while (t + step < tmax) {
+            const F3 a = step * hetero_attenuation(sc, o + t * d);
+            tau = f3(tau.x + a.x, tau.y + a.y, tau.z + a.z);
+            t += step;
+        }
+        const F3 a = (tmax - t) * hetero_attenuation(sc, o + t * d);
+        tau = f3(tau.x + a.x, tau.y + a.y, tau.z + a.z);
+        return f3(gbl_expf(-tau.x), gbl_expf(-tau.y), gbl_expf(-tau.z));
+    }
     if (!vol_intersect(v, o, d, mint, maxt, &tmin, &tmax)) return f3(1.0f, 1.0f, 1.0f);
     const float len = length((o + tmax * d) - (o + tmin * d));
     const F3 tau = len * f3(v.attenuation[0], v.attenuation[1], v.attenuation[2]);
@@ -127,6 +178,61 @@ __device__ __forceinline__ bool vol_shadow_occluded(const DevScene& sc, int li, 
     return ref_leaf_reached(sc, h.tri, xf_point(in.inv, p), xf_vector(in.inv, wi), 0.0f, maxt);
 }
 
+// Renderer::Lv, heterogeneous branch (GoblinRenderer.cpp:397-445): march the camera ray in steps of step_size from a jittered
+// start; at every sample point one light sample (pick + LightSample: 4 random numbers, and one more for the shadow ray's
+// own jittered transmittance when it is unoccluded).
+template <bool STATS, class STK>
+__device__ __forceinline__ F3 volume_lv_hetero(const DevScene& sc, F3 o, F3 d, float tmin, float tmax, VolRand& rnd, const STK& stk, LaneCounters& cnt) {
+    const DevVolume& vol = sc.volume;
+    const F3 albedo = f3(vol.albedo[0], vol.albedo[1], vol.albedo[2]);
+    F3 Lv = f3(0, 0, 0);
+    const float step = vol.step;
+    F3 p_prev = o + tmin * d;
+    float t = tmin + step * rnd.f();
+    F3 p = o + t * d;
+    F3 transmittance = f3(1.0f, 1.0f, 1.0f);
+    while (t <= tmax) {
+        const F3 sigma_t = hetero_attenuation(sc, p);   // HeterogeneousVolumeRegion::eval (:297-311)
+        const F3 sigma_s = sigma_t * albedo;
+        const F3 tau = sigma_t * length(p - p_prev);
+        transmittance = transmittance * f3(gbl_expf(-tau.x), gbl_expf(-tau.y), gbl_expf(-tau.z));
+        {   // Lv += transmittance * emission, emission = Black
+            const F3 e = transmittance * f3(0.0f, 0.0f, 0.0f);
+            Lv = f3(Lv.x + e.x, Lv.y + e.y, Lv.z + e.z);
+        }
+        const float pick = rnd.f();
+        int li = -1;
+        float pick_pdf = 0.0f;
+        if (sc.num_lights != 0) {
+            li = 0;
+            for (int k = 1; k <= sc.num_lights; ++k)
+                if (sc.light_cdf[k] < pick) li = k;
+            if (li >= sc.num_lights) li = sc.num_lights - 1;
+            pick_pdf = sc.light_pick_pdf[li];
+        }
+        if (li >= 0 && pick_pdf != 0.0f) {
+            const DevLight& light = sc.lights[li];
+            const float u_comp = rnd.f(), u1 = rnd.f(), u2 = rnd.f();   // LightSample ls(rng)
+            LightSampleOut ls;
+            light_sample<true>(sc, light, p, 0.0f, u_comp, u1, u2, ls);
+            if (!is_black(ls.L) && ls.pdf > 0.0f) {
+                if (STATS) cnt.shadow += 1;
+                if (!vol_shadow_occluded<STATS>(sc, li, p, ls.wi, ls.maxt, stk, cnt)) {
+                    const F3 tr_light = vol_transmittance(sc, p, ls.wi, 0.0f, ls.maxt, rnd);
+                    const F3 Ld = div(tr_light * ls.L, pick_pdf * ls.pdf);
+                    const float phase = vol_contains(vol, p) ? phase_hg(d, ls.wi, vol.g) : 0.0f;   // VolumeRegion::phase
+                    const F3 term = transmittance * sigma_s * phase * Ld;
+                    Lv = f3(Lv.x + term.x, Lv.y + term.y, Lv.z + term.z);
+                }
+            }
+        }
+        t += step;
+        p_prev = p;
+        p = o + t * d;
+    }
+    return step * Lv;
+}
+
 // Renderer::Lv, homogeneous branch (GoblinRenderer.cpp:298-391).  (o, d, mint, maxt): the camera ray after Li.
 template <bool STATS, class STK>
 __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mint, float maxt, VolRand& rnd, const STK& stk, LaneCounters& cnt) {
@@ -134,6 +240,7 @@ __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mi
     float tmin, tmax;
     if (!vol_intersect(vol, o, d, mint, maxt, &tmin, &tmax)) return f3(0, 0, 0);
     if ((tmax - tmin) < 1e-5f) return f3(0, 0, 0);
+    if (vol.hetero != 0u) return volume_lv_hetero<STATS>(sc, o, d, tmin, tmax, rnd, stk, cnt);
     const F3 att = f3(vol.attenuation[0], vol.attenuation[1], vol.attenuation[2]), sca = f3(vol.scatter[0], vol.scatter[1], vol.scatter[2]);
     const F3 zero = f3(0, 0, 0);
     F3 Lv = f3(0, 0, 0);
@@ -166,7 +273,7 @@ __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mi
             if (!is_black(ls.L) && ls.pdf > 0.0f) {
                 if (STATS) cnt.shadow += 1;
                 if (!vol_shadow_occluded<STATS>(sc, li, p_e, ls.wi, ls.maxt, stk, cnt)) {
-                    const F3 tr_light = vol_transmittance(vol, p_e, ls.wi, 0.0f, ls.maxt);
+                    const F3 tr_light = vol_transmittance(sc, p_e, ls.wi, 0.0f, ls.maxt, rnd);
                     const F3 Ld = div(tr_light * ls.L, pick_pdf * ls.pdf);
                     const float phase = in_e ? phase_hg(d, ls.wi, vol.g) : 0.0f;   // VolumeRegion::phase
                     const float sig = sss_luminance(sigma_te);
@@ -194,7 +301,7 @@ __device__ __forceinline__ F3 volume_lv(const DevScene& sc, F3 o, F3 d, float mi
             if (!is_black(ls.L) && ls.pdf > 0.0f) {
                 if (STATS) cnt.shadow += 1;
                 if (!vol_shadow_occluded<STATS>(sc, li, p_d, ls.wi, ls.maxt, stk, cnt)) {
-                    const F3 tr_light = vol_transmittance(vol, p_d, ls.wi, 0.0f, ls.maxt);
+                    const F3 tr_light = vol_transmittance(sc, p_d, ls.wi, 0.0f, ls.maxt, rnd);
                     const F3 Ld = div(tr_light * ls.L, pick_pdf * ls.pdf);
                     const float phase = in_d ? phase_hg(d, ls.wi, vol.g) : 0.0f;
                     const float pdf_te2 = D / ((theta_b - theta_a) * (D * D + td * td));

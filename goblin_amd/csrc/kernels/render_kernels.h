@@ -325,7 +325,7 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
             rnd.raw = sv.raw + sv.off[k];
             rnd.key = 0u;
             rnd.i = 0u;
-            const F3 tr = vol_transmittance(sc.volume, o, d, mint, sv.t[k]);
+            const F3 tr = vol_transmittance(sc, o, d, mint, sv.t[k], rnd);
             const F3 Lv = volume_lv<STATS>(sc, o, d, mint, sv.t[k], rnd, stk, cnt);
             const float4 L = li[k];
             li[k] = make_float4(1.0f * (tr.x * L.x + Lv.x), 1.0f * (tr.y * L.y + Lv.y), 1.0f * (tr.z * L.z + Lv.z), L.w);

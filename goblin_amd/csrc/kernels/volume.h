@@ -54,8 +54,8 @@ __global__ __launch_bounds__(GBL_BLOCK) void vol_kernel(DevScene sc, RenderArgs 
             LaneCounters scratch = {};   // the integrator's own query: not counted twice
             if (trace<false, false, true>(sc, o, d, mint, INFINITY, stk, hit, scratch)) maxt = hit.t;
         }
-        const F3 tr = vol_transmittance(sc.volume, o, d, mint, maxt);
         VolRand rnd = vol_rand_hashed(image_x, image_y);
+        const F3 tr = vol_transmittance(sc, o, d, mint, maxt, rnd);   // (Renderer::transmittance comes first: the heterogeneous region's jitter is the sample's first draw)
         const F3 Lv = volume_lv<STATS>(sc, o, d, mint, maxt, rnd, stk, cnt);
         float4* q = reinterpret_cast<float4*>(ra.vol) + 2 * static_cast<size_t>(out_index);
         q[0] = make_float4(tr.x, tr.y, tr.z, 0.0f);

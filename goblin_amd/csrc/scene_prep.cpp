@@ -1164,9 +1164,20 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
 
     // ---- participating medium
     memset(&out->volume, 0, sizeof(out->volume));
-    if (d->volume.type == GBL_VOLUME_HOMOGENEOUS) {
+    if (d->volume.type == GBL_VOLUME_HOMOGENEOUS || d->volume.type == GBL_VOLUME_HETEROGENEOUS) {
         DevVolume& v = out->volume;
         v.on = 1u;
+        if (d->volume.type == GBL_VOLUME_HETEROGENEOUS) {
+            const gbl_volume& g = d->volume;
+            if (g.grid[0] <= 0 || g.grid[1] <= 0 || g.grid[2] <= 0 || (g.grid_channels != 1 && g.grid_channels != 3) || g.density == nullptr) {
+                *err = "heterogeneous volume: the density grid needs positive dimensions, 1 or 3 channels and its data";
+                return GBL_ERR_INVALID;
+            }
+            v.hetero = 1u;
+            v.step = g.step_size;
+            v.nx = g.grid[0], v.ny = g.grid[1], v.nz = g.grid[2], v.nch = g.grid_channels;
+            out->vol_density.assign(g.density, g.density + static_cast<size_t>(v.nx) * v.ny * v.nz * v.nch);
+        }
         for (int k = 0; k < 3; ++k) {
             v.attenuation[k] = d->volume.attenuation[k];
             v.scatter[k] = d->volume.attenuation[k] * d->volume.albedo[k];
@@ -1174,6 +1185,10 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             v.lo[k] = std::min(d->volume.box_min[k], d->volume.box_max[k]);   // BBox(p1, p2), GoblinBBox.h:20-23
             v.hi[k] = std::max(d->volume.box_min[k], d->volume.box_max[k]);
             v.bound_center[k] = 0.5f * (scene_bound.lo[k] + scene_bound.hi[k]);
+        }
+        for (int k = 0; k < 3; ++k) {
+            v.albedo[k] = d->volume.albedo[k];
+            v.normalize[k] = 1.0f / (v.hi[k] - v.lo[k]);
         }
         v.g = d->volume.g;
         v.sample_num = d->volume.sample_num;

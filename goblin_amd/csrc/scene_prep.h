@@ -18,7 +18,7 @@ struct PackedScene {
     std::vector<DevMaterial> materials;
     std::vector<DevTexture> textures;
     std::vector<DevImage> images;
-    std::vector<float> ewa_lut, ibl_dist;
+    std::vector<float> ewa_lut, ibl_dist, vol_density;
     int32_t has_ibl = 0;
     std::vector<DevLight> lights;
     std::vector<DevLightTri> light_tris;

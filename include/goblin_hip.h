@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 10
+#define GBL_ABI_VERSION 11
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -263,7 +263,8 @@ typedef struct gbl_render_setting {
  * "heterogeneous" (a density grid file) is GBL_ERR_UNSUPPORTED. */
 typedef enum gbl_volume_type {
     GBL_VOLUME_NONE = 0,
-    GBL_VOLUME_HOMOGENEOUS = 1
+    GBL_VOLUME_HOMOGENEOUS = 1,
+    GBL_VOLUME_HETEROGENEOUS = 2   /* HeterogeneousVolumeRegion (GoblinVolume.h:106-122): sigma_t from a density grid, ray marched */
 } gbl_volume_type;
 typedef struct gbl_volume {
     uint32_t type;          /* gbl_volume_type                                              */
@@ -272,8 +273,13 @@ typedef struct gbl_volume {
     float emission[3];
     float g;                /* Henyey-Greenstein asymmetry ("g", default 0)                 */
     int32_t sample_num;     /* light samples along the camera ray ("sample_num", default 5) */
-    float box_min[3], box_max[3]; /* the region, in its own space                           */
+    float box_min[3], box_max[3]; /* the region, in its own space (heterogeneous: the grid's bounding box) */
     gbl_trs to_world;
+    /* GBL_VOLUME_HETEROGENEOUS (createHeterogeneousVolume, GoblinVolume.cpp:362-384): attenuation / emission unused */
+    float step_size;        /* ray marching step in world units ("step_size", default 0.1)   */
+    int32_t grid[3];        /* cells along x, y, z of the density grid (.vol file, float32)  */
+    int32_t grid_channels;  /* 1 or 3                                                        */
+    const float* density;   /* data[((z * ny + y) * nx + x) * channels + c]                  */
 } gbl_volume;
 
 typedef struct gbl_scene_desc {

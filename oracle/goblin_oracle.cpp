@@ -492,12 +492,18 @@ struct orc_scene {
     std::vector<std::vector<Cdf>> ibl_rows;      // ... and mConditionalDist
     bool has_masks = false;
     std::vector<uint32_t> light_samples;   // Light::getSamplesNum per light (the Whitted renderer's quota)
-    // HomogeneousVolumeRegion (GoblinVolume.h:72-112)
+    // HomogeneousVolumeRegion (GoblinVolume.h:72-112) / HeterogeneousVolumeRegion + VolumeGrid (GoblinVolume.cpp:135-341)
     struct Volume {
         bool on = false;
+        bool hetero = false;
         Col attenuation, scatter, emission;
+        Col albedo;
         float g = 0.0f;
         int sample_num = 0;
+        float step = 0.0f;
+        int nx = 0, ny = 0, nz = 0, nch = 0;
+        V3 normalize;                 // VolumeGrid::mNormalizeTerm: 1 / (bbox extent)
+        std::vector<float> density;
         Box box;
         Xform xf;
     } volume;
@@ -751,9 +757,16 @@ void prepare(orc_scene* s) {
     s->tlas.build(iboxes);
     // lights
     s->lights.resize(d.num_lights);
-    if (d.volume.type == GBL_VOLUME_HOMOGENEOUS) {
+    if (d.volume.type == GBL_VOLUME_HOMOGENEOUS || d.volume.type == GBL_VOLUME_HETEROGENEOUS) {
         orc_scene::Volume& v = s->volume;
         v.on = true;
+        v.hetero = d.volume.type == GBL_VOLUME_HETEROGENEOUS;
+        v.albedo = Col(d.volume.albedo[0], d.volume.albedo[1], d.volume.albedo[2]);
+        if (v.hetero) {
+            v.step = d.volume.step_size;
+            v.nx = d.volume.grid[0], v.ny = d.volume.grid[1], v.nz = d.volume.grid[2], v.nch = d.volume.grid_channels;
+            v.density.assign(d.volume.density, d.volume.density + static_cast<size_t>(v.nx) * v.ny * v.nz * v.nch);
+        }
         v.attenuation = Col(d.volume.attenuation[0], d.volume.attenuation[1], d.volume.attenuation[2]);
         v.scatter = v.attenuation * Col(d.volume.albedo[0], d.volume.albedo[1], d.volume.albedo[2]);   // mScatter(attenuation * albedo)
         v.emission = Col(d.volume.emission[0], d.volume.emission[1], d.volume.emission[2]);
@@ -764,6 +777,8 @@ void prepare(orc_scene* s) {
         v.box.lo = V3(std::min(a[0], b[0]), std::min(a[1], b[1]), std::min(a[2], b[2]));   // BBox(p1, p2), GoblinBBox.h:20-23
         v.box.hi = V3(std::max(a[0], b[0]), std::max(a[1], b[1]), std::max(a[2], b[2]));
         v.xf.set(d.volume.to_world.position, d.volume.to_world.orientation, d.volume.to_world.scale);
+        const V3 dim = v.box.hi - v.box.lo;
+        v.normalize = V3(1.0f / dim.x, 1.0f / dim.y, 1.0f / dim.z);
     }
     s->light_samples.resize(d.num_lights);
     for (uint32_t i = 0; i < d.num_lights; ++i) s->light_samples[i] = d.lights[i].sample_num;
@@ -2985,6 +3000,7 @@ struct VolRand {
     }
     float f() { return c->rng ? c->rng->f() : nat_u01(nat_mix(key, 0x766f6c00u + i++)); }
 };
+inline float vol_rand_next(VolRand& rnd);
 inline bool box_intersect(const Box& b, V3 o, V3 d, float mint, float maxt, float* tmin, float* tmax) {   // BBox::intersect, GoblinBBox.cpp:57-77
     float t0 = mint, t1 = maxt;
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z};
@@ -3009,8 +3025,60 @@ inline bool vol_contains(const orc_scene* s, V3 p) {   // BBox::contain(invertPo
     V3 q = v.xf.invert_point(p);
     return v.box.lo.x <= q.x && q.x <= v.box.hi.x && v.box.lo.y <= q.y && q.y <= v.box.hi.y && v.box.lo.z <= q.z && q.z <= v.box.hi.z;
 }
-inline Col vol_transmittance(const orc_scene* s, const Ray& r) {   // HomogeneousVolumeRegion::transmittance, :25-36
+// VolumeGrid::getVoxel / eval (GoblinVolume.cpp:148-196): trilinear interpolation of the density at a point of the region's
+// own space.  (As written there the index scale is  normalize * n - 0.5  -- the half-cell shift multiplies.)
+inline Col grid_voxel(const orc_scene::Volume& v, int x, int y, int z) {
+    if (x < 0 || x >= v.nx || y < 0 || y >= v.ny || z < 0 || z >= v.nz) return Col(0.0f);
+    if (v.nch == 1) return Col(v.density[z * v.nx * v.ny + y * v.nx + x]);
+    if (v.nch == 3) {
+        int off = 3 * (z * v.nx * v.ny + y * v.nx + x);
+        return Col(v.density[off], v.density[off + 1], v.density[off + 2]);
+    }
+    return Col(0.0f);
+}
+inline Col col_lerp(float t, Col a, Col b) { return (1.0f - t) * a + t * b; }   // lerp<T>, GoblinUtils.h:109-112
+inline Col grid_eval(const orc_scene::Volume& v, V3 p_local) {
+    V3 f = p_local - v.box.lo;
+    f.x *= v.normalize.x * v.nx - 0.5f;
+    f.y *= v.normalize.y * v.ny - 0.5f;
+    f.z *= v.normalize.z * v.nz - 0.5f;
+    int ix = floor_int(f.x), iy = floor_int(f.y), iz = floor_int(f.z);
+    float dx = f.x - ix, dy = f.y - iy, dz = f.z - iz;
+    Col d00 = col_lerp(dx, grid_voxel(v, ix, iy, iz), grid_voxel(v, ix + 1, iy, iz));
+    Col d10 = col_lerp(dx, grid_voxel(v, ix, iy + 1, iz), grid_voxel(v, ix + 1, iy + 1, iz));
+    Col d01 = col_lerp(dx, grid_voxel(v, ix, iy, iz + 1), grid_voxel(v, ix + 1, iy, iz + 1));
+    Col d11 = col_lerp(dx, grid_voxel(v, ix, iy + 1, iz + 1), grid_voxel(v, ix + 1, iy + 1, iz + 1));
+    Col d0 = col_lerp(dy, d00, d10);
+    Col d1 = col_lerp(dy, d01, d11);
+    return col_lerp(dz, d0, d1);
+}
+// HeterogeneousVolumeRegion::getAttenuation (:313-321)
+inline Col hetero_attenuation(const orc_scene* s, V3 p) {
+    const auto& v = s->volume;
+    V3 q = v.xf.invert_point(p);
+    bool inside = v.box.lo.x <= q.x && q.x <= v.box.hi.x && v.box.lo.y <= q.y && q.y <= v.box.hi.y && v.box.lo.z <= q.z && q.z <= v.box.hi.z;
+    return inside ? grid_eval(v, q) : Col(0.0f);
+}
+struct VolRand;
+inline float vol_rand_next(VolRand& rnd);
+// HomogeneousVolumeRegion::transmittance (:25-36): Beer's law, no random number.  HeterogeneousVolumeRegion::transmittance
+// (:323-341): a jittered ray march -- one random number -- and BLACK, not white, for a ray that misses the region.
+inline Col vol_transmittance(const orc_scene* s, const Ray& r, VolRand& rnd) {
     float tmin, tmax;
+    if (s->volume.hetero) {
+        if (!vol_intersect(s, r, &tmin, &tmax)) return Col(0.0f);
+        const float step = s->volume.step;
+        float t = tmin;
+        float jitter = vol_rand_next(rnd) * step;
+        Col tau = jitter * hetero_attenuation(s, r.o + t * r.d);
+        t += jitter;
+        while (t + step < tmax) {
+            tau += step * hetero_attenuation(s, r.o + t * r.d);
+            t += step;
+        }
+        tau += (tmax - t) * hetero_attenuation(s, r.o + t * r.d);
+        return Col(std::exp(-tau.r), std::exp(-tau.g), std::exp(-tau.b));
+    }
     if (!vol_intersect(s, r, &tmin, &tmax)) return Col(1.0f);
     Col tau = length((r.o + tmax * r.d) - (r.o + tmin * r.d)) * s->volume.attenuation;
     return Col(std::exp(-tau.r), std::exp(-tau.g), std::exp(-tau.b));
@@ -3049,6 +3117,51 @@ V3 light_sample_position(const orc_scene* s, int li, float u_comp, float u1, flo
     }
     return l.pos;
 }
+inline float vol_rand_next(VolRand& rnd) { return rnd.f(); }
+// Renderer::Lv, heterogeneous branch (GoblinRenderer.cpp:397-445): march the camera ray in steps of step_size from a
+// jittered start; at every sample point one light sample (pick + LightSample: 4 random numbers, one more for the shadow
+// ray's own jittered transmittance when it is unoccluded).
+Col volume_lv_hetero(LiCtx* c, const Ray& ray, float tmin, float tmax, VolRand& rnd) {
+    const orc_scene* s = c->s;
+    const auto& vol = s->volume;
+    Col Lv(0.0f);
+    const float step = vol.step;
+    V3 p_prev = ray.o + tmin * ray.d;
+    float t = tmin + step * rnd.f();
+    V3 p = ray.o + t * ray.d;
+    Col transmittance(1.0f);
+    while (t <= tmax) {
+        // HeterogeneousVolumeRegion::eval (:297-311)
+        Col sigma_t = hetero_attenuation(s, p);
+        Col sigma_s = sigma_t * vol.albedo;
+        Col emission(0.0f);
+        Col tau = sigma_t * length(p - p_prev);
+        transmittance *= Col(std::exp(-tau.r), std::exp(-tau.g), std::exp(-tau.b));
+        Lv += transmittance * emission;
+        float pick = rnd.f();
+        float pick_pdf = 0.0f;
+        int light = s->lights.empty() ? -1 : s->light_power.sample_discrete(pick, &pick_pdf);
+        if (light >= 0 && pick_pdf != 0.0f) {
+            float u_comp = rnd.f(), u1 = rnd.f(), u2 = rnd.f();   // LightSample ls(rng)
+            V3 wi;
+            float light_pdf_v;
+            Ray shadow;
+            Col L = light_sample(s, light, p, 0.0f, u_comp, u1, u2, &wi, &light_pdf_v, &shadow);
+            if (L != BLACK && light_pdf_v > 0.0f) {
+                if (!scene_occluded(s, shadow, &c->cnt)) {
+                    Col tr_light = vol_transmittance(s, shadow, rnd);
+                    Col Ld = tr_light * L / (pick_pdf * light_pdf_v);
+                    float phase = vol_contains(s, p) ? phase_hg(ray.d, wi, vol.g) : 0.0f;   // VolumeRegion::phase
+                    Lv += transmittance * sigma_s * phase * Ld;
+                }
+            }
+        }
+        t += step;
+        p_prev = p;
+        p = ray.o + t * ray.d;
+    }
+    return step * Lv;
+}
 // Renderer::Lv, homogeneous branch (GoblinRenderer.cpp:298-391)
 Col volume_lv(LiCtx* c, const Ray& ray, VolRand& rnd) {
     const orc_scene* s = c->s;
@@ -3056,6 +3169,7 @@ Col volume_lv(LiCtx* c, const Ray& ray, VolRand& rnd) {
     float tmin, tmax;
     if (!vol.on || !vol_intersect(s, ray, &tmin, &tmax)) return BLACK;
     if ((tmax - tmin) < 1e-5f) return BLACK;
+    if (vol.hetero) return volume_lv_hetero(c, ray, tmin, tmax, rnd);
     Col Lv(0.0f);
     const int n_samples = vol.sample_num;
     for (int i = 0; i < n_samples; ++i) {
@@ -3083,7 +3197,7 @@ Col volume_lv(LiCtx* c, const Ray& ray, VolRand& rnd) {
             Col Le = light_sample(s, light, p_e, 0.0f, e_comp, e_u1, e_u2, &wi, &light_pdf_v, &shadow);
             if (Le != BLACK && light_pdf_v > 0.0f) {
                 if (!scene_occluded(s, shadow, &c->cnt)) {
-                    Col tr_light = vol_transmittance(s, shadow);
+                    Col tr_light = vol_transmittance(s, shadow, rnd);
                     Col Ld = tr_light * Le / (pick_pdf * light_pdf_v);
                     float phase = in_e ? phase_hg(ray.d, wi, vol.g) : 0.0f;   // VolumeRegion::phase(p, wi, wo), GoblinVolume.cpp:17-23
                     float sig = luminance(sigma_te);
@@ -3111,7 +3225,7 @@ Col volume_lv(LiCtx* c, const Ray& ray, VolRand& rnd) {
             Col Ldist = light_sample(s, light, p_d, 0.0f, d_comp, d_u1, d_u2, &wi, &light_pdf_v, &shadow);
             if (Ldist != BLACK && light_pdf_v > 0.0f) {
                 if (!scene_occluded(s, shadow, &c->cnt)) {
-                    Col tr_light = vol_transmittance(s, shadow);
+                    Col tr_light = vol_transmittance(s, shadow, rnd);
                     Col Ld = tr_light * Ldist / (pick_pdf * light_pdf_v);
                     float phase = in_d ? phase_hg(ray.d, wi, vol.g) : 0.0f;
                     float pdf_te2 = D / ((theta_b - theta_a) * (D * D + td * td));
@@ -3130,7 +3244,7 @@ inline Col task_sample(LiCtx* c, const float* rec, Col L) {
         Ray ray = camera_ray(c->s, rec[0], rec[1], rec[2], rec[3], nullptr);
         ray.maxt = c->primary_maxt;
         VolRand rnd(c, rec);
-        tr = vol_transmittance(c->s, ray);   // Renderer::transmittance: the homogeneous region draws nothing
+        tr = vol_transmittance(c->s, ray, rnd);   // Renderer::transmittance: the homogeneous region draws nothing, the heterogeneous one its jitter
         Lv = volume_lv(c, ray, rnd);
     }
     Col TL = tr * L;

@@ -111,6 +111,13 @@ CASES = {
     # AORenderer::Li draws nothing from the tile's generator, WhittedRenderer::Li 6 floats per (light, slot) and per level
     "volume_ao_spot": ("volume", dict(ov((48, 48), 4, method="ao", ao=4), lights=SPOT), 0, False),
     "volume_whitted_spot": ("volume", dict(ov((48, 48), 4, 3, method="whitted"), lights=SPOT), 0, False),
+    # a heterogeneous medium (HeterogeneousVolumeRegion: .vol density grid, trilinear lookups, ray-marched transmittance and
+    # Lv with a data-dependent number of random numbers per sample); one-channel grid under the path tracer, three-channel
+    # grid in a rotated region under Whitted and AO
+    "hetero_pt": ("hetero", ov((48, 48), 4, 4), 0, False),
+    "hetero_spot": ("hetero", dict(ov((48, 48), 4, 4), lights=SPOT), 0, False),
+    "hetero_tint_whitted": ("hetero_tint", ov((40, 40), 4, 3, method="whitted"), 0, False),
+    "hetero_tint_ao": ("hetero_tint", ov((40, 40), 4, method="ao", ao=4), 0, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
     # subsurface materials under the Whitted renderer: Lsubsurface at every level of the recursion (here also behind the
     # mirror and the glass), SubsurfaceMaterial's BSDFAll lobe never matching the non-specular / specular requests
@@ -139,6 +146,8 @@ def absolute_scene(scene, overrides, path):
         for g in doc.get(section, []):
             if "file" in g:
                 g["file"] = os.path.join(os.path.dirname(src), g["file"])
+    if "density_grid" in doc.get("volume", {}):   # the heterogeneous medium's .vol grid
+        doc["volume"]["density_grid"] = os.path.join(os.path.dirname(src), doc["volume"]["density_grid"])
     with open(path, "w") as f:
         json.dump(doc, f)
 

@@ -329,6 +329,40 @@ def test_participating_medium_matches_oracle(torch, schedule, ov):
     assert flips <= LI_FLIP_TOL and helpers.rel_l2(li[:, :3], li_ref[:, :3]) <= LI_RELL2_TOL
 
 
+@pytest.mark.parametrize("name,ov", [("hetero", gs.config_overrides(resolution=(40, 40), spp=9, depth=4)),
+                                     ("hetero", dict(gs.config_overrides(resolution=(32, 32), spp=4, depth=3), **SPOT_ONLY)),
+                                     ("hetero_tint", gs.config_overrides(resolution=(32, 32), spp=4, depth=3, method="whitted")),
+                                     ("hetero_tint", gs.config_overrides(resolution=(32, 32), spp=4, method="ao", ao_samples=4))])
+def test_heterogeneous_medium_matches_oracle(torch, schedule, name, ov):
+    """HeterogeneousVolumeRegion (GoblinVolume.cpp:283-341) behind RenderTask's tr * L + Lv: density from a .vol grid
+    (trilinear, one and three channels), jittered ray-marched transmittance, Renderer::Lv's marching branch with its
+    data-dependent number of draws per sample (hashed in sequence here and in the oracle; the oracle's own stream mode is
+    pinned to the compiled reference's Film in tests/test_oracle_vs_reference.py).  Same radiance bit for bit."""
+    seed = 17
+    scene = gs.load_scene(name, ov)
+    o = ob.Oracle(scene)
+    r = make_renderer(scene, schedule)
+    samples = o.native_samples(seed)
+    li_ref, _ = o.li_replay(samples, threads=4)
+    out = r.render(seed=seed, want_li=True)
+    li = out["li"].cpu().numpy()
+    flips = helpers.li_mismatch_fraction(li, li_ref)
+    rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
+    film_ref = o.splat(samples, li_ref)
+    frel = helpers.rel_l2(ob.normalize_film(out["film"].numpy()), ob.normalize_film(film_ref))
+    print(name, "heterogeneous medium: flips", flips, "sample relL2", rel, "film relL2", frel, "mean", li_ref[:, :3].mean())
+    assert li_ref[:, :3].mean() > 1e-3
+    assert flips <= LI_FLIP_TOL and rel <= LI_RELL2_TOL and frel <= FILM_RELL2_TOL
+
+
+def test_heterogeneous_medium_is_refused_under_the_stream_sampler(torch):
+    """The stream sampler lays a pixel's medium draws out ahead of time; the ray marcher's count depends on the data."""
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("hetero", gs.config_overrides(resolution=(16, 16), spp=1, depth=2))
+    with pytest.raises(RuntimeError, match="heterogeneous"):
+        HipPathTracer(scene, 0).render(sampler="stream")
+
+
 def test_headline_scene_radiance_is_bit_identical(torch, schedule):
     """bunny.json (Lambert floor, glass bunny, spot light): every float operation on its paths rounds as on the host --
     IEEE sqrt / divide, glibc's sinf / cosf restated (refmath.h), the reference's visiting order for exact-t ties -- so

@@ -74,7 +74,6 @@ def test_render_methods():
 
 def test_out_of_scope_features_fail_loudly():
     cases = [
-        minimal(volume={"type": "heterogeneous", "density_grid": "x.vol"}),
         minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
     ]
     for doc in cases:
@@ -399,3 +398,28 @@ def test_repeated_json_key_keeps_its_last_value_and_nesting_is_bounded():
     with pytest.raises(_abi.GoblinError) as e:
         gs.load_scene_text("[" * 100000, MODELS)
     assert "nested too deeply" in str(e.value)
+
+
+def test_heterogeneous_volume_and_vol_grid(tmp_path):
+    """createHeterogeneousVolume + loadVolFile (GoblinVolume.cpp:222-257, 362-384): float32 .vol grids, the grid's bounding
+    box as the region, step_size / sample_num defaults; a missing file, a wrong signature or another encoding falls back to the
+    reference's one-cell grid of density 1 on [-1, 1]^3."""
+    import struct
+    data = np.arange(2 * 3 * 4 * 3, dtype=np.float32).reshape(4, 3, 2, 3) / 10.0   # z, y, x, channel
+    with open(tmp_path / "g.vol", "wb") as f:
+        f.write(b"VOL\x03" + struct.pack("<5i", 1, 2, 3, 4, 3) + struct.pack("<6f", -1, -2, -3, 1.5, 2.5, 3.5) + data.tobytes())
+    with open(tmp_path / "half.vol", "wb") as f:   # float16 encoding: not loaded
+        f.write(b"VOL\x03" + struct.pack("<5i", 2, 2, 3, 4, 1) + struct.pack("<6f", -1, -2, -3, 1.5, 2.5, 3.5) + bytes(2 * 24))
+    vol = {"type": "heterogeneous", "density_grid": str(tmp_path / "g.vol"), "albedo": [0.5, 0.6, 0.7], "g": 0.2, "position": [1, 2, 3]}
+    s = gs.load_scene_text(json.dumps(minimal(volume=vol)), MODELS)
+    v = s.desc.volume
+    assert v.type == _abi.GBL_VOLUME_HETEROGENEOUS and list(v.grid) == [2, 3, 4] and v.grid_channels == 3
+    assert list(v.box_min) == [-1, -2, -3] and list(v.box_max) == [1.5, 2.5, 3.5]
+    assert v.step_size == pytest.approx(0.1) and v.sample_num == 5 and v.g == pytest.approx(0.2)
+    np.testing.assert_array_equal(np.ctypeslib.as_array(v.density, shape=(72,)), data.ravel())
+    assert list(v.to_world.position) == [1, 2, 3]
+    for bad in (str(tmp_path / "missing.vol"), str(tmp_path / "half.vol")):
+        s = gs.load_scene_text(json.dumps(minimal(volume=dict(vol, density_grid=bad, step_size=0.25, sample_num=2))), MODELS)
+        v = s.desc.volume
+        assert list(v.grid) == [1, 1, 1] and v.grid_channels == 1 and v.density[0] == 1.0
+        assert list(v.box_min) == [-1, -1, -1] and list(v.box_max) == [1, 1, 1] and v.step_size == 0.25 and v.sample_num == 2
