@@ -179,6 +179,11 @@ WORKLOADS = {
     # name: (scene, resolution, spp, depth, what it is)
     "bunny": ("bunny", (512, 512), 256, 8, "BASELINE configs[1]: bunny.json, glass stand-in bunny (69120 tris) on a plane, spot light"),
     "grid": ("grid", (1024, 1024), 256, 8, "BASELINE configs[3]: grid.json, 15 instances of the bunny BLAS (1.04 M instanced triangles)"),
+    # the other two configurations, for profiles (tools/profile_gpu.sh): run them with --spp to bound the time, the kernels'
+    # per-launch behaviour does not depend on it
+    "cornell": ("cornell", (1024, 1024), 1024, 16, "BASELINE configs[2]: cornell.json, Cornell box + glass bunny, area light, divergent BSDF mix"),
+    "ao": ("bunny", (2048, 2048), 4096, 8, "BASELINE configs[4]: bunny.json under the AO integrator (1 closest hit + 25 any-hit rays per camera sample)",
+           {"method": "ao", "ao_samples": 25}),
 }
 VALU_CYCLES_PER_WAVE_INSTRUCTION = 4   # MI355X_MICROARCH.md: one wave64 f32 VALU instruction holds its SIMD's issue for 4 cycles
 SIMDS = 256 * 4
@@ -249,13 +254,14 @@ def main():
     torch.cuda.set_device(device_index)
 
     wl_name = args.workload or ("bunny" if world == 1 else "grid")
-    scene_name, res, spp, depth, wl_text = WORKLOADS[wl_name]
+    scene_name, res, spp, depth, wl_text = WORKLOADS[wl_name][:5]
+    wl_extra = WORKLOADS[wl_name][5] if len(WORKLOADS[wl_name]) > 5 else {}
     res = tuple(args.resolution) if args.resolution else res
     spp = args.spp or spp
     depth = args.depth or depth
     standard = (res, spp, depth) == WORKLOADS[wl_name][1:4]
     scaling = args.scaling or ("strong" if world > 1 else "weak")
-    overrides = gs.config_overrides(resolution=res, spp=spp, depth=depth)
+    overrides = gs.config_overrides(resolution=res, spp=spp, depth=depth, **wl_extra)
     scene = gs.load_scene(scene_name, overrides)
     tracer = HipPathTracer(scene, device_index)
     film = tracer.new_film()
@@ -298,6 +304,8 @@ def main():
     job_paths = float(paths.item())   # paths all ranks traced in one step
 
     auto_wavefront = depth >= _abi.GBL_AUTO_WAVEFRONT_DEPTH or tracer.info.instanced_triangles >= _abi.GBL_AUTO_WAVEFRONT_TRIS
+    if wl_extra.get("method") == "ao":
+        auto_wavefront = False   # the wavefront schedule covers the path tracer; AO runs its persistent kernel
     resolved = args.schedule if args.schedule != "auto" else ("wavefront" if auto_wavefront else "megakernel")
     if rank == 0:
         call_ms = [a for a, _ in per_step]                                    # device events around gbl_render (the launch stream)
@@ -309,6 +317,8 @@ def main():
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         kernel_tag = {"megakernel": "path_trace_kernel<false, false, false, false>", "wavepool": "wp_kernel<false, false, false>",
                       "wavefront": "wf_trace<false, false, false, false, false>"}[resolved]
+        if wl_extra.get("method") == "ao":
+            kernel_tag = "ao_kernel<false, false, false, false>"
         pmc, pmc_note = (pmc_for(kernel_tag, wl_name, resolved) if (standard and world == 1) else (None, "non-standard run: no counters quoted"))
         rays = counted["extension_rays"] + counted["shadow_rays"]
         value = job_paths * args.steps / elapsed * 1e-6
