@@ -62,10 +62,36 @@ def pmc_for(kernel_tag, workload, schedule):
     stamp = build.source_stamp()
     if d.get("source_stamp") != stamp:
         return None, "%s was collected from source stamp %s, this tree is %s" % (os.path.basename(path), d.get("source_stamp"), stamp)
+    if schedule == "wavefront":
+        # a step is hundreds of launches of three kernels: the counters of one step = sum over the un-instrumented wavefront
+        # kernels of (counters per launch x launches per render); their kernel time likewise, from the same kernel trace
+        calls = d.get("kernel_calls", {})
+        renders = sum(n for k, n in calls.items() if "wf_splat<" in k and _template_arg(k, 1) == "false")
+        agg, kernels = {}, []
+        for name, c in d.get("counters_per_launch", {}).items():
+            if not name.startswith("void wf_") or _template_arg(name, 1) != "false" or name not in calls or not renders:
+                continue
+            per_render = calls[name] / renders
+            kernels.append("%s x %g" % (name.split("(")[0].replace("void ", ""), per_render))
+            for key in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "FETCH_SIZE", "WRITE_SIZE"):
+                if key in c:
+                    agg[key] = agg.get(key, 0.0) + c[key] * per_render
+            agg["kernel_avg_ms"] = agg.get("kernel_avg_ms", 0.0) + c.get("kernel_avg_ms", 0.0) * per_render
+        if agg.get("SQ_INSTS_VALU"):
+            return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp), None
+        return None, "no wavefront kernels in %s" % os.path.basename(path)
     for name, c in d.get("counters_per_launch", {}).items():
         if kernel_tag in name:
             return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp), None
     return None, "no kernel matching %r in %s" % (kernel_tag, os.path.basename(path))
+
+
+def _template_arg(kernel_name, index):
+    """The index-th template argument of a demangled kernel name ('void wf_trace<false, true, ...>(...)' -> 'true' for 1)."""
+    a = kernel_name.find("<")
+    b = kernel_name.find(">", a)
+    args = [x.strip() for x in kernel_name[a + 1:b].split(",")] if a >= 0 and b > a else []
+    return args[index] if index < len(args) else None
 
 
 def cpu_baseline(workload_overrides, spp_sample, cores):
@@ -315,7 +341,7 @@ def main():
         avg_kernel_ms = sum(main_ms) / len(main_ms)
         alg_bytes = algorithmic_bytes(counted)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        kernel_tag = {"megakernel": "path_trace_kernel<false, false, false, false>", "wavepool": "wp_kernel<false, false, false>",
+        kernel_tag = {"megakernel": "path_trace_kernel<false, false, false, false, false, false>", "wavepool": "wp_kernel<false, false, false>",
                       "wavefront": "wf_trace<false, false, false, false, false>"}[resolved]
         if wl_extra.get("method") == "ao":
             kernel_tag = "ao_kernel<false, false, false, false>"
