@@ -294,20 +294,39 @@ def main():
     base_seed = 20261003
     part = gd.shard_for(rank, world, "samples" if scaling == "weak" else "tiles", base_seed)
 
+    # a call takes fewer than 2^32 camera samples (configs[4] at its 4096 spp has 1.7e10): such a frame is rendered in
+    # bands of 8-pixel tile rows, one call each, all of them inside the timed step
+    x0, x1, y0, y1 = tracer.window
+    rows_per_band = max(8, ((1 << 31) // max(1, (x1 - x0) * scene.spp())) // 8 * 8)
+    bands = [(x0, x1, y, min(y1, y + rows_per_band)) for y in range(y0, y1, rows_per_band)]
+    if len(bands) == 1:
+        bands = [None]
+
+    def render_frame(target, **kw):
+        out = None
+        for w in bands:
+            r = tracer.render(film=target, window=w, **kw)
+            if out is None:
+                out = r
+            elif r["stats"]:
+                for k, v in r["stats"].items():
+                    out["stats"][k] += v
+        return out
+
     # counters for the roofline (one instrumented launch, outside the timed region;
     # the sampler is counter-based so every timed launch does exactly this work)
-    counted = tracer.render(film=film, seed=part["seed"], shard=part["shard"], stats=True, schedule=args.schedule)["stats"]
+    counted = render_frame(film, seed=part["seed"], shard=part["shard"], stats=True, schedule=args.schedule)["stats"]
     my_paths = counted["paths"]
 
     one_gpu_ms = None
     if world > 1 and rank == 0 and scaling == "strong":
         # the WHOLE frame on one GPU, outside the timed region: the N-GPU line then carries its own strong-scaling baseline
         whole = tracer.new_film()
-        tracer.render(film=whole, seed=base_seed, schedule=args.schedule)
+        render_frame(whole, seed=base_seed, schedule=args.schedule)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         whole.zero_()
-        tracer.render(film=whole, seed=base_seed, schedule=args.schedule)
+        render_frame(whole, seed=base_seed, schedule=args.schedule)
         torch.cuda.synchronize()
         one_gpu_ms = (time.perf_counter() - t1) * 1e3
         del whole
@@ -316,7 +335,7 @@ def main():
         gd.allreduce_film(torch.zeros(16, device=tracer.device))
         gd.barrier()
     elapsed, per_step = run_steps(
-        render=lambda: tracer.render(film=film, seed=part["seed"], shard=part["shard"], schedule=args.schedule),
+        render=lambda: render_frame(film, seed=part["seed"], shard=part["shard"], schedule=args.schedule),
         zero_film=film.zero_, allreduce=lambda: gd.allreduce_film(film.accum), barrier=gd.barrier, sync=torch.cuda.synchronize,
         steps=args.steps, warmup=args.warmup, world=world, make_event=lambda: torch.cuda.Event(enable_timing=True))
 
@@ -336,9 +355,9 @@ def main():
     if rank == 0:
         call_ms = [a for a, _ in per_step]                                    # device events around gbl_render (the launch stream)
         reduce_ms = [b for _, b in per_step]
-        timings = tracer.timings(args.steps)                                   # HIP events inside the library, per kernel class
+        timings = tracer.timings(args.steps * len(bands))                      # HIP events inside the library, per kernel class and call
         main_ms = [x[0] for x in timings] or call_ms
-        avg_kernel_ms = sum(main_ms) / len(main_ms)
+        avg_kernel_ms = sum(main_ms) / args.steps if timings else sum(main_ms) / len(main_ms)   # per step (a step is len(bands) calls)
         alg_bytes = algorithmic_bytes(counted)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         kernel_tag = {"megakernel": "path_trace_kernel<false, false, false, false, false, false>", "wavepool": "wp_kernel<false, false, false>",
