@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 11
+GBL_ABI_VERSION = 12
 GBL_AUTO_WAVEFRONT_DEPTH, GBL_AUTO_WAVEFRONT_TRIS = 12, 400000   # gbl_schedule AUTO thresholds (goblin_hip.h)
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM, GBL_ERR_INTERNAL = range(7)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
@@ -65,7 +65,7 @@ class gbl_material(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color", C.c_float * 3), ("color2", C.c_float * 3), ("index", C.c_float),
                 ("k", C.c_float), ("exponent", C.c_float), ("tex_color", C.c_int32), ("tex_color2", C.c_int32),
                 ("tex_exponent", C.c_int32), ("masked_material", C.c_int32), ("color3", C.c_float * 3),
-                ("tex_color3", C.c_int32)]
+                ("tex_color3", C.c_int32), ("tex_bump", C.c_int32), ("tex_normal", C.c_int32)]
 
 
 class gbl_instance(C.Structure):

@@ -106,6 +106,7 @@ struct DevMaterial {
     // type 5 (subsurface): color = sigma_a, color2 = sigma_s', color3 = Kr, index = eta, k = g, exponent = A = (1 + Fdr) / (1 - Fdr)
     float color3[3];
     int32_t tex_color3;
+    int32_t tex_bump, tex_normal;                   // BumpShaders: float displacement / colour normal map, -1 none (a mask carries the wrapped material's)
     float pad;
 };
 

@@ -622,7 +622,7 @@ private:
         gbl_material black;
         memset(&black, 0, sizeof(black));
         black.type = GBL_MAT_LAMBERT;
-        black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = black.tex_color3 = -1;
+        black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = black.tex_color3 = black.tex_bump = black.tex_normal = -1;
         material_ids_[camera_type_ + "_lens_material"] = static_cast<int>(s_->materials.size());
         s_->materials.push_back(black);
         ModelDecl d;
@@ -903,13 +903,24 @@ private:
         }
         if (!decl) return fail(GBL_ERR_INVALID, "Material " + name + " not defined!");
         Params p(decl);
-        if (p.has_string("bumpmap") || p.has_string("normalmap"))
-            return fail(GBL_ERR_UNSUPPORTED, "bump/normal maps are outside the device path");
         std::string type = p.get_string("type");
         gbl_material m;
         memset(&m, 0, sizeof(m));
-        m.tex_color = m.tex_color2 = m.tex_exponent = m.masked_material = m.tex_color3 = -1;
+        m.tex_color = m.tex_color2 = m.tex_exponent = m.masked_material = m.tex_color3 = m.tex_bump = m.tex_normal = -1;
         gbl_status st;
+        if (type != "mask") {
+            // getBumpShaders (GoblinMaterial.cpp:813-824): every factory but the mask's reads "bumpmap" (float texture) and
+            // "normalmap" (colour texture); a constant texture perturbs nothing but is still looked up
+            float unused[3];
+            if (p.has_string("bumpmap")) {
+                if ((st = texture_ref(true, p.get_string("bumpmap"), 1 << 30, &m.tex_bump, unused)) != GBL_OK) return st;
+                if (m.tex_bump < 0) m.tex_bump = add_constant(true, unused);
+            }
+            if (p.has_string("normalmap")) {
+                if ((st = texture_ref(false, p.get_string("normalmap"), 1 << 30, &m.tex_normal, unused)) != GBL_OK) return st;
+                if (m.tex_normal < 0) m.tex_normal = add_constant(false, unused);
+            }
+        }
         if (type == "blinn") {
             m.type = GBL_MAT_BLINN;
             if ((st = color_texture(p.get_string("Kg"), m.color, &m.tex_color)) != GBL_OK) return st;
@@ -1153,7 +1164,7 @@ private:
                 gbl_material black;
                 memset(&black, 0, sizeof(black));
                 black.type = GBL_MAT_LAMBERT;
-                black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = black.tex_color3 = -1;
+                black.tex_color = black.tex_color2 = black.tex_exponent = black.masked_material = black.tex_color3 = black.tex_bump = black.tex_normal = -1;
                 gbl_instance inst;
                 memset(&inst, 0, sizeof(inst));
                 inst.mesh = lt.mesh;

@@ -40,13 +40,105 @@ struct TexFrag {
     float dudx, dvdx, dudy, dvdy;
 };
 
+// What a texture lookup reads of the scene, by value: an out-of-line function taking `const DevScene&` would force the
+// 1 KB kernel argument block into scratch (image.h).
+struct TexCtx {
+    const DevTexture* textures;
+    ImgCtx img;
+};
+__device__ __forceinline__ TexCtx tex_ctx(const DevScene& sc) {
+    TexCtx c = {sc.textures, img_ctx(sc)};
+    return c;
+}
+template <int DEPTH>
+__device__ __forceinline__ F3 tex_eval_ctx(const TexCtx& tc, int id, const Frag& fr, const TexFrag& tf);
+// Material::perturb -> BumpShaders::evaluate (GoblinMaterial.cpp:221-283), which Scene::intersect runs on the closest hit's
+// fragment (GoblinScene.cpp:75-83) before any ray differential is attached to it: the lookups see a zero footprint.
+// `bump` displaces the surface along its normal (forward differences over du = dv = 0.002 in uv, the position moved along
+// dpdu / dpdv), `normal` holds 2 n - 1 in the shading frame.  Out of line: three texture lookups nobody else needs inlined.
+// Arguments and result travel by value (registers): handing the callee pointers to the caller's Frag / TexFrag put both
+// into scratch for every EXT kernel (149 spilled registers, bump maps in the scene or not).
+struct BumpOut {
+    F3 n, dpdu, dpdv;
+};
+__device__ __noinline__ BumpOut perturb_fragment(TexCtx sc, int tex_bump, int tex_normal, F3 p, F3 n_in, float u, float v, F3 dpdu_in, F3 dpdv_in) {
+    Frag fr;
+    TexFrag tf;
+    fr.p = p;
+    fr.n = n_in;
+    fr.t = fr.b = f3(0.0f, 0.0f, 0.0f);   // (texture lookups read p, uv and the differentials only)
+    fr.eps = 0.0f;
+    tf.u = u;
+    tf.v = v;
+    tf.dpdu = dpdu_in;
+    tf.dpdv = dpdv_in;
+    tf.dudx = tf.dvdx = tf.dudy = tf.dvdy = 0.0f;
+    tf.dpdx = tf.dpdy = f3(0.0f, 0.0f, 0.0f);
+    if (tex_bump >= 0) {
+        const F3 n = fr.n;
+        const float bump_d = tex_eval_ctx<GBL_TEX_MAX_DEPTH>(sc, tex_bump, fr, tf).x;
+        const float du = 0.002f;
+        Frag fdu = fr;
+        TexFrag tdu = tf;
+        fdu.p = p + du * tf.dpdu;
+        tdu.u = u + du;
+        tdu.v = v + 0.0f;
+        const float bump_ddu = tex_eval_ctx<GBL_TEX_MAX_DEPTH>(sc, tex_bump, fdu, tdu).x;
+        const F3 bump_dpdu = tf.dpdu + (bump_ddu - bump_d) / du * n;
+        const float dv = 0.002f;
+        Frag fdv = fr;
+        TexFrag tdv = tf;
+        fdv.p = p + dv * tf.dpdv;
+        tdv.u = u + 0.0f;
+        tdv.v = v + dv;
+        const float bump_ddv = tex_eval_ctx<GBL_TEX_MAX_DEPTH>(sc, tex_bump, fdv, tdv).x;
+        const F3 bump_dpdv = tf.dpdv + (bump_ddv - bump_d) / dv * n;
+        F3 bump_n = normalize(cross(bump_dpdu, bump_dpdv));
+        if (dot(bump_n, n) < 0.0f) bump_n = bump_n * -1.0f;
+        fr.n = bump_n;
+        tf.dpdu = bump_dpdu;
+        tf.dpdv = bump_dpdv;
+    }
+    if (tex_normal >= 0) {
+        // (the lookup reads the fragment as the bump map left it; Fragment::getWorldToShade: rows t, b, n)
+        const F3 c = tex_eval_ctx<GBL_TEX_MAX_DEPTH>(sc, tex_normal, fr, tf);
+        const F3 ns = 2.0f * c - f3(1.0f, 1.0f, 1.0f);
+        const F3 n = fr.n;
+        const F3 t = normalize(tf.dpdu - n * dot(tf.dpdu, n));
+        const F3 b = cross(n, t);
+        F3 nw = f3(t.x * ns.x + b.x * ns.y + n.x * ns.z, t.y * ns.x + b.y * ns.y + n.y * ns.z, t.z * ns.x + b.z * ns.y + n.z * ns.z);
+        nw = normalize(nw);
+        if (dot(nw, fr.n) < 0.0f) nw = nw * -1.0f;
+        fr.n = nw;
+    }
+    BumpOut o;
+    o.n = fr.n;
+    o.dpdu = tf.dpdu;
+    o.dpdv = tf.dpdv;
+    return o;
+}
+// make_fragment's tail for a material with bump shaders
+__device__ __forceinline__ void apply_perturb(const DevScene& sc, const DevMaterial& m, Frag& fr, TexFrag& tf) {
+    const BumpOut o = perturb_fragment(tex_ctx(sc), m.tex_bump, m.tex_normal, fr.p, fr.n, tf.u, tf.v, tf.dpdu, tf.dpdv);
+    fr.n = o.n;
+    tf.dpdu = o.dpdu;
+    tf.dpdv = o.dpdv;
+    fr.t = normalize(tf.dpdu - fr.n * dot(tf.dpdu, fr.n));
+    fr.b = cross(fr.n, fr.t);
+}
+
 // Rebuild the reference's Fragment for the closest hit and move it to world space.
 template <bool EXT>
-__device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, F3 wo_origin, F3 w_dir, Frag& fr, TexFrag* tf = nullptr) {
+__device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, F3 wo_origin, F3 w_dir, Frag& fr, TexFrag* tf_out = nullptr) {
     const DevInstance* ip = sc.instances + h.inst;
     // the object-space ray the triangle test saw (Transform::invertRay)
     F3 ro = xf_point(ip->inv, wo_origin), rd = xf_vector(ip->inv, w_dir);
-    const bool want_tex = EXT && tf != nullptr && sc.materials[ip->material].has_tex != 0u;
+    const bool bumped = EXT && (sc.materials[ip->material].tex_bump >= 0 || sc.materials[ip->material].tex_normal >= 0);
+    // (computed into a local and copied out at the end: selecting between the caller's TexFrag and a local one by pointer
+    //  put both through scratch at every call site -- +10 % on every EXT scene)
+    TexFrag tf_local;
+    TexFrag* const tf = &tf_local;
+    const bool want_tex = EXT && (tf_out != nullptr || bumped) && sc.materials[ip->material].has_tex != 0u;
     if (EXT && ip->shape != 0u) {
         // Sphere::intersect (GoblinSphere.cpp:32-86) / Disk::intersect (GoblinDisk.cpp:33-60): position, normal and
         // dpdu are algebraic in the hit point; uv and dpdv (atan2 / acos) only feed textures and bump maps
@@ -78,6 +170,8 @@ __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, 
         fr.t = normalize(dpdu_w - fr.n * dot(dpdu_w, fr.n));
         fr.b = cross(fr.n, fr.t);
         fr.eps = 1e-3f * h.t;
+        if (bumped) apply_perturb(sc, sc.materials[ip->material], fr, *tf);
+        if (tf_out != nullptr && want_tex) *tf_out = tf_local;
         return;
     }
     const DevTri* tp = sc.tris + h.tri;
@@ -128,6 +222,8 @@ __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, 
     fr.t = normalize(dpdu_w - fr.n * dot(dpdu_w, fr.n));
     fr.b = cross(fr.n, fr.t);
     fr.eps = 1e-3f * h.t;
+    if (EXT && bumped) apply_perturb(sc, sc.materials[ip->material], fr, *tf);
+    if (EXT && tf_out != nullptr && want_tex) *tf_out = tf_local;
 }
 
 // ------------------------------------------------------------------- textures
@@ -213,7 +309,7 @@ __device__ __forceinline__ TexCoord tex_map(const DevTexture& g, const Frag& fr,
 }
 // Texture<T>::lookup (float textures carry their value in every channel)
 template <int DEPTH>
-__device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& fr, const TexFrag& tf) {
+__device__ __forceinline__ F3 tex_eval_ctx(const TexCtx& sc, int id, const Frag& fr, const TexFrag& tf) {
     const DevTexture& g = sc.textures[id];
     const F3 value = f3(g.value[0], g.value[1], g.value[2]);
     if constexpr (DEPTH == 0) {
@@ -222,10 +318,10 @@ __device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& f
         if (g.type == 0u) return value;
         if (g.type == 3u) {   // ImageTexture<T>::lookup: map, then the MIPMap
             const TexCoord tc = tex_map(g, fr, tf);
-            return mip_lookup(img_ctx(sc), sc.images + g.image, g.is_float != 0u, tc, g.filter, g.address, g.max_aniso);
+            return mip_lookup(sc.img, sc.img.images + g.image, g.is_float != 0u, tc, g.filter, g.address, g.max_aniso);
         }
-        const F3 a = tex_eval<DEPTH - 1>(sc, g.child[0], fr, tf);
-        const F3 b = tex_eval<DEPTH - 1>(sc, g.child[1], fr, tf);
+        const F3 a = tex_eval_ctx<DEPTH - 1>(sc, g.child[0], fr, tf);
+        const F3 b = tex_eval_ctx<DEPTH - 1>(sc, g.child[1], fr, tf);
         if (g.type == 2u) return a * b.x;   // ScaleTexture: mScale->lookup * mTexture->lookup
         const TexCoord tc = tex_map(g, fr, tf);
         const float s = tc.s, t = tc.t, dsdx = tc.dsdx, dtdx = tc.dtdx, dsdy = tc.dsdy, dtdy = tc.dtdy;
@@ -241,6 +337,10 @@ __device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& f
         if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
         return (1.0f - area2) * a + area2 * b;
     }
+}
+template <int DEPTH>
+__device__ __forceinline__ F3 tex_eval(const DevScene& sc, int id, const Frag& fr, const TexFrag& tf) {
+    return tex_eval_ctx<DEPTH>(tex_ctx(sc), id, fr, tf);
 }
 // The hit's material with its texture slots evaluated at this fragment (every lookup of a bounce sees the same
 // Fragment, so resolving once is what the reference's repeated lookups return).

@@ -796,6 +796,11 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         dm.has_tex = (m.tex_color >= 0 || m.tex_color2 >= 0 || m.tex_exponent >= 0) ? 1u : 0u;
         dm.masked = m.type == GBL_MAT_MASK ? m.masked_material : -1;
         dm.tex_color3 = -1;
+        // Material::perturb -> BumpShaders::evaluate; MaskMaterial::perturb forwards to the wrapped material (GoblinMaterial.h:456-458)
+        const gbl_material& bump_of = m.type == GBL_MAT_MASK ? d->materials[m.masked_material] : m;
+        dm.tex_bump = bump_of.tex_bump;
+        dm.tex_normal = bump_of.tex_normal;
+        if (dm.tex_bump >= 0 || dm.tex_normal >= 0) dm.has_tex = 1u;
         if (m.type == GBL_MAT_SUBSURFACE) {
             for (int k = 0; k < 3; ++k) dm.color3[k] = m.color3[k];
             dm.tex_color3 = m.tex_color3;
@@ -811,7 +816,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             const gbl_material& in = d->materials[m.masked_material];
             if (in.tex_color >= 0 || in.tex_color2 >= 0 || in.tex_exponent >= 0) dm.has_tex = 1u;
         }
-        for (int32_t t : {m.tex_color, m.tex_color2, m.tex_exponent, m.type == GBL_MAT_SUBSURFACE ? m.tex_color3 : -1}) {
+        for (int32_t t : {m.tex_color, m.tex_color2, m.tex_exponent, m.type == GBL_MAT_SUBSURFACE ? m.tex_color3 : -1, m.tex_bump, m.tex_normal}) {
             if (t < 0) continue;
             out->extended = 1;
             int depth = texture_depth(d, t, 0);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 11
+#define GBL_ABI_VERSION 12
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -163,6 +163,11 @@ typedef struct gbl_material {
      * GoblinMaterial.h:393). */
     float color3[3];
     int32_t tex_color3;
+    /* BumpShaders (getBumpShaders, GoblinMaterial.cpp:813-824; evaluated by Material::perturb at every closest hit,
+     * GoblinScene.cpp:75-83, GoblinMaterial.cpp:221-283): "bumpmap" = a FLOAT texture displacing the surface along its
+     * normal (forward differences over du = dv = 0.002), "normalmap" = a COLOUR texture holding 2 n - 1 in the shading
+     * frame.  -1: none.  A mask forwards to the wrapped material's. */
+    int32_t tex_bump, tex_normal;
 } gbl_material;
 
 /* InstancedPrimitive over a Model(geometry, material[, areaLight])

@@ -1094,6 +1094,10 @@ inline void tri_fragment(const Mesh& m, uint32_t t, const Ray& ray, float tt, fl
     f->v = v;
     f->dpdu = dpdu;
     f->dpdv = dpdv;
+    // `*fragment = Fragment(position, normal, uv, dpdu, dpdv)`: the constructor zeroes the differentials (GoblinGeometry.cpp:7-12),
+    // which Material::perturb's lookups read before computeUVDifferential sets them
+    f->dpdx = f->dpdy = V3(0, 0, 0);
+    f->dudx = f->dvdx = f->dudy = f->dvdy = 0.0f;
 }
 
 // quadratic, GoblinUtils.cpp:93-113
@@ -1175,6 +1179,8 @@ inline bool shape_test(const Mesh& m, const Ray& ray, float* t_out) {
 inline void shape_fragment(const Mesh& m, const Ray& ray, float t, Frag* f) {
     if (m.shape == GBL_SHAPE_SPHERE) sphere_fragment(m.radius, ray, t, f);
     else disk_fragment(m.radius, ray, t, f);
+    f->dpdx = f->dpdy = V3(0, 0, 0);   // `*fragment = Fragment(...)`, as in tri_fragment
+    f->dudx = f->dvdx = f->dudy = f->dvdy = 0.0f;
 }
 
 struct Hit {
@@ -1188,9 +1194,55 @@ struct Hit {
 // GoblinModel.cpp:39-55).  ray.maxt shrinks in place.  Frag state persists
 // across candidate hits exactly as the reference's single Intersection does.
 bool scene_intersect_impl(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt, int filter);
+Col tex_lookup(const orc_scene* sc, int id, const Frag& f);
+// Material::perturb -> BumpShaders::evaluate (GoblinMaterial.cpp:221-283), run by Scene::intersect on the closest hit's
+// fragment (GoblinScene.cpp:75-83) -- before any ray differential is attached to it, so the lookups see a zero footprint.
+// MaskMaterial::perturb forwards to the wrapped material (GoblinMaterial.h:456-458).
+inline void perturb_fragment(const orc_scene* s, int material, Frag* f) {
+    const gbl_material* m = &s->materials[material];
+    if (m->type == GBL_MAT_MASK) m = &s->materials[m->masked_material];
+    if (m->tex_bump >= 0) {
+        const V3 p = f->p, n = f->n;
+        const float u = f->u, v = f->v;
+        const float bump_d = tex_lookup(s, m->tex_bump, *f).r;
+        const float du = 0.002f;
+        Frag fdu = *f;
+        fdu.p = p + du * f->dpdu;
+        fdu.u = u + du;
+        fdu.v = v + 0.0f;
+        const float bump_ddu = tex_lookup(s, m->tex_bump, fdu).r;
+        const V3 bump_dpdu = f->dpdu + (bump_ddu - bump_d) / du * n;
+        const float dv = 0.002f;
+        Frag fdv = *f;
+        fdv.p = p + dv * f->dpdv;
+        fdv.u = u + 0.0f;
+        fdv.v = v + dv;
+        const float bump_ddv = tex_lookup(s, m->tex_bump, fdv).r;
+        const V3 bump_dpdv = f->dpdv + (bump_ddv - bump_d) / dv * n;
+        V3 bump_n = normalize(cross(bump_dpdu, bump_dpdv));
+        if (dot(bump_n, n) < 0.0f) bump_n = bump_n * -1.0f;
+        f->n = bump_n;
+        f->dpdu = bump_dpdu;
+        f->dpdv = bump_dpdv;
+    }
+    if (m->tex_normal >= 0) {
+        const Col c = tex_lookup(s, m->tex_normal, *f);
+        V3 ns(c.r, c.g, c.b);
+        ns = 2.0f * ns - V3(1.0f, 1.0f, 1.0f);
+        // Fragment::getWorldToShade rows t, b, n; its transpose times nShade
+        const V3 n = f->n;
+        const V3 t = normalize(f->dpdu - n * dot(f->dpdu, n));
+        const V3 b = cross(n, t);
+        V3 nw(t.x * ns.x + b.x * ns.y + n.x * ns.z, t.y * ns.x + b.y * ns.y + n.y * ns.z, t.z * ns.x + b.z * ns.y + n.z * ns.z);
+        nw = normalize(nw);
+        if (dot(nw, f->n) < 0.0f) nw = nw * -1.0f;
+        f->n = nw;
+    }
+}
 bool scene_intersect(const orc_scene* s, Ray& ray, Hit* hit, Counters* cnt, int filter = FILTER_NONE) {
     const Ray in = ray;
     const bool any = scene_intersect_impl(s, ray, hit, cnt, filter);
+    if (any) perturb_fragment(s, static_cast<int>(s->instances[hit->instance].material), &hit->frag);
     if (cnt->log) {
         V3 fn(0, 0, 0), ft(0, 0, 0);
         if (any) {   // Fragment::getWorldToShade's n and t rows

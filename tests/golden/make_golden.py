@@ -118,6 +118,11 @@ CASES = {
     "hetero_spot": ("hetero", dict(ov((48, 48), 4, 4), lights=SPOT), 0, False),
     "hetero_tint_whitted": ("hetero_tint", ov((40, 40), 4, 3, method="whitted"), 0, False),
     "hetero_tint_ao": ("hetero_tint", ov((40, 40), 4, method="ao", ao=4), 0, False),
+    # bump and normal maps (BumpShaders: Material::perturb at every closest hit): image / scaled / checkerboard / constant
+    # float bump maps, image and constant normal maps, on lambert, blinn and glass, and behind a mask
+    "bumpy_pt": ("bumpy", ov((64, 64), 9, 5), 2048, False),
+    "bumpy_whitted": ("bumpy", ov((48, 48), 4, 3, method="whitted"), 1024, False),
+    "bumpy_ao": ("bumpy", ov((40, 40), 4, method="ao", ao=4), 512, False),
     "subsurface_pt": ("subsurface", ov((64, 64), 9, 5), 2048, False),
     # subsurface materials under the Whitted renderer: Lsubsurface at every level of the recursion (here also behind the
     # mirror and the glass), SubsurfaceMaterial's BSDFAll lobe never matching the non-specular / specular requests

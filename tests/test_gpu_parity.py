@@ -85,7 +85,7 @@ def fake_window(full, n_pixels):
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "bunny_vn_box",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
-                                  "imagetex_pt", "ibl_pt", "ibl_whitted"])
+                                  "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -114,7 +114,8 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
-                                  "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted", "imagetex_pt", "ibl_pt", "ibl_whitted"])
+                                  "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted", "imagetex_pt", "ibl_pt", "ibl_whitted",
+                                  "bumpy_pt", "bumpy_whitted"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -142,7 +143,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
-                                  "imagetex_pt", "ibl_pt", "ibl_whitted"])
+                                  "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
     """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
     Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators

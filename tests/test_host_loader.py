@@ -72,14 +72,23 @@ def test_render_methods():
     assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
 
 
-def test_out_of_scope_features_fail_loudly():
-    cases = [
-        minimal(materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b"}]),
-    ]
-    for doc in cases:
-        with pytest.raises(_abi.GoblinError) as e:
-            load(doc)
-        assert e.value.status == _abi.GBL_ERR_UNSUPPORTED, doc
+def test_bump_and_normal_maps_load():
+    """getBumpShaders (GoblinMaterial.cpp:813-824): "bumpmap" names a float texture, "normalmap" a colour texture, on every
+    material type but the mask; constant textures become texture nodes too (a constant bump map still swaps the shading
+    normal for cross(dpdu, dpdv)); an undefined name is an error like any other texture reference."""
+    tex = [{"format": "color", "name": "w", "type": "constant", "color": [1, 1, 1]},
+           {"format": "float", "name": "b", "type": "constant", "float": 0.25},
+           {"format": "color", "name": "nm", "type": "constant", "color": [0.5, 0.5, 1.0]}]
+    s = load(minimal(textures=tex, materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "b", "normalmap": "nm"}]))
+    m = s.desc.materials[0]
+    assert m.tex_bump >= 0 and m.tex_normal >= 0 and m.tex_bump != m.tex_normal
+    tb, tn = s.desc.textures[m.tex_bump], s.desc.textures[m.tex_normal]
+    assert tb.type == _abi.GBL_TEX_CONSTANT and tb.is_float == 1 and tb.value[0] == 0.25
+    assert tn.type == _abi.GBL_TEX_CONSTANT and tn.is_float == 0 and list(tn.value) == [0.5, 0.5, 1.0]
+    s = load(minimal(textures=tex, materials=[{"name": "m", "type": "lambert", "Kd": "w"}]))
+    assert s.desc.materials[0].tex_bump == -1 and s.desc.materials[0].tex_normal == -1
+    with pytest.raises(_abi.GoblinError):
+        load(minimal(textures=tex, materials=[{"name": "m", "type": "lambert", "Kd": "w", "bumpmap": "missing"}]))
 
 
 def test_image_textures_and_image_based_light():

@@ -6,7 +6,7 @@ import torch
 from goblin_amd import _abi
 from goblin_amd import scene as gs
 from goblin_amd.renderer import HipPathTracer
-for name in ("shapes", "textured", "masked", "subsurface", "whitted", "imagetex", "ibl", "volume", "hetero"):
+for name in ("shapes", "textured", "masked", "subsurface", "whitted", "imagetex", "ibl", "bumpy", "volume", "hetero"):
     scene = gs.load_scene(name, gs.config_overrides(resolution=(512, 512), spp=64))
     tr = HipPathTracer(scene, 0)
     film = tr.new_film()
