@@ -22,7 +22,8 @@ tag, name = sys.argv[1], sys.argv[2]
 what = sys.argv[3] if len(sys.argv) > 3 else ""
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles")
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+# (gpurun merges a call's files into gpurun_out/ beside older ones: always the newest of each kind)
+stats = max(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 cmd = open(os.path.join(src, "command.txt")).read().strip().replace(REPO + "/", "") if os.path.exists(os.path.join(src, "command.txt")) else ""
@@ -33,7 +34,12 @@ summary = {"name": name, "source_stamp": build.source_stamp(),
            "kernel_calls": {r["Name"]: int(r["Calls"]) for r in rows if float(r["Percentage"]) > 0.05},
            "kernel_total_ms": {r["Name"]: round(float(r["TotalDurationNs"]) * 1e-6, 3) for r in rows if float(r["Percentage"]) > 0.05},
            "counters_per_launch": {}, "launch_info": {}}
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    group = os.path.relpath(f, src).split(os.sep)[0]
+    if group not in newest or os.path.getmtime(f) > os.path.getmtime(newest[group]):
+        newest[group] = f
+for f in newest.values():
     acc = {}
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
