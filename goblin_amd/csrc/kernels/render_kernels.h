@@ -460,13 +460,8 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 
         for (;;) {
             // ---- regeneration: idle lanes start a new camera path
-#ifdef GBL_REGEN_WHOLE_WAVE
-            const bool may_fetch = __ballot(active) == 0ull;   // experiment: refill only a fully idle wave
-#else
-            const bool may_fetch = true;
-#endif
-            int fetched = wave_fetch(!active && !exhausted && may_fetch, ctrl + 1);
-            if (!active && !exhausted && may_fetch) {
+            int fetched = wave_fetch(!active && !exhausted, ctrl + 1);
+            if (!active && !exhausted) {
                 if (fetched >= 0 && fetched < it.paths) {
                     int pix = fetched / ra.chunk_spp;
                     src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);

@@ -1,5 +1,8 @@
+"""Bit-identity check of the megakernel regrouping experiments against the plain megakernel at several depths:
+    python tools/regroup_check.py [1 = kernels/blocktrace.h | 2 = kernels/rayexchange.h]"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np
 from goblin_amd import scene as gs
 from goblin_amd.renderer import HipPathTracer
