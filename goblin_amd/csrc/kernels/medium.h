@@ -170,11 +170,13 @@ __device__ __forceinline__ bool vol_shadow_occluded(const DevScene& sc, int li, 
     Hit h;
     if (!trace<false, STATS, true>(sc, p, wi, 0.0f, maxt, stk, h, cnt)) return false;
     const DevInstance& in = sc.instances[h.inst];
-    if (in.area_light != li || in.shape != 0u || sc.tri_order == nullptr) return true;
-    // the hit is on the sampled emitter's own mesh: the reference's box tests on the way to it -- the instance's world
-    // bound in the scene BVH, then the triangle's bound in the instance's space
+    if (in.area_light != li) return true;
+    // the hit is on the sampled emitter itself: the reference's box tests on the way to it -- the instance's world bound in
+    // the scene BVH (a disk's is flat: a segment that ends on it enters the box AT maxt and the strict test culls it, found
+    // by the round-2 fuzz scenes), then, for a mesh, the triangle's bound in the instance's space
     const DevInstanceBound wb = sc.instance_bounds[h.inst];
     if (!ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), p, wi, 0.0f, maxt)) return false;
+    if (in.shape != 0u || sc.tri_order == nullptr) return true;
     return ref_leaf_reached(sc, h.tri, xf_point(in.inv, p), xf_vector(in.inv, wi), 0.0f, maxt);
 }
 

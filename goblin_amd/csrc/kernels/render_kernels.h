@@ -257,6 +257,7 @@ struct PathState {
     int bounce;         // -1: the ray in flight is the camera ray
     uint32_t path;      // index of this path inside the work item
     bool punch;         // EXT: the ray in flight left a mask surface through its alpha (sampledType == BSDFnullptr)
+    bool first;         // EXT: PathTracer::Li's firstBounce -- no real bounce yet, only punch-throughs (GoblinPathtracer.cpp:75,176)
 };
 
 // GBL_SAMPLES_STREAM with a participating medium.  RenderTask::run continues each sample with transmittance(ray) and
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     ps.Li = f3(0.0f, 0.0f, 0.0f);
                     ps.bounce = -1;
                     ps.punch = false;
+                    ps.first = true;
                     ps.path = fetched;
                     path_draws = 0;
                     prim_t = INFINITY;
@@ -592,8 +594,15 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     // the bounce that punched through a mask contributes no direct light (`continue`, :122-136)
                     ps.punch = false;
                     ps.bounce += 1;
-                    if (!got) finished = true;
+                    if (!got) {
+                        if (ps.first) {   // "primary ray need to evaluate image based lighting in this case" (:125-131)
+                            const F3 le = ps.throughput * environment_le<EXT>(sc, ps.d);
+                            ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                        }
+                        finished = true;
+                    }
                 } else {
+                    ps.first = false;
                     // close the previous bounce: MIS term for the sampled direction, then Li and throughput
                     if (mis_inst >= 0 && sc.instances[mis_inst].area_light == ps.light) {
                         F3 le = hit_Le(sc, mis_inst, mis_n, -ps.d);

@@ -252,8 +252,10 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         out_index = id.y;
         k = id.z;
         ps.punch = (id.w & 1u) != 0u;
+        ps.first = (id.w & 2u) != 0u;
     } else {
         ps.punch = false;
+        ps.first = true;
     }
     const bool masks = EXT && sc.has_masks != 0;
     const bool alive = ps.bounce >= -1;
@@ -350,8 +352,15 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             } else if (EXT && ps.punch) {
                 ps.punch = false;   // the bounce that punched through a mask adds no direct light (GoblinPathtracer.cpp:122-136)
                 ps.bounce += 1;
-                if (!got) finished = true;
+                if (!got) {
+                    if (ps.first) {   // "primary ray need to evaluate image based lighting in this case" (:125-131)
+                        const F3 le = ps.throughput * environment_le<EXT>(sc, ps.d);
+                        ps.Li = f3(ps.Li.x + le.x, ps.Li.y + le.y, ps.Li.z + le.z);
+                    }
+                    finished = true;
+                }
             } else {
+                ps.first = false;
                 if (mis_inst >= 0 && sc.instances[mis_inst].area_light == ps.light) {
                     F3 le = hit_Le(sc, mis_inst, mis_n, -ps.d);
                     if (!is_black(le)) {
@@ -567,6 +576,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
                         ps.light = 0;
                         ps.bounce = -1;
                         ps.punch = false;
+                        ps.first = true;
                         started = true;
                         has_ray = true;
                         if (STATS) cnt.dims += 2;
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         wa.s_pixel[slot] = pixel_key;
     }
     if (keep || dead || want_new || wa.init)
-        wa.s_id[slot] = make_uint4(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16), out_index, k, ps.punch ? 1u : 0u);
+        wa.s_id[slot] = make_uint4(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16), out_index, k, (ps.punch ? 1u : 0u) | (ps.first ? 2u : 0u));
     // ---- extension queue: compacted into this wave's region
     {
         bool enq = keep && has_ray;

@@ -2724,6 +2724,7 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
     Ray cur = ray;
     Col throughput(1.0f);
     float epsilon = hit.epsilon;
+    bool first_bounce = true;   // :75; stays true while the path only punches through masks (`continue` skips :176)
     for (int bounce = 0; bounce < c->rs->max_ray_depth - 1; ++bounce) {
         float ls_comp = rec[c->q->off1[c->ix->light1[bounce]]];
         const float* ls_geo = rec + c->q->off2[c->ix->light2[bounce]];
@@ -2766,7 +2767,11 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
                 cur.o = p; cur.d = wi; cur.mint = epsilon; cur.maxt = INF;
                 Hit nh;
                 nh.frag = hit.frag;
-                if (!scene_intersect(s, cur, &nh, &c->cnt)) break;   // evalEnvironmentLight = 0 on this path
+                if (!scene_intersect(s, cur, &nh, &c->cnt)) {
+                    // "primary ray need to evaluate image based lighting in this case" (:125-131)
+                    if (first_bounce) Li += throughput * environment_le(s, cur.d);
+                    break;
+                }
                 hit = nh;
                 epsilon = nh.epsilon;
                 continue;
@@ -2803,6 +2808,7 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
                 if (!scene_intersect(s, cur, &nh, &c->cnt)) break;
                 hit = nh;
                 epsilon = nh.epsilon;
+                first_bounce = false;
                 continue;
             }
             Hit lh;
@@ -2837,6 +2843,7 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
             // difference, and it reads fields both queries overwrite alike.
             hit = lh;
             epsilon = lh.epsilon;
+            first_bounce = false;
         } else {
             Li += throughput * Ld / pick_pdf;
             break;

@@ -135,6 +135,55 @@ def random_scene(seed):
     return doc, use_mask or use_sss
 
 
+def random_scene_r2(seed, whitted=False):
+    """random_scene(seed) plus the features of round 2, drawn from a stream of their own: image textures (every filter and
+    address mode, colour and float, uv and spherical mapping), bump and normal maps, an image based light, a homogeneous
+    or heterogeneous participating medium.  Returns (doc, has_heterogeneous_medium)."""
+    doc, _ = (random_whitted_scene if whitted else random_scene)(seed)
+    rng = np.random.default_rng(seed + 15485863)
+    U = lambda a, b: float(rng.uniform(a, b))
+    pick = lambda xs: xs[int(rng.integers(len(xs)))]
+    tex, mats = doc["textures"], doc["materials"]
+    filters, modes = ["nearest", "bilinear", "trilinear", "EWA"], ["repeat", "clamp", "border"]
+    tex.append({"format": "color", "name": "img", "type": "image", "file": "images/tiles.exr", "filter": pick(filters), "address": pick(modes),
+                "scale": [U(1, 6), U(1, 6)], "offset": [U(-.5, .5), U(-.5, .5)], "gamma": pick([1.0, 2.2])})
+    tex.append({"format": "color", "name": "img_sph", "type": "image", "file": "images/tiles.exr", "filter": pick(filters), "address": "repeat",
+                "mapping": "spherical", "position": [U(-1, 1), U(0, 1), U(-1, 1)], "orientation": quat(rng), "scale": [U(.1, .4)] * 3})
+    tex.append({"format": "float", "name": "imgf", "type": "image", "file": "images/tiles.exr", "filter": pick(filters), "address": pick(modes),
+                "channel": pick(["R", "G", "B"]), "scale": [U(2, 8), U(2, 8)], "gamma": 1.0})
+    tex.append({"format": "float", "name": "amp", "type": "constant", "float": U(.02, .1)})
+    tex.append({"format": "float", "name": "imgf_small", "type": "scale", "texture": "imgf", "scale": "amp"})
+    tex.append({"format": "color", "name": "flatn", "type": "constant", "color": [0.5, 0.5, 1.0]})
+    plain = [m for m in mats if m["type"] in ("lambert", "blinn", "transparent", "mirror")]
+    for m in plain:
+        if rng.integers(3) == 0:
+            key = {"lambert": "Kd", "blinn": "Kg", "transparent": "Kt", "mirror": "Kr"}[m["type"]]
+            m[key] = pick(["img", "img_sph"])
+        r = int(rng.integers(4))
+        if r == 0:
+            m["bumpmap"] = pick(["imgf_small", "cut", "f1"])
+        elif r == 1:
+            m["normalmap"] = pick(["img", "flatn"])
+        elif r == 2:
+            m["bumpmap"] = pick(["imgf_small", "amp"])
+            m["normalmap"] = pick(["img", "flatn"])
+    if rng.integers(3) == 0:
+        doc["lights"].append({"name": "sky", "type": "ibl", "file": "images/env.exr", "filter": [U(.5, 1), U(.5, 1), U(.5, 1)],
+                              "orientation": quat(rng), "sample_num": int(rng.integers(1, 5))})
+    hetero = False
+    v = int(rng.integers(4))
+    if v == 1:
+        doc["volume"] = {"type": "homogeneous", "attenuation": [U(.1, .5), U(.1, .5), U(.1, .5)], "albedo": [U(.5, .9)] * 3, "emission": [0.0, 0.0, 0.0],
+                         "g": U(0, .6), "sample_num": int(rng.integers(1, 4)), "box_min": [-1, -1, -1], "box_max": [1, 1, 1],
+                         "position": [U(-.5, .5), U(.8, 1.3), U(-.3, .6)], "orientation": quat(rng), "scale": [U(1, 2), U(.8, 1.4), U(1, 2)]}
+    elif v == 2:
+        hetero = True
+        doc["volume"] = {"type": "heterogeneous", "density_grid": pick(["volumes/puff.vol", "volumes/tint.vol"]), "albedo": [U(.5, .9), U(.5, .9), U(.5, .9)],
+                         "g": U(0, .6), "step_size": U(.15, .4), "sample_num": int(rng.integers(1, 4)),
+                         "position": [U(-.5, .5), U(.8, 1.3), U(-.3, .6)], "orientation": quat(rng), "scale": [U(1, 2), U(.8, 1.4), U(1, 2)]}
+    return doc, hetero
+
+
 def random_whitted_scene(seed):
     """random_scene(seed) under the Whitted renderer: shallow recursion, per-light sample counts on the area lights."""
     doc, special = random_scene(seed)

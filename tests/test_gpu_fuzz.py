@@ -87,3 +87,41 @@ def test_random_whitted_scene_matches_oracle(seed):
     np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
     assert rel <= 6e-5, (seed, rel)   # measured <= 5.9e-6 (seed 2: summation order over a bright area-light pixel)
 
+
+
+@pytest.mark.parametrize("seed,whitted", [(s, False) for s in range(10)] + [(s, True) for s in range(4)])
+def test_random_scene_with_round2_features_matches_oracle(seed, whitted):
+    """helpers.random_scene_r2: the same generator plus image textures (all filters / address modes, colour and float, uv and
+    spherical), bump and normal maps, an image based light, a homogeneous or heterogeneous medium -- scenes on which the
+    oracle equals the compiled reference bit for bit (tests/test_oracle_fuzz.py).  Native samples against the oracle under
+    both schedules and BVH builders: bit-identical radiance; the device's stream Film against the oracle's render (not
+    for a heterogeneous medium, which the stream sampler refuses)."""
+    import torch
+    assert torch.cuda.is_available()
+    from goblin_amd.renderer import HipPathTracer
+    doc, hetero = helpers.random_scene_r2(2000 + seed, whitted)
+    scene = gs.load_scene_text(json.dumps(doc), SCENE_DIR)
+    o = ob.Oracle(scene)
+    rseed = 99 + seed
+    samples = o.native_samples(rseed)
+    li_ref, _ = o.li_replay(samples, threads=4)
+    assert np.isfinite(li_ref).all()
+    for bvh in ("host", "device"):
+        r = HipPathTracer(scene, 0, bvh=bvh)
+        for schedule in (("megakernel",) if whitted else ("megakernel", "wavefront")):
+            li = r.render(seed=rseed, want_li=True, schedule=schedule)["li"].cpu().numpy()
+            assert np.isfinite(li).all(), (seed, bvh, schedule)
+            flips = helpers.li_mismatch_fraction(li, li_ref)
+            rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])
+            print("seed", seed, "whitted" if whitted else "pt", bvh, schedule, "volume", doc.get("volume", {}).get("type"), "flips %.5f relL2 %.2e" % (flips, rel))
+            assert flips == 0.0 and rel == 0.0, (seed, whitted, bvh, schedule, flips, rel)
+    if hetero:
+        with pytest.raises(_abi.GoblinError):
+            HipPathTracer(scene, 0).render(sampler="stream")
+        return
+    ref = o.render(threads=1)["film"]
+    film = HipPathTracer(scene, 0).render(sampler="stream")["film"].numpy()
+    rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
+    print("seed", seed, "stream film relL2 %.2e" % rel)
+    np.testing.assert_allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
+    assert rel <= 6e-5, (seed, whitted, rel)

@@ -54,3 +54,40 @@ def test_oracle_matches_reference_on_random_scene(seed, whitted):
     assert bad <= 1e-3 and rel <= 1e-4
     np.testing.assert_allclose(film[..., 3], film_ref[..., 3], rtol=1e-6, atol=1e-7)   # same sample stream
     assert frel <= 1e-4
+
+
+@pytest.mark.parametrize("seed,whitted", [(s, False) for s in range(10)] + [(s, True) for s in range(4)])
+def test_oracle_matches_reference_on_random_scene_with_round2_features(seed, whitted):
+    """The same comparison on scenes that also draw image textures, bump / normal maps, an image based light and a
+    homogeneous or heterogeneous medium (helpers.random_scene_r2): Films and records bit-identical."""
+    doc, _ = helpers.random_scene_r2(2000 + seed, whitted)
+    doc["render_setting"]["thread_num"] = 1
+    ref_doc = json.loads(json.dumps(doc))
+    for section in ("geometries", "textures", "lights"):
+        for g in ref_doc[section]:
+            if "file" in g:
+                g["file"] = os.path.join(SCENE_DIR, g["file"])
+    if "density_grid" in ref_doc.get("volume", {}):
+        ref_doc["volume"]["density_grid"] = os.path.join(SCENE_DIR, ref_doc["volume"]["density_grid"])
+    with tempfile.TemporaryDirectory() as tmp:
+        jp = os.path.join(tmp, "s.json")
+        with open(jp, "w") as f:
+            json.dump(ref_doc, f)
+        prefix = os.path.join(tmp, "o")
+        try:
+            meta = json.loads(subprocess.check_output([HARNESS, "li", jp, prefix, "1", "100000"], stderr=subprocess.DEVNULL, timeout=300).decode())
+        except (OSError, subprocess.SubprocessError) as e:   # a harness built for another machine
+            pytest.skip("ref_harness did not run here: %s" % e)
+        samples = np.fromfile(prefix + ".samples.f32", np.float32).reshape(-1, meta["dims"])
+        li_ref = np.fromfile(prefix + ".li.f32", np.float32).reshape(-1, 4)
+        film_ref = np.fromfile(prefix + ".film.f32", np.float32).reshape(meta["yres"], meta["xres"], 4)
+    scene = gs.load_scene_text(json.dumps(doc), SCENE_DIR)
+    o = ob.Oracle(scene)
+    assert o.dims() == meta["dims"] and o.window() == tuple(meta["window"])
+    li, _ = o.li_replay(samples, threads=4)
+    film = o.render(threads=1)["film"]
+    print("seed", seed, "whitted" if whitted else "pt", "volume", doc.get("volume", {}).get("type"), "records", len(li),
+          "li exact", np.array_equal(li, li_ref), "film exact", np.array_equal(film, film_ref))
+    if "volume" not in doc:   # (with a medium the oracle's per-sample output is what the tile receives, tr * L + Lv; the probe logs Li)
+        np.testing.assert_array_equal(li, li_ref)
+    np.testing.assert_array_equal(film, film_ref)
