@@ -156,6 +156,13 @@ __device__ __forceinline__ F3 light_sample_position(const DevScene& sc, const De
         const F3 disk = f3(v.bound_center[0], v.bound_center[1], v.bound_center[2]) + v.bound_radius * (dx * x + dy * y);
         return disk - z * v.bound_radius;
     }
+    if (l.type == GBL_LIGHT_IBL) {   // ImageBasedLight::samplePosition (GoblinLight.cpp:556-568): a point of the scene's bounding sphere
+        const DevVolume& v = sc.volume;
+        const float z = 1.0f - 2.0f * u1;
+        const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        const float phi = GBL_TWO_PI * u2;
+        return f3(v.bound_center[0], v.bound_center[1], v.bound_center[2]) + v.bound_radius * f3(sin_t * gbl_cosf(phi), sin_t * gbl_sinf(phi), z);
+    }
     return f3(l.pos[0], l.pos[1], l.pos[2]);
 }
 

@@ -3174,6 +3174,11 @@ V3 light_sample_position(const orc_scene* s, int li, float u_comp, float u1, flo
         V3 disk = center + radius * (dx * x + dy * y);
         return disk - z * radius;
     }
+    if (l.type == GBL_LIGHT_IBL) {   // ImageBasedLight::samplePosition (:556-568): a point of the scene's bounding sphere
+        V3 center = 0.5f * (s->tlas.bounds.lo + s->tlas.bounds.hi);
+        float radius = length(s->tlas.bounds.hi - s->tlas.bounds.lo);
+        return center + radius * uniform_sample_sphere(u1, u2);
+    }
     return l.pos;
 }
 inline float vol_rand_next(VolRand& rnd) { return rnd.f(); }
