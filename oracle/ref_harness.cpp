@@ -258,7 +258,9 @@ static int image_mode(int argc, char** argv) {
         int w = 0, h = 0;
         Color* c = loadImage(argv[2], &w, &h);
         if (!c) return 1;
-        MIPMap<Color> mip(c, w, h, static_cast<float>(atof(argv[7])));
+        Color* copy = new Color[static_cast<size_t>(w) * h];   // (MIPMap takes ownership with delete[]; loadImage's buffer is malloc'ed)
+        memcpy(copy, c, sizeof(Color) * static_cast<size_t>(w) * h);
+        MIPMap<Color> mip(copy, w, h, static_cast<float>(atof(argv[7])));
         FILE* f = fopen(argv[3], "rb");
         if (!f) return 1;
         fseek(f, 0, SEEK_END);
