@@ -149,6 +149,25 @@ static int block_trace_wanted() {   // 1: blocktrace.h, 2: rayexchange.h
     return e != nullptr ? atoi(e) : 0;
 }
 
+// Random numbers one camera sample's transmittance + Lv may draw (GBL_SAMPLES_STREAM sizes a pixel's tail with it): 9 per light
+// sample and the pick for the homogeneous region; for a heterogeneous one the jitters and up to 5 per point of the march,
+// whose length is bounded by the region's longest world-space diagonal over the step (kernels/render_kernels.h
+// stream_medium_phase) -- plus room for the generator state that phase sets aside.
+static uint64_t medium_draws_per_sample(const DevScene& sc) {
+    if (sc.volume.on == 0u) return 0;
+    if (sc.volume.hetero == 0u) return 9ull * static_cast<uint64_t>(std::max(0, sc.volume.sample_num)) + 1;
+    const DevVolume& v = sc.volume;
+    double diag = 0.0;
+    for (int s = 0; s < 4; ++s) {
+        const double e[3] = {double(v.hi[0] - v.lo[0]), (s & 1 ? -1.0 : 1.0) * double(v.hi[1] - v.lo[1]), (s & 2 ? -1.0 : 1.0) * double(v.hi[2] - v.lo[2])};
+        double w[3];
+        for (int r = 0; r < 3; ++r) w[r] = v.m[4 * r] * e[0] + v.m[4 * r + 1] * e[1] + v.m[4 * r + 2] * e[2];
+        diag = std::max(diag, std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+    }
+    const double steps = std::floor(diag / std::max(1e-6, double(v.step))) + 3.0;
+    return 2ull + 5ull * static_cast<uint64_t>(std::min(steps, 1.0e6)) + 700ull;
+}
+
 // Stack levels of the wavefront trace kernels beyond the LDS part: one column per thread of the largest persistent
 // trace grid (8 workgroups per CU).  Re-made when an instance edit deepens the TLAS.
 gbl_status wf_ensure_spill(gbl_ctx* ctx) {
@@ -764,12 +783,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         return GBL_ERR_UNSUPPORTED;
     }
     const bool replay = p->sample_mode == GBL_SAMPLES_REPLAY || stream_mode;
-    if (stream_mode && sc.volume.on != 0u && sc.volume.hetero != 0u) {
-        // the stream sampler lays a pixel's medium draws out ahead of time (9 per light sample); the ray marcher's count
-        // depends on what it meets (HeterogeneousVolumeRegion::transmittance, Renderer::Lv, GoblinRenderer.cpp:397-445)
-        ctx->error = "GBL_SAMPLES_STREAM does not cover a heterogeneous medium (data-dependent number of random numbers per sample): use the native or replay sampler";
-        return GBL_ERR_UNSUPPORTED;
-    }
     if (stream_mode) {
         if (p->schedule == GBL_SCHEDULE_WAVEFRONT) {
             ctx->error = "GBL_SAMPLES_STREAM runs on the megakernel schedule";
@@ -930,7 +943,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             if (sc.volume.on != 0u) {
                 uint64_t slots = 0;
                 for (int i = 0; i < sc.num_lights; ++i) slots += ctx->h_light_slots[i];
-                const uint64_t med = 9ull * static_cast<uint64_t>(std::max(0, sc.volume.sample_num)) + 1;
+                const uint64_t med = medium_draws_per_sample(sc);
                 const uint64_t worst = ((2ull << std::min(ra.max_depth, 20)) - 1) * (6 * slots + 6) + med;
                 tail = static_cast<uint32_t>(std::max<uint64_t>(med, std::min<uint64_t>(worst, (1ull << 20) / L.S)));
                 if (const char* e = getenv("GBL_STREAM_TAIL")) tail = static_cast<uint32_t>(std::max<uint64_t>(med, strtoull(e, nullptr, 10)));   // tests: force the chunked walk
@@ -1028,11 +1041,11 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
                                                  p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
             // a sample's tail in the stream: up to 6 discarded floats per bounce, 9 per light sample of the medium
-            const uint32_t tail = (p->integrator == GBL_INTEGRATOR_AO ? 0u : 6u * static_cast<uint32_t>(ra.max_depth)) +
-                                  (sc.volume.on ? 9u * static_cast<uint32_t>(std::max(0, sc.volume.sample_num)) + 1u : 0u);
+            const uint32_t med = static_cast<uint32_t>(medium_draws_per_sample(sc));
+            const uint32_t tail = (p->integrator == GBL_INTEGRATOR_AO ? 0u : 6u * static_cast<uint32_t>(ra.max_depth)) + med;
             uint32_t tail_words = tail;
             if (const char* e = getenv("GBL_STREAM_TAIL"))   // tests: force the medium phase's chunked walk
-                if (sc.volume.on) tail_words = std::max<uint32_t>(9u * static_cast<uint32_t>(std::max(0, sc.volume.sample_num)) + 1u, static_cast<uint32_t>(strtoul(e, nullptr, 10)));
+                if (sc.volume.on) tail_words = std::max<uint32_t>(med, static_cast<uint32_t>(strtoul(e, nullptr, 10)));
             ra.stream_tail_cap = L.S * tail_words;
             gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail_words), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;

@@ -285,6 +285,83 @@ template <bool STATS, class STK>
 __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, const StreamCtx& scx, const StreamLayout& slay, const StreamVol& sv,
                                     uint32_t* ctrl, float4* li, const STK& stk, LaneCounters& cnt) {
     __syncthreads();
+    if (sc.volume.hetero != 0u) {
+        // A heterogeneous region: how many numbers a sample's transmittance and Lv draw depends on what the march meets
+        // (4 per step, a 5th when the light sample is unoccluded), and sample k + 1 starts where sample k stopped -- so the
+        // pixel's samples are taken ONE AFTER THE OTHER, by one lane, each reading the stream from where the previous one
+        // left it.  Per chunk of samples: remember the generator's state, emit an upper bound of the chunk's draws (a
+        // sample's march is at most floor((t1 - t0) / step) + 2 points long), let lane 0 walk the chunk and count what it
+        // really drew, then put the generator back and advance it by exactly that.  (Slow -- a tile runs on one lane here --
+        // and only ever used where the reference's own Film is wanted.)
+        const uint32_t cap = ra.stream_tail_cap - (GBL_MT_N + 16u);
+        uint32_t* save = sv.raw + cap;
+        for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
+            const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+            F3 o, d;
+            float mint;
+            camera_ray<true>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
+            float t0, t1;
+            uint32_t bound = 0u;
+            if (vol_intersect(sc.volume, o, d, mint, sv.t[k], &t0, &t1)) {
+                bound = 1u;   // transmittance's jitter
+                if (!((t1 - t0) < 1e-5f)) bound += 1u + 5u * (static_cast<uint32_t>(fminf(floorf((t1 - t0) / sc.volume.step), 1.0e6f)) + 2u);
+            }
+            sv.off[k] = bound;
+        }
+        uint32_t k0 = 0;
+        while (k0 < slay.S) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t run = sv.off[k0], k1 = k0 + 1;
+                while (k1 < slay.S && run + sv.n[k1] + sv.off[k1] <= cap) {
+                    run += sv.n[k1] + sv.off[k1];
+                    k1 += 1;
+                }
+                ctrl[1] = sv.n[k0];
+                ctrl[2] = min(run, cap);
+                ctrl[3] = k1;
+            }
+            __syncthreads();
+            const uint32_t skip = ctrl[1], total = ctrl[2], k1 = ctrl[3];
+            __syncthreads();
+            stream_emit(scx, nullptr, skip);
+            for (uint32_t t = threadIdx.x; t < GBL_MT_N; t += GBL_BLOCK) save[t] = scx.mt[t];
+            if (threadIdx.x == 0) save[GBL_MT_N] = *scx.pos;
+            __syncthreads();
+            stream_emit(scx, sv.raw, total);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t pos = 0;
+                for (uint32_t k = k0; k < k1; ++k) {
+                    if (k > k0) pos += sv.n[k];
+                    const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;
+                    F3 o, d;
+                    float mint;
+                    camera_ray<true>(sc.camera, rec[0], rec[1], rec[2], rec[3], &o, &d, &mint);
+                    VolRand rnd;
+                    rnd.raw = sv.raw + pos;
+                    rnd.key = 0u;
+                    rnd.i = 0u;
+                    const F3 tr = vol_transmittance(sc, o, d, mint, sv.t[k], rnd);
+                    const F3 Lv = volume_lv<STATS>(sc, o, d, mint, sv.t[k], rnd, stk, cnt);
+                    const float4 L = li[k];
+                    li[k] = make_float4(1.0f * (tr.x * L.x + Lv.x), 1.0f * (tr.y * L.y + Lv.y), 1.0f * (tr.z * L.z + Lv.z), L.w);
+                    pos += rnd.i;
+                }
+                ctrl[2] = pos;
+            }
+            __syncthreads();
+            const uint32_t consumed = ctrl[2];
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < GBL_MT_N; t += GBL_BLOCK) scx.mt[t] = save[t];
+            if (threadIdx.x == 0) *scx.pos = save[GBL_MT_N];
+            __syncthreads();
+            stream_emit(scx, nullptr, consumed);
+            k0 = k1;
+        }
+        __syncthreads();
+        return;
+    }
     const uint32_t per = static_cast<uint32_t>(max(0, sc.volume.sample_num)) * (sc.num_lights > 0 ? 9u : 1u);
     for (uint32_t k = threadIdx.x; k < slay.S; k += GBL_BLOCK) {
         const float* rec = scx.recs + static_cast<size_t>(k) * ra.dims;

@@ -143,7 +143,8 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_config1", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "shapes_ao", "bunny_vn_box", "cornell_triangle_crop",
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
-                                  "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao"])
+                                  "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao",
+                                  "hetero_pt", "hetero_spot", "hetero_tint_whitted", "hetero_tint_ao"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
     """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
     Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators
@@ -337,8 +338,8 @@ def test_participating_medium_matches_oracle(torch, schedule, ov):
 def test_heterogeneous_medium_matches_oracle(torch, schedule, name, ov):
     """HeterogeneousVolumeRegion (GoblinVolume.cpp:283-341) behind RenderTask's tr * L + Lv: density from a .vol grid
     (trilinear, one and three channels), jittered ray-marched transmittance, Renderer::Lv's marching branch with its
-    data-dependent number of draws per sample (hashed in sequence here and in the oracle; the oracle's own stream mode is
-    pinned to the compiled reference's Film in tests/test_oracle_vs_reference.py).  Same radiance bit for bit."""
+    data-dependent number of draws per sample (hashed in sequence here and in the oracle; under the stream sampler the
+    pixel's samples are walked one after the other, test_stream_mode_reproduces_the_reference_film).  Same radiance bit for bit."""
     seed = 17
     scene = gs.load_scene(name, ov)
     o = ob.Oracle(scene)
@@ -354,14 +355,6 @@ def test_heterogeneous_medium_matches_oracle(torch, schedule, name, ov):
     print(name, "heterogeneous medium: flips", flips, "sample relL2", rel, "film relL2", frel, "mean", li_ref[:, :3].mean())
     assert li_ref[:, :3].mean() > 1e-3
     assert flips <= LI_FLIP_TOL and rel <= LI_RELL2_TOL and frel <= FILM_RELL2_TOL
-
-
-def test_heterogeneous_medium_is_refused_under_the_stream_sampler(torch):
-    """The stream sampler lays a pixel's medium draws out ahead of time; the ray marcher's count depends on the data."""
-    from goblin_amd.renderer import HipPathTracer
-    scene = gs.load_scene("hetero", gs.config_overrides(resolution=(16, 16), spp=1, depth=2))
-    with pytest.raises(RuntimeError, match="heterogeneous"):
-        HipPathTracer(scene, 0).render(sampler="stream")
 
 
 def test_headline_scene_radiance_is_bit_identical(torch, schedule):

@@ -24,7 +24,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
                 bad.append((seed, whitted, schedule, n))
                 print("MISMATCH seed", seed, "whitted" if whitted else "pt", schedule, n, "of", li.shape[0], "volume", doc.get("volume", {}).get("type"),
                       "lights", [(l["type"], l.get("geometry")) for l in doc["lights"]], flush=True)
-        if not hetero:
+        if True:
             ref = o.render(threads=1)["film"]
             film = r.render(sampler="stream")["film"].numpy()
             rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
