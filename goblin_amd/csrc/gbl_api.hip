@@ -843,12 +843,8 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         return GBL_ERR_UNSUPPORTED;
     }
     bool wavepool = p->schedule == GBL_SCHEDULE_WAVEPOOL;
-    // (image textures / image based lights: their MIPMap lookups are out-of-line calls (kernels/image.h), and the lean
-    //  native instantiation of the wave-pool kernel came out with different radiance on imagetex.json -- 14 % of the samples
-    //  -- while its replay and instrumented instantiations, and every other schedule, match the oracle; until that is
-    //  understood the schedule refuses such scenes rather than render them differently)
-    if (wavepool && (!wf_capable || stream_mode || sc.has_masks || ctx->has_images)) {
-        ctx->error = "the wave-pool schedule covers the path tracer on scenes without mask materials, image textures or image based lights, under the native and replay samplers";
+    if (wavepool && (!wf_capable || stream_mode || sc.has_masks)) {
+        ctx->error = "the wave-pool schedule covers the path tracer on scenes without mask materials, under the native and replay samplers";
         return GBL_ERR_UNSUPPORTED;
     }
     // the wave-pool kernel writes per-sample radiance only (no LDS film tile): a call whose radiance buffer exceeds the

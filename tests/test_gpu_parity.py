@@ -45,9 +45,9 @@ def schedule(request):
 
 def scene_has_masks(scene):
     """What the wave-pool kernel refuses: materials whose type carries BSDFnullptr -- masks, and subsurface materials
-    (BSDFAll), DevScene::has_masks -- and scenes with image textures / image based lights."""
+    (BSDFAll), DevScene::has_masks."""
     d = scene.desc
-    return d.num_images > 0 or any(d.materials[i].type in (_abi.GBL_MAT_MASK, _abi.GBL_MAT_SUBSURFACE) for i in range(d.num_materials))
+    return any(d.materials[i].type in (_abi.GBL_MAT_MASK, _abi.GBL_MAT_SUBSURFACE) for i in range(d.num_materials))
 
 
 class _Scheduled:
