@@ -144,6 +144,10 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
 }
 
 // Experiment switch of the megakernel's workgroup-level tracing (kernels/blocktrace.h)
+static bool suspend_wanted() {   // kernels/suspend.h
+    const char* e = getenv("GBL_MK_SUSPEND");
+    return e != nullptr && atoi(e) != 0;
+}
 static int block_trace_wanted() {   // 1: blocktrace.h, 2: rayexchange.h
     const char* e = getenv("GBL_MK_BLOCKTRACE");
     return e != nullptr ? atoi(e) : 0;
@@ -170,8 +174,8 @@ static uint64_t medium_draws_per_sample(const DevScene& sc) {
 
 // Stack levels of the wavefront trace kernels beyond the LDS part: one column per thread of the largest persistent
 // trace grid (8 workgroups per CU).  Re-made when an instance edit deepens the TLAS.
-gbl_status wf_ensure_spill(gbl_ctx* ctx) {
-    const int deep = ctx->scene.stack_entries > GBL_WF_STACK_LDS ? ctx->scene.stack_entries - GBL_WF_STACK_LDS : 1;
+gbl_status wf_ensure_spill(gbl_ctx* ctx, int min_levels = 0) {
+    const int deep = std::max(min_levels, ctx->scene.stack_entries > GBL_WF_STACK_LDS ? ctx->scene.stack_entries - GBL_WF_STACK_LDS : 1);
     if (ctx->wf_spill && deep <= ctx->wf_spill_levels) return GBL_OK;
     if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
     ctx->wf_spill = nullptr;
@@ -1128,6 +1132,13 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
             grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * 8);   // (the occupancy query below trims it; the stack backing holds 8 per CU)
             grid = dim3(static_cast<unsigned>(grid64));
+        }
+        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted() == 0 && suspend_wanted()) {
+            // kernels/suspend.h: the extension query parks its last stragglers (16 words per thread, in the stack backing buffer)
+            kernel = gbl_kernel_path_suspend(replay, want_stats, ext || want_stats);
+            gbl_status sst = wf_ensure_spill(ctx, static_cast<int>(gbl_suspend_park_words()));
+            if (sst != GBL_OK) return sst;
+            ra.bt_spill = ctx->wf_spill;
         }
         if (wavepool && !defer) {
             ctx->error = "the wave-pool schedule keeps 16 bytes per camera sample of the call: render this window in smaller pieces";

@@ -92,6 +92,9 @@ uint32_t gbl_block_trace_lds_words(void);   // LDS words of the exchange area, b
 // kernels_exchange.hip: the megakernel whose waves hand their long rays to one another through LDS (kernels/rayexchange.h)
 gbl_render_kernel gbl_kernel_path_exchange(bool replay, bool stats, bool ext);
 uint32_t gbl_ray_exchange_lds_words(void);
+// kernels_suspend.hip: the megakernel whose extension queries park their last stragglers (kernels/suspend.h)
+gbl_render_kernel gbl_kernel_path_suspend(bool replay, bool stats, bool ext);
+uint32_t gbl_suspend_park_words(void);   // words of parked traversal state per thread
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext);

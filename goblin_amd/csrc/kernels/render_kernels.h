@@ -24,6 +24,7 @@
 #include "trace.h"
 #include "blocktrace.h"
 #include "rayexchange.h"
+#include "suspend.h"
 #include "vecmath.h"
 
 struct ItemInfo {
@@ -419,7 +420,8 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 // few node visits, the surviving rays packed into as few waves as hold them in between); everything else is unchanged.
 // RX: the same two rays go through the workgroup's ray exchange instead (kernels/rayexchange.h: no barriers; the waves hand
 // their long rays to one another through LDS and help with whatever waits there while their own results are out).
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false, bool RX = false>
+// SUSP: the extension query leaves its last few stragglers for the next iteration (kernels/suspend.h).
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false, bool RX = false, bool SUSP = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
@@ -442,6 +444,9 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
         bx.spill_stride = ra.bt_spill_stride;
     }
     static_assert(!(RX && (STREAM || BT)), "the ray exchange is built for the native / replay samplers");
+    static_assert(!(SUSP && (STREAM || BT || RX)), "suspendable queries are built for the plain megakernel under the native / replay samplers");
+    gbl_glb_u32* const susp_park = SUSP ? gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK + threadIdx.x) : nullptr;
+    bool susp = false;   // SUSP: this lane's extension ray is parked
     RayXch rx = {};
     if constexpr (RX) {   // LDS: ... | stacks: min(stack_entries, GBL_WF_STACK_LDS) levels | records | owner columns | flags | ring | counters
         const int lds_levels = sc.stack_entries < GBL_WF_STACK_LDS ? sc.stack_entries : GBL_WF_STACK_LDS;
@@ -604,6 +609,14 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 got = trace_rx<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, rx, hit, cnt, GBL_FILTER_NONE);
                 if (active && !want) finished = true;
                 if (STATS && want) cnt.ext += 1;
+            } else if constexpr (SUSP) {
+                const bool want = active && sc.num_lights != 0;
+                bool done = false, parked = false;
+                got = trace_suspendable<STATS, EXT, REPLAY || STATS>(sc, want && !susp, want && susp, ps.o, ps.d, ps.mint, susp_park, ra.bt_spill_stride, stk,
+                                                                       hit, cnt, &done, &parked);
+                if (STATS && want && !susp) cnt.ext += 1;
+                susp = parked;
+                if (active && !want) finished = true;
             } else if (active) {
                 if (sc.num_lights == 0) {
                     finished = true;   // PathTracer::Li returns Black without lights (:53-56)
@@ -612,9 +625,11 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     if (STATS) cnt.ext += 1;
                 }
             }
+            // (SUSP: a lane whose ray is parked sits this iteration's shading out; its path state is untouched)
+            const bool vis = SUSP ? (active && !susp) : active;
             Frag fr;
             TexFrag tf;
-            if (active && !finished) {
+            if (vis && !finished) {
                 if (got) {
                     make_fragment<EXT>(sc, hit, ps.o, ps.d, fr, &tf);
                     if (EXT && sc.materials[sc.instances[hit.inst].material].has_tex != 0u)
@@ -715,7 +730,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             float l_cos = 0.0f, l_w = 1.0f, l_pdf = 1.0f;
             bool l_area = false;
             float u_bsdf_c = 0.0f, u_bsdf_1 = 0.0f, u_bsdf_2 = 0.0f;
-            if (active && !finished) {
+            if (vis && !finished) {
                 const int b = ps.bounce;
                 float u_light_c, u_light_1, u_light_2, u_pick;
                 if (REPLAY) {
@@ -801,7 +816,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 }
             }
             // ---- BSDF sample: the next ray
-            if (active && !finished) {
+            if (vis && !finished) {
                 F3 wi;
                 float pdf;
                 bool specular;
@@ -854,7 +869,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 }
             }
             // ---- path end: splat and free the lane
-            if (active && finished) {
+            if (vis && finished) {
                 // RenderTask::run: w * (tr * L + Lv), w = 1, tr = 1, Lv = 0
                 if (ra.li_defer) {
                     reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);

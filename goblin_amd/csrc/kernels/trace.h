@@ -202,6 +202,13 @@ __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st,
     if (STATS) {
         cnt.nodes += 4;
         probe(cnt.int_lane, cnt.int_wave);
+#ifdef GBL_PROBE_OCC
+        {   // experiment build: interior wave-steps by the number of lanes inside them (bins <= 4, 8, 16, 32, 64 in hist[0..4])
+            const unsigned long long m = __ballot(1);
+            const int n = __popcll(m);
+            if ((threadIdx.x & 63) == __ffsll(static_cast<long long>(m)) - 1) cnt.hist[n <= 4 ? 0 : (n <= 8 ? 1 : (n <= 16 ? 2 : (n <= 32 ? 3 : 4)))] += 1;
+        }
+#endif
     }
     int sp = st.sp;
     if (SORTED) {
@@ -437,11 +444,13 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
             break;
         }
     }
+#ifndef GBL_PROBE_OCC
     if (STATS && !ANY) {
         int b = steps <= 3 ? 0 : min(6, 30 - __clz(static_cast<int>(steps)));
         cnt.hist[b] += 1;
         cnt.hist_steps[b] += steps;
     }
+#endif
     if (ANY) return occluded;
     hit = st.hit;
     return st.hit.inst >= 0;

@@ -409,12 +409,13 @@ def test_paired_query_megakernel_is_bit_identical(torch, monkeypatch):
         np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "suspend"])
 def test_workgroup_tracing_experiments_are_bit_identical(torch, monkeypatch, mode):
     """GBL_MK_BLOCKTRACE=1 (kernels/blocktrace.h: the workgroup's rays traced in rounds, survivors packed into fewer waves at
     barriers) and =2 (kernels/rayexchange.h: waves hand their long rays to one another through an LDS ring) move rays between
-    lanes but never change a ray's own sequence of node visits: same radiance bit for bit, masks / shapes / textures / image
-    lookups / medium and the film included.  (Measured slower than the plain megakernel, DESIGN.md 4.1: kept as experiments.)"""
+    lanes, GBL_MK_SUSPEND=1 (kernels/suspend.h) parks a wave's last stragglers until its next extension query; none of them
+    changes a ray's own sequence of node visits: same radiance bit for bit, masks / shapes / textures / image lookups /
+    medium and the film included.  (Measured slower than the plain megakernel, DESIGN.md 4.1: kept as experiments.)"""
     from goblin_amd.renderer import HipPathTracer
     for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=8)),
                      ("cornell", gs.config_overrides(resolution=(48, 48), spp=16, depth=12)),
@@ -424,8 +425,12 @@ def test_workgroup_tracing_experiments_are_bit_identical(torch, monkeypatch, mod
                      ("volume", gs.config_overrides(resolution=(32, 32), spp=4, depth=4))):
         scene = gs.load_scene(name, ov)
         monkeypatch.delenv("GBL_MK_BLOCKTRACE", raising=False)
+        monkeypatch.delenv("GBL_MK_SUSPEND", raising=False)
         ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        monkeypatch.setenv("GBL_MK_BLOCKTRACE", mode)
+        if mode == "suspend":
+            monkeypatch.setenv("GBL_MK_SUSPEND", "1")
+        else:
+            monkeypatch.setenv("GBL_MK_BLOCKTRACE", mode)
         got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
         np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
         np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
