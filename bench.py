@@ -81,7 +81,9 @@ def pmc_for(kernel_tag, workload, schedule):
             return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp), None
         return None, "no wavefront kernels in %s" % os.path.basename(path)
     for name, c in d.get("counters_per_launch", {}).items():
-        if kernel_tag in name:
+        # the lean instantiation: the named kernel with every template argument false (the list grows with the experiments)
+        base = kernel_tag.split("<")[0]
+        if (" " + base + "<") in (" " + name) and all(_template_arg(name, i) in ("false", None) for i in range(12)) and _template_arg(name, 0) == "false":
             return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp), None
     return None, "no kernel matching %r in %s" % (kernel_tag, os.path.basename(path))
 
@@ -360,7 +362,7 @@ def main():
         avg_kernel_ms = sum(main_ms) / args.steps if timings else sum(main_ms) / len(main_ms)   # per step (a step is len(bands) calls)
         alg_bytes = algorithmic_bytes(counted)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        kernel_tag = {"megakernel": "path_trace_kernel<false, false, false, false, false, false>", "wavepool": "wp_kernel<false, false, false>",
+        kernel_tag = {"megakernel": "path_trace_kernel<false, ...>", "wavepool": "wp_kernel<false, false, false>",
                       "wavefront": "wf_trace<false, false, false, false, false>"}[resolved]
         if wl_extra.get("method") == "ao":
             kernel_tag = "ao_kernel<false, false, false, false>"
