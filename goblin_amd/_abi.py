@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 12
+GBL_ABI_VERSION = 13
 GBL_AUTO_WAVEFRONT_DEPTH, GBL_AUTO_WAVEFRONT_TRIS = 12, 400000   # gbl_schedule AUTO thresholds (goblin_hip.h)
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM, GBL_ERR_INTERNAL = range(7)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
@@ -133,7 +133,7 @@ class gbl_render_params(C.Structure):
 class gbl_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("nodes", C.c_uint64), ("tris", C.c_uint64), ("splats", C.c_uint64), ("dims", C.c_uint64),
-                ("kernel_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("schedule", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -839,9 +839,14 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
     // instanced triangles (config 4, 15 bunnies: 300 ms against 438 ms).  AO always runs the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
     // filtered MIS query and the attenuation walks inline in the trace kernel: 48.6 ms against 16.1 ms on masked.json).
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
+    // ... and when the lean megakernel's full-depth LDS stacks would leave room for two workgroups per CU instead of three:
+    // 3 * (TLAS + BLAS depth) + 2 entries per lane is 47 KB for the bunny (13 + 2 levels: three workgroups just fit), 50 KB one
+    // BLAS level deeper -- and a third fewer waves cost 28 % (bunny with 2-triangle leaves: 66 against 51 ms; the wavefront's
+    // trace kernel keeps 16 levels in LDS and the rest in a global backing column, and runs that scene in 56 ms)
+    const bool mk_lds_cliff = sc.extended == 0 && lds * 3 > 160 * 1024;
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
-                                                                          ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS)));
+                                                                          ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS || mk_lds_cliff)));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
         ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;
@@ -980,6 +985,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             memset(stats, 0, sizeof(*stats));
             stats->kernel_ms = ms;
+            stats->schedule = GBL_SCHEDULE_MEGAKERNEL;
             stats->paths = npix * ra.spp;
             if (want_stats) {
                 unsigned long long h[32];
@@ -1186,6 +1192,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         memset(stats, 0, sizeof(*stats));
         stats->kernel_ms = ms;
+        stats->schedule = wavefront ? GBL_SCHEDULE_WAVEFRONT : (wavepool ? GBL_SCHEDULE_WAVEPOOL : GBL_SCHEDULE_MEGAKERNEL);
         uint64_t shard_pixels = 0;
         for (int t = ra.shard_index; t < total_tiles; t += ra.shard_count) {
             int tx = t % ra.tiles_x, ty = t / ra.tiles_x;

@@ -255,7 +255,10 @@ struct Builder {
         }
         int room = depth_cap - depth;   // levels available below this node
         // binned SAH over the centroid bounds, all three axes
-        const int B = 16;
+        // (tuning knobs like GBL_SAH_CT: GBL_SAH_BINS, and GBL_MAX_LEAF below.  On bunny.json 8 / 16 / 32 bins trace alike --
+        //  51.3 / 51.3 / 51.1 ms -- while 64 bins or 2-triangle leaves add a BLAS level and with it the LDS for a third
+        //  workgroup per CU: 65.6 / 66.1 ms)
+        static const int B = [] { const char* e = getenv("GBL_SAH_BINS"); return e ? std::max(4, std::min(64, atoi(e))) : 16; }();
         float best_cost = INFINITY;
         int best_axis = -1, best_bin = -1;
         float parent_area = box.half_area();
@@ -263,16 +266,16 @@ struct Builder {
             for (int axis = 0; axis < 3; ++axis) {
                 float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
                 if (!(ext > 0.0f)) continue;
-                Aabb bb[B];
-                size_t bn[B] = {0};
+                Aabb bb[64];
+                size_t bn[64] = {0};
                 float scale = B / ext;
                 for (size_t i = start; i < end; ++i) {
                     int b = std::min(B - 1, static_cast<int>((prims[i].c[axis] - lo) * scale));
                     bb[b].grow(prims[i].box);
                     bn[b]++;
                 }
-                Aabb right_acc[B];
-                size_t right_n[B];
+                Aabb right_acc[64];
+                size_t right_n[64];
                 Aabb acc;
                 size_t cnt = 0;
                 for (int b = B - 1; b >= 1; --b) {
@@ -709,7 +712,8 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
             for (int k = 0; k < 3; ++k) s.v[k] = gm.vertex_offset + I[3 * t + k];
             s.flags = (gm.has_normal ? 1u : 0u) | (gm.has_uv ? 2u : 0u);
         }
-        Builder b(prims, GBL_MAX_LEAF_TRIS, kBlasCap);
+        const int leaf_knob = [] { const char* e = getenv("GBL_MAX_LEAF"); return e ? std::max(1, std::min(GBL_MAX_LEAF_TRIS, atoi(e))) : GBL_MAX_LEAF_TRIS; }();
+        Builder b(prims, leaf_knob, kBlasCap);
         int root = b.build_parallel(prims.size());
         Flat4 f4(b, out->nodes);
         uint32_t tri_base = static_cast<uint32_t>(out->tris.size());

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 12
+#define GBL_ABI_VERSION 13
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -464,6 +464,8 @@ typedef struct gbl_stats {
     uint64_t splats;         /* film pixel updates                            */
     uint64_t dims;           /* sample dimensions consumed (floats)           */
     double kernel_ms;        /* HIP-event time of the render kernel(s)        */
+    uint32_t schedule;       /* the gbl_schedule the call ran under (what GBL_SCHEDULE_AUTO resolved to; megakernel for AO / Whitted) */
+    uint32_t reserved;
 } gbl_stats;
 
 /* Build the two-level BVH on the host, pack and upload the scene once

@@ -29,7 +29,8 @@ _lib = None
 def build_oracle():
     """Compile liboracle.so if it is missing or stale (g++, a few seconds)."""
     src = os.path.join(ORACLE_DIR, "goblin_oracle.cpp")
-    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    hdr = os.path.join(os.path.dirname(ORACLE_DIR), "include", "goblin_hip.h")   # the ABI structs (and version) it is compiled against
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
 
 

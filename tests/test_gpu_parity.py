@@ -436,6 +436,25 @@ def test_workgroup_tracing_experiments_are_bit_identical(torch, monkeypatch, mod
         np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_auto_schedule_avoids_the_megakernels_lds_cliff(torch, monkeypatch):
+    """GBL_SCHEDULE_AUTO: bunny.json at depth 8 runs the megakernel (47 stack entries per lane: three workgroups per CU just
+    fit); the same scene built with 2-triangle leaves (GBL_MAX_LEAF=2: one BLAS level more, 50 entries) would leave room for
+    two, so AUTO takes the wavefront schedule there (56 against 66 ms at full size).  gbl_stats reports what ran; the
+    radiance is the same either way."""
+    from goblin_amd.renderer import HipPathTracer
+    ov = gs.config_overrides(resolution=(96, 96), spp=16, depth=8)
+    monkeypatch.delenv("GBL_MAX_LEAF", raising=False)
+    r = HipPathTracer(gs.load_scene("bunny", ov), 0)
+    a = r.render(seed=5, want_li=True, stats=True)
+    assert a["stats"]["schedule"] == 1 and 3 * (r.info.blas_depth + r.info.tlas_depth) + 2 <= 48
+    monkeypatch.setenv("GBL_MAX_LEAF", "2")
+    r2 = HipPathTracer(gs.load_scene("bunny", ov), 0)
+    b = r2.render(seed=5, want_li=True, stats=True)
+    assert 3 * (r2.info.blas_depth + r2.info.tlas_depth) + 2 > 48 and b["stats"]["schedule"] == 2
+    assert r2.render(seed=5, stats=True, schedule="megakernel")["stats"]["schedule"] == 1
+    np.testing.assert_array_equal(a["li"].cpu().numpy().view(np.uint32), b["li"].cpu().numpy().view(np.uint32))
+
+
 def test_wavefront_without_stream_overlap_keeps_its_stack_backing_in_bounds(torch, monkeypatch):
     """GBL_WF_NO_OVERLAP=1 serialises the shadow and extension trace launches on one stream; each then takes the full
     occupancy, and both must stay inside the stack backing (deep BVH: the bunny's stacks spill past the 16 LDS levels)."""
