@@ -144,6 +144,10 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
 }
 
 // Experiment switch of the megakernel's workgroup-level tracing (kernels/blocktrace.h)
+static bool quad_wanted() {   // kernels/quadtrace.h
+    const char* e = getenv("GBL_MK_QUAD");
+    return e && e[0] != '\0' && e[0] != '0';
+}
 static bool suspend_wanted() {   // kernels/suspend.h
     const char* e = getenv("GBL_MK_SUSPEND");
     return e != nullptr && atoi(e) != 0;
@@ -1145,6 +1149,15 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             gbl_status sst = wf_ensure_spill(ctx, static_cast<int>(gbl_suspend_park_words()));
             if (sst != GBL_OK) return sst;
             ra.bt_spill = ctx->wf_spill;
+        }
+        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted() == 0 && !suspend_wanted() && defer && quad_wanted() &&
+            !(pair_candidate && getenv("GBL_MK_PAIRED"))) {
+            // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records
+            // take the LDS film tile's place
+            kernel = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
+            lds = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         }
         if (wavepool && !defer) {
             ctx->error = "the wave-pool schedule keeps 16 bytes per camera sample of the call: render this window in smaller pieces";

@@ -1,0 +1,326 @@
+// Quad-per-ray interior steps for the persistent megakernel: when at most GBL_QUAD_MAX lanes of a wave stand at interior
+// nodes, the wave's 64 lanes regroup as 16 quads, one quad per such ray, and every lane of a quad tests ONE of the node's
+// four children; the five compare-exchanges of trav_interior's sorting network run across the quad on DPP.
+//
+// Why: the megakernel is bound by VALU issue, and 60 % of its interior wave-steps run with <= 4 of 64 lanes,
+// 83 % with <= 16 (the few rays of a wave that wander through the bunny's BLAS).  The round's earlier experiments made
+// those sparse steps RARE by moving rays between lanes, waves or iterations, and lost to the idle waves that creates; this
+// one leaves every ray in its lane and makes the sparse step CHEAP: a quad step is one box test per lane (~60 VALU
+// instructions with the sort) where the plain step is four (~150).  Occupancy, path state and the per-ray sequence of node
+// visits are untouched, so hits, ties and radiance are bit-identical (Scene::intersect / occluded, GoblinBVH.cpp:189-280).
+//
+// A query starts as trace() does, one ray per lane.  Once at most 16 of the wave's rays are unfinished they MIGRATE: each
+// publishes its traversal state to a record of the wave's LDS slab (rank order), quad q takes record q and owns that ray for
+// the rest of the query -- interior steps with one child per lane, leaf / instance steps replicated in its four lanes,
+// pushing to and popping from the ray's own LDS stack column -- and hands the hit back through the record at the end.
+// (A first form returned every ray to its lane after each run of interior steps: 27 % fewer VALU instructions and no
+// faster -- two LDS round trips per run on a chain that is latency bound once the VALU work shrinks.)  LDS operations of
+// one wave execute in order, so the slab and the foreign stack columns need no barrier, only compiler fences.
+#pragma once
+#include "trace.h"
+
+#ifndef GBL_QUAD_MAX
+#define GBL_QUAD_MAX 16           // rays per run: 64 lanes / 4
+#endif
+// record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8)
+// result (same words, written by the quad's first lane): hit.inst hit.tri hit.b1 hit.b2 hit.t occluded steps
+#define GBL_QUAD_REC_WORDS 21
+#define GBL_QUAD_LDS_WORDS ((GBL_BLOCK / 64) * 16 * GBL_QUAD_REC_WORDS)
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp_f(float v) {
+    return __uint_as_float(quad_dpp<CTRL>(__float_as_uint(v)));
+}
+#define GBL_QP_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define GBL_QP_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define GBL_QP_MID 0xD8    // quad_perm [0,2,1,3]
+#define GBL_QP_BC0 0x00    // quad_perm [0,0,0,0]
+
+// One compare-exchange of GBL_CSWAP across lanes.  `side` is -INFINITY in the lane that holds the pair's first element and
+// +INFINITY in the one that holds its second: med3(t, partner, side) is then min(t, partner) / max(t, partner), and a lane
+// takes the partner's pair exactly when that differs from its own t -- the strict `tb < ta` swap of GBL_CSWAP (equal
+// entries stay where they are).  Entry distances are never NaN (child_entry).
+template <int CTRL>
+__device__ __forceinline__ void quad_cswap(float& t, uint32_t& r, float side) {
+    const float tp = quad_dpp_f<CTRL>(t);
+    const uint32_t rp = quad_dpp<CTRL>(r);
+    const float nt = __builtin_amdgcn_fmed3f(t, tp, side);
+    r = nt != t ? rp : r;
+    t = nt;
+}
+
+__device__ __forceinline__ void quad_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The quad's lanes, set up once per migration: which child a lane tests and on which side of each compare-exchange it sits.
+struct QuadLane {
+    uint32_t c, bitc, selx, sely, selz;
+    float side1, side2;
+    gbl_lds_u32* col;   // the ray's LDS stack column (LdsStack layout)
+};
+// v_perm selectors: byte 0 <- this child's plane crossed first, byte 1 <- the one crossed last ({qhi, qlo} = bytes 4-7, 0-3)
+__device__ __forceinline__ void quad_selectors(QuadLane& ql, F3 idir) {
+    const uint32_t c = ql.c;
+    ql.selx = idir.x < 0.0f ? (0x0c0c0004u + c + (c << 8)) : (0x0c0c0400u + c + (c << 8));
+    ql.sely = idir.y < 0.0f ? (0x0c0c0004u + c + (c << 8)) : (0x0c0c0400u + c + (c << 8));
+    ql.selz = idir.z < 0.0f ? (0x0c0c0004u + c + (c << 8)) : (0x0c0c0400u + c + (c << 8));
+}
+
+// trav_interior() for a ray held by a quad: st is replicated in the quad's four lanes, lane c tests child c.
+template <bool SORTED, bool STATS>
+__device__ __forceinline__ void quad_interior(const DevScene& sc, TravState& st, const QuadLane& ql, LaneCounters& cnt) {
+    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
+#ifndef GBL_QUAD_PIECE_LOADS
+    const uint4 w0 = np[0];   // o.x o.y o.z scale.x
+    const uint4 w1 = np[1];   // scale.y scale.z qlo.x qlo.y
+    const uint4 w2 = np[2];   // qlo.z qhi.x qhi.y qhi.z
+#else
+    // experiment: one 16-byte piece per lane -- the quad fetches the node's 64 bytes once -- handed round on DPP.  Measured
+    // slower (54.5 against 52.1 ms on config [1]): the address pipe is not what bounds a quad step (TA busy 55 % either way)
+    // and the twelve DPP moves are VALU work
+    const uint4 mine = np[ql.c];
+    uint4 w0, w1, w2;
+    w0.x = quad_dpp<0x00>(mine.x); w0.y = quad_dpp<0x00>(mine.y); w0.z = quad_dpp<0x00>(mine.z); w0.w = quad_dpp<0x00>(mine.w);
+    w1.x = quad_dpp<0x55>(mine.x); w1.y = quad_dpp<0x55>(mine.y); w1.z = quad_dpp<0x55>(mine.z); w1.w = quad_dpp<0x55>(mine.w);
+    w2.x = quad_dpp<0xAA>(mine.x); w2.y = quad_dpp<0xAA>(mine.y); w2.z = quad_dpp<0xAA>(mine.z); w2.w = quad_dpp<0xAA>(mine.w);
+#endif
+    uint32_t r = reinterpret_cast<const uint32_t*>(np)[12 + ql.c];
+    const int sp = st.sp;
+    const uint32_t popped = ql.col[(sp - 1) * GBL_BLOCK];   // the stack's top, should every child be missed
+    const RaySpace& rs = st.r;
+    const F3 A = f3(__builtin_fmaf(__uint_as_float(w0.x), rs.idir.x, -rs.ood.x), __builtin_fmaf(__uint_as_float(w0.y), rs.idir.y, -rs.ood.y),
+                    __builtin_fmaf(__uint_as_float(w0.z), rs.idir.z, -rs.ood.z));
+    const F3 B = f3(__uint_as_float(w0.w) * rs.idir.x, __uint_as_float(w1.x) * rs.idir.y, __uint_as_float(w1.y) * rs.idir.z);
+    const uint32_t px = __builtin_amdgcn_perm(w2.y, w1.z, ql.selx);
+    const uint32_t py = __builtin_amdgcn_perm(w2.z, w1.w, ql.sely);
+    const uint32_t pz = __builtin_amdgcn_perm(w2.w, w2.x, ql.selz);
+    float t = child_entry(px, py, pz, px >> 8, py >> 8, pz >> 8, A, B, st.mint, st.maxt);
+    if (STATS) {
+        cnt.nodes += 1;   // four lanes per node visit: the same 4 per visit trav_interior counts
+        if (ql.c == 0u) cnt.int_lane += 1;
+        if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(1)))) - 1u) cnt.int_wave += 1;
+    }
+    if (SORTED) {   // trav_interior's network: (0,1) (2,3) | (0,2) (1,3) | (1,2)
+        quad_cswap<GBL_QP_XOR1>(t, r, ql.side1);
+        quad_cswap<GBL_QP_XOR2>(t, r, ql.side2);
+        quad_cswap<GBL_QP_MID>(t, r, ql.side2);   // lanes 0 and 3 meet themselves: nothing changes
+    }
+    const bool h = t < INFINITY;
+    uint32_t m = h ? ql.bitc : 0u;   // the quad's hit mask
+    m |= quad_dpp<GBL_QP_XOR1>(m);
+    m |= quad_dpp<GBL_QP_XOR2>(m);
+    const int n = __popc(m);
+    // position among the hit children in visiting order (sorted: the hits are the first n lanes)
+    const int p = SORTED ? static_cast<int>(ql.c) : __popc(m & (ql.bitc - 1u));
+    uint32_t first;
+    if (SORTED) {
+        first = quad_dpp<GBL_QP_BC0>(r);
+    } else {
+        first = (h && p == 0) ? r : 0u;
+        first |= quad_dpp<GBL_QP_XOR1>(first);
+        first |= quad_dpp<GBL_QP_XOR2>(first);
+    }
+    // the first is visited next, the others go on the stack farthest / last first
+    if (h && p >= 1) ql.col[(sp + n - 1 - p) * GBL_BLOCK] = r;
+    st.cur = static_cast<int>(n > 0 ? first : popped);
+    st.sp = sp + n - 1;
+}
+
+// A triangle leaf for a ray held by a quad: lane c tests the leaf's triangle c, so a leaf is ONE memory round trip where the
+// loop of trav_other makes up to four dependent ones.  What that loop leaves behind -- it accepts a triangle when
+// mint <= t <= maxt and shrinks maxt to t, so the nearest accepted triangle stays and, among equal distances, the one
+// tested last -- is the minimum over the quad with ties going to the higher lane.  (Used where the reference's tie rule is
+// compiled out, GBL `TIES` = false, and for any-hit queries; a NaN distance, which the loop would accept, loses here.)
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded) {
+    const uint32_t ref = ~static_cast<uint32_t>(st.cur);
+    const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
+    const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
+    float t = INFINITY, b1 = 0.0f, b2 = 0.0f;
+    bool ok = false;
+    if (ql.c < count) {
+        if (STATS) cnt.tris += 1;
+        ok = tri_test(sc.tris + first + ql.c, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2);
+    }
+    const float tq = ok ? t : INFINITY;
+    float m = fminf(tq, quad_dpp_f<GBL_QP_XOR1>(tq));
+    m = fminf(m, quad_dpp_f<GBL_QP_XOR2>(m));
+    if (m < INFINITY) {   // (the same in the quad's four lanes)
+        if (ANY) {
+            *occluded = true;
+            return true;
+        }
+        uint32_t wm = (ok && tq == m) ? ql.bitc : 0u;
+        wm |= quad_dpp<GBL_QP_XOR1>(wm);
+        wm |= quad_dpp<GBL_QP_XOR2>(wm);
+        const uint32_t cw = 31u - static_cast<uint32_t>(__clz(static_cast<int>(wm)));
+        uint32_t u1 = ql.c == cw ? __float_as_uint(b1) : 0u, u2 = ql.c == cw ? __float_as_uint(b2) : 0u;
+        u1 |= quad_dpp<GBL_QP_XOR1>(u1);
+        u2 |= quad_dpp<GBL_QP_XOR1>(u2);
+        u1 |= quad_dpp<GBL_QP_XOR2>(u1);
+        u2 |= quad_dpp<GBL_QP_XOR2>(u2);
+        st.maxt = m;
+        st.hit.t = m;
+        st.hit.inst = st.inst;
+        st.hit.tri = first + cw;
+        st.hit.b1 = __uint_as_float(u1);
+        st.hit.b2 = __uint_as_float(u2);
+    }
+    st.cur = static_cast<int>(popped);
+    st.sp -= 1;
+    return false;
+}
+
+// trace() for a whole wave: every lane of the wave calls it (`want`: the lane has a ray); the exits are wave-uniform.
+// `slab`: this wave's 16 records; `wave_stack`: the LDS stack column of the wave's lane 0 (LdsStack layout).
+// ANY = true : Scene::occluded;  ANY = false: Scene::intersect -- as trace() (trace.h).
+template <bool ANY, bool STATS, bool EXT, bool TIES>
+__device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, F3 d, float mint, float maxt, const LdsStack& stk, gbl_lds_u32* slab,
+                                           gbl_lds_u32* wave_stack, Hit& hit, LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
+    TravState st;
+    if (want) {
+        trav_begin(sc, st, o, d, mint, maxt, stk);
+    } else {
+        st.sp = 0;
+        st.cur = GBL_STACK_EXIT;
+        st.inst = -1;
+        st.mint = st.maxt = 0.0f;
+        st.hit.t = INFINITY;
+        st.hit.inst = -1;
+        st.hit.tri = 0;
+        st.hit.b1 = st.hit.b2 = 0.0f;
+        st.r.o = st.r.d = st.r.idir = st.r.ood = f3(0.0f, 0.0f, 0.0f);
+        st.world = st.r;
+    }
+    bool done = !want, occluded = false;
+    uint32_t steps = 0;
+    // ---- more than 16 rays in flight: one ray per lane, as trace()
+    unsigned long long live = __ballot(!done);
+    while (__popcll(live) > GBL_QUAD_MAX) {
+        if (!done) {
+            if (trav_at_interior(st)) {
+                trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+                if (STATS) ++steps;
+            } else {
+                done = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, stk, cnt, &occluded, filter);
+            }
+        }
+        live = __ballot(!done);
+    }
+    Hit res = st.hit;   // (of the lanes that are done)
+    if (live != 0ull) {
+        // ---- migration: ray of rank k -> record k -> quad k
+        const uint32_t lane = threadIdx.x & 63u, q = lane >> 2;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+        const uint32_t nl = static_cast<uint32_t>(__popcll(live));
+        const bool owner = !done;
+        if (owner) {
+            gbl_lds_u32* rec = slab + rank * GBL_QUAD_REC_WORDS;
+            rec[0] = __float_as_uint(st.r.o.x); rec[1] = __float_as_uint(st.r.o.y); rec[2] = __float_as_uint(st.r.o.z);
+            rec[3] = __float_as_uint(st.r.d.x); rec[4] = __float_as_uint(st.r.d.y); rec[5] = __float_as_uint(st.r.d.z);
+            rec[6] = __float_as_uint(st.world.o.x); rec[7] = __float_as_uint(st.world.o.y); rec[8] = __float_as_uint(st.world.o.z);
+            rec[9] = __float_as_uint(st.world.d.x); rec[10] = __float_as_uint(st.world.d.y); rec[11] = __float_as_uint(st.world.d.z);
+            rec[12] = __float_as_uint(st.mint); rec[13] = __float_as_uint(st.maxt);
+            rec[14] = static_cast<uint32_t>(st.cur); rec[15] = static_cast<uint32_t>(st.inst);
+            rec[16] = static_cast<uint32_t>(st.hit.inst); rec[17] = st.hit.tri;
+            rec[18] = __float_as_uint(st.hit.b1); rec[19] = __float_as_uint(st.hit.b2);
+            rec[20] = static_cast<uint32_t>(st.sp) | (lane << 8);
+        }
+        quad_fence();
+        const bool qlive = q < nl;
+        QuadLane ql;
+        ql.c = lane & 3u;
+        ql.bitc = 1u << ql.c;
+        ql.side1 = (ql.c & 1u) == 0u ? -INFINITY : INFINITY;
+        ql.side2 = (ql.c & 2u) == 0u ? -INFINITY : INFINITY;
+        ql.col = wave_stack + lane;
+        bool qdone = true, qocc = false;
+        uint32_t qsteps = 0;
+        gbl_lds_u32* const qrec = slab + q * GBL_QUAD_REC_WORDS;
+        if (qlive) {
+            // the same arithmetic on the same operands as the lane that started the ray: ray_space() of (o, d)
+            ray_space(st.r, f3(__uint_as_float(qrec[0]), __uint_as_float(qrec[1]), __uint_as_float(qrec[2])),
+                      f3(__uint_as_float(qrec[3]), __uint_as_float(qrec[4]), __uint_as_float(qrec[5])));
+            st.inst = static_cast<int>(qrec[15]);
+            if (st.inst >= 0)
+                ray_space(st.world, f3(__uint_as_float(qrec[6]), __uint_as_float(qrec[7]), __uint_as_float(qrec[8])),
+                          f3(__uint_as_float(qrec[9]), __uint_as_float(qrec[10]), __uint_as_float(qrec[11])));
+            else
+                st.world = st.r;
+            st.mint = __uint_as_float(qrec[12]);
+            st.maxt = __uint_as_float(qrec[13]);
+            st.cur = static_cast<int>(qrec[14]);
+            st.hit.inst = static_cast<int>(qrec[16]);
+            st.hit.tri = qrec[17];
+            st.hit.b1 = __uint_as_float(qrec[18]);
+            st.hit.b2 = __uint_as_float(qrec[19]);
+            st.hit.t = st.hit.inst >= 0 ? st.maxt : INFINITY;   // the accepted distance is the ray's maxt (trav_other)
+            const uint32_t w = qrec[20];
+            st.sp = static_cast<int>(w & 0xffu);
+            ql.col = wave_stack + (w >> 8);
+            qdone = false;
+        }
+        quad_fence();
+        // ---- a quad per ray until the ray is done
+        const LdsStack qstk = {ql.col};
+        uint32_t keep_tris = cnt.tris, keep_ol = cnt.oth_lane, keep_ow = cnt.oth_wave;
+        int sel_inst = -2;   // the instance space the v_perm selectors were made for
+        while (!qdone) {
+            if (trav_at_interior(st)) {
+                if (sel_inst != st.inst) {
+                    quad_selectors(ql, st.r.idir);
+                    sel_inst = st.inst;
+                }
+                quad_interior<!ANY, STATS>(sc, st, ql, cnt);
+                if (STATS) ++qsteps;
+            } else if ((ANY ? !STATS : !TIES) && st.cur < 0 && st.inst >= 0 &&
+                       (!EXT || (~static_cast<uint32_t>(st.cur) >> 2) < GBL_SHAPE_FIRST_DISK)) {
+                qdone = quad_leaf<ANY, STATS>(sc, st, ql, cnt, &qocc);
+            } else {
+                qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, qstk, cnt, &qocc, filter);
+            }
+        }
+        if (STATS && ql.c != 0u) {   // leaf / instance steps ran in all four lanes: count them once
+            cnt.tris = keep_tris;
+            cnt.oth_lane = keep_ol;
+            cnt.oth_wave = keep_ow;
+        }
+        if (qlive && ql.c == 0u) {
+            qrec[0] = static_cast<uint32_t>(st.hit.inst);
+            qrec[1] = st.hit.tri;
+            qrec[2] = __float_as_uint(st.hit.b1);
+            qrec[3] = __float_as_uint(st.hit.b2);
+            qrec[4] = __float_as_uint(st.hit.t);
+            qrec[5] = qocc ? 1u : 0u;
+            if (STATS) qrec[6] = qsteps;
+        }
+        quad_fence();
+        if (owner) {
+            const gbl_lds_u32* rec = slab + rank * GBL_QUAD_REC_WORDS;
+            res.inst = static_cast<int>(rec[0]);
+            res.tri = rec[1];
+            res.b1 = __uint_as_float(rec[2]);
+            res.b2 = __uint_as_float(rec[3]);
+            res.t = __uint_as_float(rec[4]);
+            occluded = rec[5] != 0u;
+            if (STATS) steps += rec[6];
+        }
+        quad_fence();   // the slab is free for the next query
+    }
+#ifndef GBL_PROBE_OCC
+    if (STATS && !ANY && want) {
+        int b = steps <= 3 ? 0 : min(6, 30 - __clz(static_cast<int>(steps)));
+        cnt.hist[b] += 1;
+        cnt.hist_steps[b] += steps;
+    }
+#endif
+    if (ANY) return occluded;
+    hit = res;
+    return res.inst >= 0;
+}

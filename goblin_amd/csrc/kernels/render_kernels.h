@@ -25,6 +25,7 @@
 #include "blocktrace.h"
 #include "rayexchange.h"
 #include "suspend.h"
+#include "quadtrace.h"
 #include "vecmath.h"
 
 struct ItemInfo {
@@ -421,7 +422,9 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 // RX: the same two rays go through the workgroup's ray exchange instead (kernels/rayexchange.h: no barriers; the waves hand
 // their long rays to one another through LDS and help with whatever waits there while their own results are out).
 // SUSP: the extension query leaves its last few stragglers for the next iteration (kernels/suspend.h).
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false, bool RX = false, bool SUSP = false>
+// QUAD: both queries run as wave-wide calls whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h);
+// the kernel writes per-sample radiance only (ra.li_defer), so the LDS film tile's place holds the quads' records.
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false, bool RX = false, bool SUSP = false, bool QUAD = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
@@ -429,9 +432,13 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
     float* ftab = tile + 4 * tp * tp;
-    uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
+    uint32_t* ctrl = QUAD ? reinterpret_cast<uint32_t*>(smem) + GBL_QUAD_LDS_WORDS : reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
     static_assert(!(BT && STREAM), "workgroup-level tracing is built for the native / replay samplers");
+    static_assert(!(QUAD && (STREAM || BT || RX || SUSP)), "quad-per-ray steps are built for the plain megakernel under the native / replay samplers");
+    // QUAD: LDS = 16 records per wave | ctrl | stacks
+    gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
+    gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
     BlockXch bx = {};
     uint32_t bt_phase = 0;
     if constexpr (BT) {   // LDS: ... | stacks: min(stack_entries, GBL_WF_STACK_LDS) levels | exchange area (blocktrace.h)
@@ -469,7 +476,8 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     } else {
         stk.p = gbl_as_lds(stack + threadIdx.x);
     }
-    for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+    if (!QUAD)
+        for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     StreamCtx scx = {};
     StreamLayout slay = {};
     if constexpr (STREAM) {
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             ctrl[0] = atomicAdd(ra.work_counter, 1u);
             ctrl[1] = 0u;
         }
-        if (!ra.li_defer)
+        if (!QUAD && !ra.li_defer)
             for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
         __syncthreads();
         const uint32_t item = ctrl[0];
@@ -617,6 +625,11 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 if (STATS && want && !susp) cnt.ext += 1;
                 susp = parked;
                 if (active && !want) finished = true;
+            } else if constexpr (QUAD) {
+                const bool want = active && sc.num_lights != 0;
+                got = trace_quad<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
+                if (active && !want) finished = true;
+                if (STATS && want) cnt.ext += 1;
             } else if (active) {
                 if (sc.num_lights == 0) {
                     finished = true;   // PathTracer::Li returns Black without lights (:53-56)
@@ -798,10 +811,17 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                                                                                (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 }
             }
+            if constexpr (QUAD) {
+                if (__ballot(need_shadow) != 0ull) {
+                    Hit dummy;
+                    bt_occluded = trace_quad<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, stk, quad_slab, quad_stack, dummy, cnt,
+                                                                     (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
+                }
+            }
             if (need_shadow) {
                 Hit dummy;
                 const bool masks = EXT && sc.has_masks != 0;
-                bool occluded = (BT || RX) ? bt_occluded
+                bool occluded = (BT || RX || QUAD) ? bt_occluded
                                    : trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
                                                              masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 if (STATS) cnt.shadow += 1;
@@ -871,7 +891,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             // ---- path end: splat and free the lane
             if (vis && finished) {
                 // RenderTask::run: w * (tr * L + Lv), w = 1, tr = 1, Lv = 0
-                if (ra.li_defer) {
+                if (QUAD || ra.li_defer) {
                     reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
                 } else {
                     splat<STATS>(sc.film, ftab, tile, tx0, ty0, tp, image_x, image_y, ps.Li, cnt);

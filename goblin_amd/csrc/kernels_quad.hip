@@ -1,0 +1,11 @@
+// libgoblin_hip.so, kernel unit: the persistent megakernel whose sparse interior steps put four lanes on each ray
+// (kernels/quadtrace.h), under the native and replay samplers.
+#include "gbl_internal.h"
+#include "kernels/render_kernels.h"
+
+gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext) {
+    if (stats) return replay ? path_trace_kernel<true, true, true, false, false, false, false, true> : path_trace_kernel<false, true, true, false, false, false, false, true>;   // instrumented builds are EXT
+    if (replay) return ext ? path_trace_kernel<true, false, true, false, false, false, false, true> : path_trace_kernel<true, false, false, false, false, false, false, true>;
+    return ext ? path_trace_kernel<false, false, true, false, false, false, false, true> : path_trace_kernel<false, false, false, false, false, false, false, true>;
+}
+uint32_t gbl_quad_lds_words(void) { return GBL_QUAD_LDS_WORDS; }
