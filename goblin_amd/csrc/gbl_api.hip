@@ -1220,6 +1220,13 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             if (getenv("GBL_PROBE"))
                 fprintf(stderr, "probe: interior lane-steps %llu wave-steps %llu (util %.3f) | leaf/other lane %llu wave %llu (util %.3f)\n", h[7], h[8],
                         h[8] ? h[7] / (64.0 * h[8]) : 0.0, h[9], h[10], h[10] ? h[9] / (64.0 * h[10]) : 0.0);
+            if (getenv("GBL_PROBE_RAW")) {
+                fprintf(stderr, "probe raw: hist");
+                for (int i = 0; i < 7; ++i) fprintf(stderr, " %llu", h[11 + i]);
+                fprintf(stderr, " | hist_steps");
+                for (int i = 0; i < 7; ++i) fprintf(stderr, " %llu", h[18 + i]);
+                fprintf(stderr, "\n");
+            }
             if (getenv("GBL_PROBE") && h[25] + h[26] + h[27] + h[28] + h[29]) {
                 const double tot = static_cast<double>(h[25] + h[26] + h[27] + h[28] + h[29]);
                 fprintf(stderr, "probe: stream sampler phases (share of the workgroups' time): emit %.1f%% permute %.1f%% assemble %.1f%% paths %.1f%% skip %.1f%%\n",

@@ -23,7 +23,7 @@
 #define GBL_QUAD_MAX 16           // rays per run: 64 lanes / 4
 #endif
 // record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8)
-// result (same words, written by the quad's first lane): hit.inst hit.tri hit.b1 hit.b2 hit.t occluded steps
+// result (written by the quad's first lane when the ray is done): words 0-5 = hit.inst hit.tri hit.b1 hit.b2 hit.t occluded, 12 = steps
 #define GBL_QUAD_REC_WORDS 21
 #define GBL_QUAD_LDS_WORDS ((GBL_BLOCK / 64) * 16 * GBL_QUAD_REC_WORDS)
 
@@ -74,25 +74,10 @@ __device__ __forceinline__ void quad_selectors(QuadLane& ql, F3 idir) {
 
 // trav_interior() for a ray held by a quad: st is replicated in the quad's four lanes, lane c tests child c.
 template <bool SORTED, bool STATS>
-__device__ __forceinline__ void quad_interior(const DevScene& sc, TravState& st, const QuadLane& ql, LaneCounters& cnt) {
-    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
-#ifndef GBL_QUAD_PIECE_LOADS
-    const uint4 w0 = np[0];   // o.x o.y o.z scale.x
-    const uint4 w1 = np[1];   // scale.y scale.z qlo.x qlo.y
-    const uint4 w2 = np[2];   // qlo.z qhi.x qhi.y qhi.z
-#else
-    // experiment: one 16-byte piece per lane -- the quad fetches the node's 64 bytes once -- handed round on DPP.  Measured
-    // slower (54.5 against 52.1 ms on config [1]): the address pipe is not what bounds a quad step (TA busy 55 % either way)
-    // and the twelve DPP moves are VALU work
-    const uint4 mine = np[ql.c];
-    uint4 w0, w1, w2;
-    w0.x = quad_dpp<0x00>(mine.x); w0.y = quad_dpp<0x00>(mine.y); w0.z = quad_dpp<0x00>(mine.z); w0.w = quad_dpp<0x00>(mine.w);
-    w1.x = quad_dpp<0x55>(mine.x); w1.y = quad_dpp<0x55>(mine.y); w1.z = quad_dpp<0x55>(mine.z); w1.w = quad_dpp<0x55>(mine.w);
-    w2.x = quad_dpp<0xAA>(mine.x); w2.y = quad_dpp<0xAA>(mine.y); w2.z = quad_dpp<0xAA>(mine.z); w2.w = quad_dpp<0xAA>(mine.w);
-#endif
-    uint32_t r = reinterpret_cast<const uint32_t*>(np)[12 + ql.c];
+__device__ __forceinline__ void quad_interior(TravState& st, const QuadLane& ql, LaneCounters& cnt, uint4 w0, uint4 w1, uint4 w2, uint32_t r,
+                                              uint32_t popped) {
+    // w0 = o.x o.y o.z scale.x | w1 = scale.y scale.z qlo.x qlo.y | w2 = qlo.z qhi.x qhi.y qhi.z | r = child[c]
     const int sp = st.sp;
-    const uint32_t popped = ql.col[(sp - 1) * GBL_BLOCK];   // the stack's top, should every child be missed
     const RaySpace& rs = st.r;
     const F3 A = f3(__builtin_fmaf(__uint_as_float(w0.x), rs.idir.x, -rs.ood.x), __builtin_fmaf(__uint_as_float(w0.y), rs.idir.y, -rs.ood.y),
                     __builtin_fmaf(__uint_as_float(w0.z), rs.idir.z, -rs.ood.z));
@@ -105,6 +90,11 @@ __device__ __forceinline__ void quad_interior(const DevScene& sc, TravState& st,
         cnt.nodes += 1;   // four lanes per node visit: the same 4 per visit trav_interior counts
         if (ql.c == 0u) cnt.int_lane += 1;
         if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(1)))) - 1u) cnt.int_wave += 1;
+#ifdef GBL_PROBE_OCC
+        // experiment build: quad wave-steps in hist[5], the rays inside them in hist[6] (trav_interior bins the one-ray-per-lane steps in hist[0..4])
+        if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(1)))) - 1u) cnt.hist[5] += 1;
+        if (ql.c == 0u) cnt.hist[6] += 1;
+#endif
     }
     if (SORTED) {   // trav_interior's network: (0,1) (2,3) | (0,2) (1,3) | (1,2)
         quad_cswap<GBL_QP_XOR1>(t, r, ql.side1);
@@ -138,15 +128,18 @@ __device__ __forceinline__ void quad_interior(const DevScene& sc, TravState& st,
 // tested last -- is the minimum over the quad with ties going to the higher lane.  (Used where the reference's tie rule is
 // compiled out, GBL `TIES` = false, and for any-hit queries; a NaN distance, which the loop would accept, loses here.)
 template <bool ANY, bool STATS>
-__device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded) {
+__device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded, uint4 w0, uint4 w1, uint4 w2,
+                                          uint32_t popped) {
     const uint32_t ref = ~static_cast<uint32_t>(st.cur);
     const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
-    const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
     float t = INFINITY, b1 = 0.0f, b2 = 0.0f;
     bool ok = false;
     if (ql.c < count) {
         if (STATS) cnt.tris += 1;
-        ok = tri_test(sc.tris + first + ql.c, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2);
+        ok = tri_test_regs(make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), 0.0f),
+                           make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), 0.0f),
+                           make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), 0.0f), st.r.o, st.r.d, st.mint, st.maxt, &t,
+                           &b1, &b2);
     }
     const float tq = ok ? t : INFINITY;
     float m = fminf(tq, quad_dpp_f<GBL_QP_XOR1>(tq));
@@ -175,6 +168,34 @@ __device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, con
     st.cur = static_cast<int>(popped);
     st.sp -= 1;
     return false;
+}
+
+// The two steps of trav_other that need the WORLD ray, for a ray held by a quad: entering an instance (a TLAS leaf) and
+// leaving one (the sentinel on the stack).  The quad keeps only the ray of the space it is in; the world ray's origin and
+// direction wait in words 6-11 of the ray's record, and leaving an instance runs ray_space() on them again -- the same
+// arithmetic on the same operands as when the ray started.
+template <bool STATS, bool EXT>
+__device__ __forceinline__ void quad_transition(const DevScene& sc, TravState& st, const LdsStack& stk, const gbl_lds_u32* rec, LaneCounters& cnt,
+                                                int filter) {
+    if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
+    const F3 wo = f3(__uint_as_float(rec[6]), __uint_as_float(rec[7]), __uint_as_float(rec[8]));
+    const F3 wd = f3(__uint_as_float(rec[9]), __uint_as_float(rec[10]), __uint_as_float(rec[11]));
+    if (st.cur == GBL_STACK_SENTINEL) {   // finished an instance: back to the world ray
+        ray_space(st.r, wo, wd);
+        st.inst = -1;
+        st.cur = static_cast<int>(stk.load(--st.sp));
+        return;
+    }
+    const uint32_t ref = ~static_cast<uint32_t>(st.cur);
+    const DevInstance* ip = sc.instances + (ref >> 2);
+    if (EXT && filter != GBL_FILTER_NONE && (ip->is_mask != 0u ? GBL_FILTER_MASK : GBL_FILTER_OPAQUE) != filter) {
+        st.cur = static_cast<int>(stk.load(--st.sp));
+        return;
+    }
+    st.inst = static_cast<int>(ref >> 2);
+    ray_space(st.r, xf_point(ip->inv, wo), xf_vector(ip->inv, wd));
+    stk.store(st.sp++, GBL_STACK_SENTINEL);
+    st.cur = ip->root;
 }
 
 // trace() for a whole wave: every lane of the wave calls it (`want`: the lane has a ray); the exits are wave-uniform.
@@ -234,6 +255,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         }
         quad_fence();
         const bool qlive = q < nl;
+        st.world.o = st.world.d = st.world.idir = st.world.ood = f3(0.0f, 0.0f, 0.0f);   // (not kept in registers from here on)
         QuadLane ql;
         ql.c = lane & 3u;
         ql.bitc = 1u << ql.c;
@@ -244,15 +266,11 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         uint32_t qsteps = 0;
         gbl_lds_u32* const qrec = slab + q * GBL_QUAD_REC_WORDS;
         if (qlive) {
-            // the same arithmetic on the same operands as the lane that started the ray: ray_space() of (o, d)
+            // the same arithmetic on the same operands as the lane that started the ray: ray_space() of (o, d).  The world ray
+            // stays in the record until the ray enters or leaves an instance (quad_transition).
             ray_space(st.r, f3(__uint_as_float(qrec[0]), __uint_as_float(qrec[1]), __uint_as_float(qrec[2])),
                       f3(__uint_as_float(qrec[3]), __uint_as_float(qrec[4]), __uint_as_float(qrec[5])));
             st.inst = static_cast<int>(qrec[15]);
-            if (st.inst >= 0)
-                ray_space(st.world, f3(__uint_as_float(qrec[6]), __uint_as_float(qrec[7]), __uint_as_float(qrec[8])),
-                          f3(__uint_as_float(qrec[9]), __uint_as_float(qrec[10]), __uint_as_float(qrec[11])));
-            else
-                st.world = st.r;
             st.mint = __uint_as_float(qrec[12]);
             st.maxt = __uint_as_float(qrec[13]);
             st.cur = static_cast<int>(qrec[14]);
@@ -272,19 +290,58 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         uint32_t keep_tris = cnt.tris, keep_ol = cnt.oth_lane, keep_ow = cnt.oth_wave;
         int sel_inst = -2;   // the instance space the v_perm selectors were made for
         while (!qdone) {
+#ifdef GBL_PROBE_OCC
+            // experiment build: shader-clock ticks per kind of quad iteration in hist_steps[0..2] (interior, quad leaf, other), their counts in hist_steps[3..5]
+            const unsigned long long pt0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+            int pkind;
+#endif
+            // (Fetching the step's record -- node or triangle -- ahead of the branch on the kind of step, so that the two kinds'
+            //  loads travel together, was measured: 49.5 against 48.8 ms.)
             if (trav_at_interior(st)) {
+                const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
+                const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
+                const uint32_t w3 = reinterpret_cast<const uint32_t*>(np)[12 + ql.c];
+                const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];   // the stack's top, should every child be missed
                 if (sel_inst != st.inst) {
                     quad_selectors(ql, st.r.idir);
                     sel_inst = st.inst;
                 }
-                quad_interior<!ANY, STATS>(sc, st, ql, cnt);
+                quad_interior<!ANY, STATS>(st, ql, cnt, w0, w1, w2, w3, popped);
                 if (STATS) ++qsteps;
+#ifdef GBL_PROBE_OCC
+                pkind = 0;
+#endif
             } else if ((ANY ? !STATS : !TIES) && st.cur < 0 && st.inst >= 0 &&
                        (!EXT || (~static_cast<uint32_t>(st.cur) >> 2) < GBL_SHAPE_FIRST_DISK)) {
-                qdone = quad_leaf<ANY, STATS>(sc, st, ql, cnt, &qocc);
-            } else {
+                const uint32_t lref = ~static_cast<uint32_t>(st.cur);
+                const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + (lref >> 2) + min(ql.c, lref & 3u));
+                const uint4 w0 = tp[0], w1 = tp[1], w2 = tp[2];
+                const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
+                qdone = quad_leaf<ANY, STATS>(st, ql, cnt, &qocc, w0, w1, w2, popped);
+#ifdef GBL_PROBE_OCC
+                pkind = 1;
+#endif
+            } else if (st.cur == GBL_STACK_SENTINEL || (st.cur < 0 && st.inst < 0)) {
+                quad_transition<STATS, EXT>(sc, st, qstk, qrec, cnt, filter);
+#ifdef GBL_PROBE_OCC
+                pkind = 2;
+#endif
+            } else {   // the exit marker; analytic shapes; leaves under the reference's tie rule
                 qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, qstk, cnt, &qocc, filter);
+#ifdef GBL_PROBE_OCC
+                pkind = 2;
+#endif
             }
+#ifdef GBL_PROBE_OCC
+            if (STATS) {
+                asm volatile("" ::"v"(st.cur), "v"(st.sp));   // the step's results are in before the clock is read
+                const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+                if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(1)))) - 1u) {
+                    cnt.hist_steps[pkind] += static_cast<uint32_t>(pt1 - pt0);
+                    cnt.hist_steps[3 + pkind] += 1;
+                }
+            }
+#endif
         }
         if (STATS && ql.c != 0u) {   // leaf / instance steps ran in all four lanes: count them once
             cnt.tris = keep_tris;
@@ -298,7 +355,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             qrec[3] = __float_as_uint(st.hit.b2);
             qrec[4] = __float_as_uint(st.hit.t);
             qrec[5] = qocc ? 1u : 0u;
-            if (STATS) qrec[6] = qsteps;
+            if (STATS) qrec[12] = qsteps;
         }
         quad_fence();
         if (owner) {
@@ -309,7 +366,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             res.b2 = __uint_as_float(rec[3]);
             res.t = __uint_as_float(rec[4]);
             occluded = rec[5] != 0u;
-            if (STATS) steps += rec[6];
+            if (STATS) steps += rec[12];
         }
         quad_fence();   // the slab is free for the next query
     }

@@ -69,12 +69,9 @@ __device__ __forceinline__ void ray_space(RaySpace& r, F3 o, F3 d) {
     r.ood = f3(o.x * r.idir.x, o.y * r.idir.y, o.z * r.idir.z);
 }
 
-// Triangle::intersect's acceptance test (GoblinTriangle.cpp:52-78).
-__device__ __forceinline__ bool tri_test(const DevTri* tp, F3 o, F3 d, float mint, float maxt, float* t_out, float* b1_out,
-                                         float* b2_out) {
-    const float4 q0 = reinterpret_cast<const float4*>(tp)[0];
-    const float4 q1 = reinterpret_cast<const float4*>(tp)[1];
-    const float4 q2 = reinterpret_cast<const float4*>(tp)[2];
+// Triangle::intersect's acceptance test (GoblinTriangle.cpp:52-78) on a fetched DevTri (q0 = p0, q1 = e1, q2 = e2).
+__device__ __forceinline__ bool tri_test_regs(float4 q0, float4 q1, float4 q2, F3 o, F3 d, float mint, float maxt, float* t_out, float* b1_out,
+                                              float* b2_out) {
     F3 p0 = f3(q0.x, q0.y, q0.z), e1 = f3(q1.x, q1.y, q1.z), e2 = f3(q2.x, q2.y, q2.z);
     F3 s1 = cross(d, e2);
     float divisor = dot(s1, e1);
@@ -93,6 +90,13 @@ __device__ __forceinline__ bool tri_test(const DevTri* tp, F3 o, F3 d, float min
     *b1_out = b1;
     *b2_out = b2;
     return true;
+}
+__device__ __forceinline__ bool tri_test(const DevTri* tp, F3 o, F3 d, float mint, float maxt, float* t_out, float* b1_out,
+                                         float* b2_out) {
+    const float4 q0 = reinterpret_cast<const float4*>(tp)[0];
+    const float4 q1 = reinterpret_cast<const float4*>(tp)[1];
+    const float4 q2 = reinterpret_cast<const float4*>(tp)[2];
+    return tri_test_regs(q0, q1, q2, o, d, mint, maxt, t_out, b1_out, b2_out);
 }
 
 // Everything a lane carries for the ray it is traversing.
