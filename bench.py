@@ -80,11 +80,20 @@ def pmc_for(kernel_tag, workload, schedule):
         if agg.get("SQ_INSTS_VALU"):
             return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp), None
         return None, "no wavefront kernels in %s" % os.path.basename(path)
+    # the lean instantiation: the named kernel with every template argument false (the list grows with the experiments) but
+    # the one that selects the quad-per-ray steps (kernels/quadtrace.h), which is what a lean scene runs by default
+    base = kernel_tag.split("<")[0]
+    quad_arg = {"path_trace_kernel": 7, "ao_kernel": 4}.get(base)
+    best = None
     for name, c in d.get("counters_per_launch", {}).items():
-        # the lean instantiation: the named kernel with every template argument false (the list grows with the experiments)
-        base = kernel_tag.split("<")[0]
-        if (" " + base + "<") in (" " + name) and all(_template_arg(name, i) in ("false", None) for i in range(12)) and _template_arg(name, 0) == "false":
-            return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp), None
+        if (" " + base + "<") not in (" " + name) or _template_arg(name, 0) != "false":
+            continue
+        if not all(_template_arg(name, i) in ("false", None) for i in range(12) if i != quad_arg):
+            continue
+        if best is None or _template_arg(name, quad_arg) == "true":
+            best = (name, c)
+    if best is not None:
+        return dict(best[1], kernel=best[0], file=os.path.relpath(path, REPO), source_stamp=stamp), None
     return None, "no kernel matching %r in %s" % (kernel_tag, os.path.basename(path))
 
 

@@ -144,9 +144,12 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
 }
 
 // Experiment switch of the megakernel's workgroup-level tracing (kernels/blocktrace.h)
-static bool quad_wanted() {   // kernels/quadtrace.h
+// Quad-per-ray steps of the megakernel (kernels/quadtrace.h): on unless GBL_MK_QUAD=0 for the lean kernels (-9 ... -11 % on
+// the BASELINE scenes), off unless GBL_MK_QUAD=1 for the EXT ones (two waves per SIMD, mostly small scenes: +1 ... +14 %)
+static bool quad_wanted(bool ext) {
     const char* e = getenv("GBL_MK_QUAD");
-    return e && e[0] != '\0' && e[0] != '0';
+    if (e == nullptr || e[0] == '\0') return !ext;
+    return e[0] != '0';
 }
 static bool suspend_wanted() {   // kernels/suspend.h
     const char* e = getenv("GBL_MK_SUSPEND");
@@ -1150,7 +1153,13 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             if (sst != GBL_OK) return sst;
             ra.bt_spill = ctx->wf_spill;
         }
-        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted() == 0 && !suspend_wanted() && defer && quad_wanted() &&
+        if (p->integrator == GBL_INTEGRATOR_AO && !stream_mode && defer && !ext && !want_stats && quad_wanted(false)) {
+            kernel = gbl_kernel_ao_quad(replay);
+            lds = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        }
+        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted() == 0 && !suspend_wanted() && defer && quad_wanted(ext || want_stats) &&
             !(pair_candidate && getenv("GBL_MK_PAIRED"))) {
             // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records
             // take the LDS film tile's place

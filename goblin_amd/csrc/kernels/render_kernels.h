@@ -939,16 +939,22 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 // Ambient occlusion (AORenderer::Li): one closest hit, N uniform-hemisphere
 // any-hit rays, unoccluded fraction as grey radiance.
 // ---------------------------------------------------------------------------
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false>
+// QUAD: the camera ray and the occlusion rays run as wave-wide queries whose last <= 16 rays migrate to quads of lanes
+// (kernels/quadtrace.h); per-sample radiance only (ra.li_defer), LDS = quads' records | ctrl | stacks.
+template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool QUAD = false>
 __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs ra) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
     float* ftab = tile + 4 * tp * tp;
-    uint32_t* ctrl = reinterpret_cast<uint32_t*>(ftab + 256);
+    uint32_t* ctrl = QUAD ? reinterpret_cast<uint32_t*>(smem) + GBL_QUAD_LDS_WORDS : reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
+    static_assert(!(QUAD && (STREAM || EXT || STATS)), "quad-per-ray steps are built for the lean AO kernel");
     const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
-    for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
+    gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
+    gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
+    if (!QUAD)
+        for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     StreamCtx scx = {};
     StreamLayout slay = {};
     if constexpr (STREAM) {   // see path_trace_kernel; AORenderer::Li draws nothing from the tile's generator itself
@@ -976,7 +982,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             ctrl[0] = atomicAdd(ra.work_counter, 1u);
             ctrl[1] = 0u;
         }
-        if (!ra.li_defer)
+        if (!QUAD && !ra.li_defer)
             for (int i = threadIdx.x; i < 4 * tp * tp; i += GBL_BLOCK) tile[i] = 0.0f;
         __syncthreads();
         const uint32_t item = ctrl[0];
@@ -1004,6 +1010,74 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
             int fetched = wave_fetch(true, ctrl + 1);
             bool valid = fetched >= 0 && fetched < it.paths;
             if (__ballot(valid) == 0ull) break;
+            if constexpr (QUAD) {
+                // the same sample, with the queries hoisted out of the per-lane branches
+                SampleSource src;
+                src.spp = ra.spp;
+                src.root = ra.root;
+                src.rec = nullptr;
+                src.pixel_key = 0;
+                src.k = 0;
+                uint32_t out_index = 0;
+                F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+                float cam_mint = 0.0f;
+                if (valid) {
+                    const int pix = fetched / ra.chunk_spp;
+                    src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);
+                    const int px = it.px0 + pix % it.tw, py = it.py0 + pix / it.tw;
+                    out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
+                    float image_x, image_y;
+                    if (REPLAY) {
+                        src.rec = ra.replay + static_cast<size_t>(out_index) * ra.dims;
+                        image_x = src.rec[0];
+                        image_y = src.rec[1];
+                    } else {
+                        const uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
+                        src.pixel_key = nat_mix(ra.seed_key, pixel);
+                        float u, v;
+                        src.native_2d(0u, 1u, 0u, false, &u, &v);
+                        image_x = px + u;
+                        image_y = py + v;
+                    }
+                    camera_ray<EXT>(sc.camera, image_x, image_y, 0.0f, 0.0f, &o, &d, &cam_mint);
+                }
+                Hit hit;
+                const bool got = trace_quad<false, STATS, EXT, REPLAY || STATS>(sc, valid, o, d, cam_mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
+                const bool want = valid && got;
+                Frag fr;
+                fr.p = f3(0, 0, 0);
+                fr.eps = 0.0f;
+                if (want) make_fragment<EXT>(sc, hit, o, d, fr);
+                uint32_t occluded = 0;
+                if (__ballot(want) != 0ull) {
+                    for (int i = 0; i < ra.ao_n; ++i) {
+                        F3 dir = f3(0, 0, 1);
+                        if (want) {
+                            float u1, u2;
+                            if (REPLAY) {
+                                u1 = src.rec[4 + 2 * i];
+                                u2 = src.rec[4 + 2 * i + 1];
+                            } else {
+                                src.native_2d(0x10000u, static_cast<uint32_t>(ra.ao_n), static_cast<uint32_t>(i), true, &u1, &u2);
+                            }
+                            dir = shade_to_world(fr, uniform_sample_hemisphere(u1, u2));
+                        }
+                        Hit dummy;
+                        const bool occ = trace_quad<true, STATS, EXT, true>(sc, want, fr.p, dir, fr.eps, INFINITY, stk, quad_slab, quad_stack, dummy, cnt);
+                        if (want && occ) occluded += 1;
+                    }
+                }
+                if (valid) {
+                    F3 L = f3(0, 0, 0);
+                    if (got) {
+                        const float g = static_cast<float>(static_cast<uint32_t>(ra.ao_n) - occluded) / static_cast<float>(static_cast<uint32_t>(ra.ao_n));
+                        L = f3(g, g, g);
+                    }
+                    reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(L.x, L.y, L.z, 1.0f);
+                    paths_done += 1;
+                }
+                continue;
+            }
             if (valid) {
             int pix = fetched / ra.chunk_spp;
             SampleSource src;
@@ -1094,7 +1168,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs r
         if constexpr (STREAM) __syncthreads();   // every record of this pixel has been read before the next overwrites them
         }   // sub
         __syncthreads();
-        if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
+        if (!QUAD && !ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
 }

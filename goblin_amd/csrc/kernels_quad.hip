@@ -8,4 +8,7 @@ gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext) {
     if (replay) return ext ? path_trace_kernel<true, false, true, false, false, false, false, true> : path_trace_kernel<true, false, false, false, false, false, false, true>;
     return ext ? path_trace_kernel<false, false, true, false, false, false, false, true> : path_trace_kernel<false, false, false, false, false, false, false, true>;
 }
+gbl_render_kernel gbl_kernel_ao_quad(bool replay) {   // the lean AO kernel only
+    return replay ? ao_kernel<true, false, false, false, true> : ao_kernel<false, false, false, false, true>;
+}
 uint32_t gbl_quad_lds_words(void) { return GBL_QUAD_LDS_WORDS; }

@@ -24,7 +24,8 @@ acc = {}
 for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "rocclr" in k or ", true>" in k or "elementwise" in k:
+        targs = [x.strip() for x in k[k.find("<") + 1:k.find(">")].split(",")] if "<" in k else []
+        if "rocclr" in k or "elementwise" in k or (len(targs) > 1 and targs[1] == "true"):   # (instrumented builds: STATS is the second argument)
             continue
         a = acc.setdefault(k[:60], {}).setdefault(r["Counter_Name"], [0.0, 0])
         a[0] += float(r["Counter_Value"]); a[1] += 1

@@ -9,11 +9,31 @@ for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=16, dept
                  ("grid", gs.config_overrides(resolution=(64, 64), spp=4, depth=5)), ("masked", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)), ("shapes", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
                  ("bumpy", gs.config_overrides(resolution=(48, 48), spp=9, depth=5))):
     scene = gs.load_scene(name, ov)
-    os.environ.pop("GBL_MK_QUAD", None)
+    os.environ["GBL_MK_QUAD"] = "0"
     a = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
     os.environ["GBL_MK_QUAD"] = "1"
     b = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
     print(name, "differ", int(np.any(a != b, axis=1).sum()), "of", a.shape[0], flush=True)
+for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=4, method="ao", ao_samples=9)), ("grid", gs.config_overrides(resolution=(64, 64), spp=4, method="ao", ao_samples=9)),
+                 ("shapes", gs.config_overrides(resolution=(48, 48), spp=4, method="ao", ao_samples=9))):
+    scene = gs.load_scene(name, ov)
+    os.environ["GBL_MK_QUAD"] = "0"
+    a = HipPathTracer(scene, 0).render(seed=3, want_li=True)["li"].cpu().numpy()
+    os.environ["GBL_MK_QUAD"] = "1"
+    b = HipPathTracer(scene, 0).render(seed=3, want_li=True)["li"].cpu().numpy()
+    print("ao", name, "differ", int(np.any(a != b, axis=1).sum()), "of", a.shape[0], flush=True)
+for sc_name in ("bunny", "grid"):
+    tr = HipPathTracer(gs.load_scene(sc_name, gs.config_overrides(resolution=(1024, 1024), spp=16, method="ao", ao_samples=25)), 0)
+    film = tr.new_film()
+    for mode in ("0", "1"):
+        os.environ["GBL_MK_QUAD"] = mode
+        best = 1e9
+        for i in range(3):
+            film.zero_()
+            out = tr.render(film=film, seed=1, timed=True)
+            torch.cuda.synchronize()
+            best = min(best, out["stats"]["kernel_ms"])
+        print("ao %s 1024^2 x 16 spp x 25 rays GBL_MK_QUAD=%s: %.2f ms" % (sc_name, mode, best), flush=True)
 scene = gs.load_scene("bunny", gs.config_overrides(resolution=(512, 512), spp=256, depth=8))
 for mode in ("0", "1"):
     os.environ["GBL_MK_QUAD"] = mode
