@@ -151,6 +151,10 @@ static bool quad_wanted(bool ext) {
     if (e == nullptr || e[0] == '\0') return !ext;
     return e[0] != '0';
 }
+static bool quad_park_wanted() {   // GBL_MK_QUAD=2: the quads' extension queries park their stragglers (experiment)
+    const char* e = getenv("GBL_MK_QUAD");
+    return e != nullptr && e[0] == '2';
+}
 static bool suspend_wanted() {   // kernels/suspend.h
     const char* e = getenv("GBL_MK_SUSPEND");
     return e != nullptr && atoi(e) != 0;
@@ -1164,6 +1168,12 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records
             // take the LDS film tile's place
             kernel = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
+            if (quad_park_wanted() && !ext && !want_stats) {   // the stragglers' state: 14 words per thread in the stack backing buffer
+                kernel = gbl_kernel_path_quad_park(replay);
+                gbl_status sst = wf_ensure_spill(ctx, static_cast<int>(gbl_quad_park_words()));
+                if (sst != GBL_OK) return sst;
+                ra.bt_spill = ctx->wf_spill;
+            }
             lds = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
             if (lds > 64 * 1024)
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

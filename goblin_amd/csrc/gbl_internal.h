@@ -98,6 +98,8 @@ uint32_t gbl_suspend_park_words(void);   // words of parked traversal state per 
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
 gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao_quad(bool replay);
+gbl_render_kernel gbl_kernel_path_quad_park(bool replay);   // ... and park their queries' last stragglers
+uint32_t gbl_quad_park_words(void);
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     uint32_t* ctrl = QUAD ? reinterpret_cast<uint32_t*>(smem) + GBL_QUAD_LDS_WORDS : reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
     static_assert(!(BT && STREAM), "workgroup-level tracing is built for the native / replay samplers");
-    static_assert(!(QUAD && (STREAM || BT || RX || SUSP)), "quad-per-ray steps are built for the plain megakernel under the native / replay samplers");
+    static_assert(!(QUAD && (STREAM || BT || RX)), "quad-per-ray steps are built for the plain megakernel under the native / replay samplers");
     // QUAD: LDS = 16 records per wave | ctrl | stacks
     gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
     gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     }
     static_assert(!(RX && (STREAM || BT)), "the ray exchange is built for the native / replay samplers");
     static_assert(!(SUSP && (STREAM || BT || RX)), "suspendable queries are built for the plain megakernel under the native / replay samplers");
+    // (SUSP with QUAD: the quads' extension queries park their stragglers, kernels/quadtrace.h)
     gbl_glb_u32* const susp_park = SUSP ? gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK + threadIdx.x) : nullptr;
     bool susp = false;   // SUSP: this lane's extension ray is parked
     RayXch rx = {};
@@ -617,6 +618,14 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 got = trace_rx<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, rx, hit, cnt, GBL_FILTER_NONE);
                 if (active && !want) finished = true;
                 if (STATS && want) cnt.ext += 1;
+            } else if constexpr (QUAD && SUSP) {
+                const bool want = active && sc.num_lights != 0;
+                bool parked = false;
+                got = trace_quad<false, STATS, EXT, REPLAY || STATS, true>(sc, want && !susp, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt,
+                                                                            GBL_FILTER_NONE, want && susp, susp_park, ra.bt_spill_stride, &parked);
+                if (STATS && want && !susp) cnt.ext += 1;
+                susp = parked;
+                if (active && !want) finished = true;
             } else if constexpr (SUSP) {
                 const bool want = active && sc.num_lights != 0;
                 bool done = false, parked = false;

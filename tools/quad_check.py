@@ -13,7 +13,9 @@ for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=16, dept
     a = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
     os.environ["GBL_MK_QUAD"] = "1"
     b = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
-    print(name, "differ", int(np.any(a != b, axis=1).sum()), "of", a.shape[0], flush=True)
+    os.environ["GBL_MK_QUAD"] = "2"
+    c2 = HipPathTracer(scene, 0).render(seed=3, want_li=True, schedule="megakernel")["li"].cpu().numpy()
+    print(name, "differ", int(np.any(a != b, axis=1).sum()), "parked form", int(np.any(a != c2, axis=1).sum()), "of", a.shape[0], flush=True)
 for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=4, method="ao", ao_samples=9)), ("grid", gs.config_overrides(resolution=(64, 64), spp=4, method="ao", ao_samples=9)),
                  ("shapes", gs.config_overrides(resolution=(48, 48), spp=4, method="ao", ao_samples=9))):
     scene = gs.load_scene(name, ov)
@@ -35,7 +37,7 @@ for sc_name in ("bunny", "grid"):
             best = min(best, out["stats"]["kernel_ms"])
         print("ao %s 1024^2 x 16 spp x 25 rays GBL_MK_QUAD=%s: %.2f ms" % (sc_name, mode, best), flush=True)
 scene = gs.load_scene("bunny", gs.config_overrides(resolution=(512, 512), spp=256, depth=8))
-for mode in ("0", "1"):
+for mode in ("0", "1", "2"):
     os.environ["GBL_MK_QUAD"] = mode
     tr = HipPathTracer(scene, 0)
     film = tr.new_film()
