@@ -339,7 +339,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
                 const uint32_t w3 = reinterpret_cast<const uint32_t*>(np)[12 + ql.c];
                 const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];   // the stack's top, should every child be missed
-                if (sel_inst != st.inst) {
+                if (sel_inst != st.inst) {   // (making them at the migration and after every transition instead: 47.4 against 45.5 ms)
                     quad_selectors(ql, st.r.idir);
                     sel_inst = st.inst;
                 }
@@ -360,6 +360,12 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
 #endif
             } else if (st.cur == GBL_STACK_SENTINEL || (st.cur < 0 && st.inst < 0)) {
                 quad_transition<STATS, EXT>(sc, st, qstk, qrec, cnt, filter);
+#ifdef GBL_PROBE_OCC
+                pkind = 2;
+#endif
+            } else if (!EXT && (ANY ? !STATS : !TIES)) {   // lean builds: all that is left is the exit marker
+                qdone = true;
+                (void)qstk;
 #ifdef GBL_PROBE_OCC
                 pkind = 2;
 #endif
