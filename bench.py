@@ -359,10 +359,8 @@ def main():
     elapsed = float(t.item())
     job_paths = float(paths.item())   # paths all ranks traced in one step
 
-    auto_wavefront = depth >= _abi.GBL_AUTO_WAVEFRONT_DEPTH or tracer.info.instanced_triangles >= _abi.GBL_AUTO_WAVEFRONT_TRIS
-    if wl_extra.get("method") == "ao":
-        auto_wavefront = False   # the wavefront schedule covers the path tracer; AO runs its persistent kernel
-    resolved = args.schedule if args.schedule != "auto" else ("wavefront" if auto_wavefront else "megakernel")
+    # what AUTO resolved to: the library reports the schedule a call ran under (gbl_stats.schedule)
+    resolved = args.schedule if args.schedule != "auto" else {1: "megakernel", 2: "wavefront", 3: "wavepool"}.get(counted.get("schedule"), "megakernel")
     if rank == 0:
         call_ms = [a for a, _ in per_step]                                    # device events around gbl_render (the launch stream)
         reduce_ms = [b for _, b in per_step]

@@ -844,20 +844,32 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         }
         ra.tile_seeds = ctx->stream_seeds;
     }
-    // schedule.  AUTO follows the measurements in DESIGN.md: the persistent megakernel wins while a path is cheap
-    // (short paths through a small scene: configs 1, 2), the wavefront formulation once traversal dominates and its
-    // compaction pays for the path pool traffic -- long paths (Cornell box at depth 16: 3.5 s against 6.5 s) or many
-    // instanced triangles (config 4, 15 bunnies: 300 ms against 438 ms).  AO always runs the megakernel; mask scenes do under AUTO (the wavefront kernels handle masks -- same radiance -- but run the
-    // filtered MIS query and the attenuation walks inline in the trace kernel: 48.6 ms against 16.1 ms on masked.json).
+    // schedule.  AUTO follows the measurements in DESIGN.md 4: the persistent megakernel wins while its workgroups fit three to
+    // a CU and the scene is small (bunny.json at any depth: 12.8 / 14.9 / 16.1 ms against the wavefront's 19.7 / 23.3 / 25.2 at
+    // depth 8 / 12 / 16, 512^2 x 64 spp), the wavefront formulation once traversal dominates and its compaction pays for the
+    // path pool traffic -- many instanced triangles (config 4, 15 bunnies: 297 ms against 385 ms) -- or once the megakernel's
+    // full-depth LDS stacks leave room for two workgroups per CU only (the Cornell box at every depth: 3.5 s against 6.5 s at
+    // depth 16).  (Until the quad-per-ray queries AUTO also went by max_ray_depth >= 12; the megakernel has since gained
+    // 11 ... 14 % and wins bunny.json at depth 16 by 56 %.)  AO always runs the megakernel; mask scenes do under AUTO (the
+    // wavefront kernels handle masks -- same radiance -- but run the filtered MIS query and the attenuation walks inline in the
+    // trace kernel: 48.6 ms against 16.1 ms on masked.json).
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
-    // ... and when the lean megakernel's full-depth LDS stacks would leave room for two workgroups per CU instead of three:
-    // 3 * (TLAS + BLAS depth) + 2 entries per lane is 47 KB for the bunny (13 + 2 levels: three workgroups just fit), 50 KB one
-    // BLAS level deeper -- and a third fewer waves cost 28 % (bunny with 2-triangle leaves: 66 against 51 ms; the wavefront's
-    // trace kernel keeps 16 levels in LDS and the rest in a global backing column, and runs that scene in 56 ms)
-    const bool mk_lds_cliff = sc.extended == 0 && lds * 3 > 160 * 1024;
+    // The cliff: 3 * (TLAS + BLAS depth) + 2 stack entries per lane is 47 KB for the bunny (13 + 2 levels: three workgroups
+    // just fit, with the film tile or with the quads' records beside them), 50 KB one BLAS level deeper -- and a third fewer
+    // waves cost 28 % (bunny with 2-triangle leaves: 66 against 51 ms; the wavefront's trace kernel keeps 16 levels in LDS and
+    // the rest in a global backing column, and runs that scene in 56 ms).  Asked of the runtime for the kernel that would run.
+    bool mk_lds_cliff = false;
+    if (wf_capable && !stream_mode && p->schedule == GBL_SCHEDULE_AUTO && sc.extended == 0) {
+        const bool quad = quad_wanted(false);
+        gbl_render_kernel k = quad ? gbl_kernel_path_quad(replay, false, false) : gbl_kernel_path(replay, false, false);
+        const size_t l = quad ? (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t) : lds;
+        if (l > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l)));
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k), GBL_BLOCK, l) == hipSuccess) mk_lds_cliff = occ < GBL_PT_WAVES;
+        else mk_lds_cliff = l * 3 > 160 * 1024;
+    }
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
-                                    (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (p->max_ray_depth >= GBL_AUTO_WAVEFRONT_DEPTH ||
-                                                                          ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS || mk_lds_cliff)));
+                                    (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS || mk_lds_cliff)));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
         ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;

@@ -416,8 +416,8 @@ typedef enum gbl_sample_mode {
  *  WAVEPOOL    one persistent kernel; every wave runs its own wavefront loop over a small cache-resident
  *              pool of path slots (trace with in-wave refill, shade in full batches; path tracer only,
  *              mask-free scenes, native / replay samplers) */
-/* AUTO: max_ray_depth >= DEPTH or instanced triangles >= TRIS -> WAVEFRONT, else MEGAKERNEL */
-#define GBL_AUTO_WAVEFRONT_DEPTH 12
+/* AUTO: instanced triangles >= TRIS, or a traversal stack so deep that the megakernel's workgroups fit two to a CU
+ * instead of three -> WAVEFRONT, else MEGAKERNEL (gbl_stats.schedule reports what a call ran under) */
 #define GBL_AUTO_WAVEFRONT_TRIS 400000
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,

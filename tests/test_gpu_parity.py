@@ -379,11 +379,15 @@ def test_headline_scene_radiance_is_bit_identical(torch, schedule):
 
 
 def test_auto_schedule_at_config3_depth_is_the_wavefront(golden, torch):
-    """BASELINE configs[2]'s shape (max_ray_depth 16): AUTO resolves to the wavefront schedule from depth
-    GBL_AUTO_WAVEFRONT_DEPTH on; every schedule gives the same per-sample radiance on the reference's records."""
+    """BASELINE configs[2]'s shape (Cornell box, max_ray_depth 16): AUTO resolves to the wavefront schedule -- the box's
+    top-level tree is a level deeper than bunny.json's and the megakernel's LDS stacks would fit two workgroups per CU;
+    bunny.json itself stays on the megakernel at that depth (16.1 against 25.2 ms at 512^2 x 64 spp).  Every schedule gives
+    the same per-sample radiance on the reference's records."""
     from goblin_amd.renderer import HipPathTracer
     meta, data = golden("cornell_pt_d16")
-    assert meta["overrides"]["render_setting"]["max_ray_depth"] == 16 >= _abi.GBL_AUTO_WAVEFRONT_DEPTH and meta["dims"] == 4 + 7 * 16 + 32
+    assert meta["overrides"]["render_setting"]["max_ray_depth"] == 16 and meta["dims"] == 4 + 7 * 16 + 32
+    assert HipPathTracer(gs.load_scene(meta["scene"], meta["overrides"]), 0).render(seed=5, stats=True)["stats"]["schedule"] == 2
+    assert HipPathTracer(gs.load_scene("bunny", gs.config_overrides(resolution=(64, 64), spp=4, depth=16)), 0).render(seed=5, stats=True)["stats"]["schedule"] == 1
     scene = gs.load_scene(meta["scene"], meta["overrides"])
     r = HipPathTracer(scene, 0)
     seed = 5
