@@ -474,6 +474,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
             node_base += static_cast<int32_t>(used);
             tri_base += gm.tri_count;
             max_depth = std::max(max_depth, depth);
+            packed.mesh_stack_need[m] = 3 * depth;
         }
         for (size_t i = 0; i < packed.instances.size(); ++i)
             if (packed.instances[i].shape == 0u) packed.instances[i].root = mesh_root[packed.instances[i].mesh];
@@ -481,7 +482,10 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
             if (desc->meshes[m].shape == GBL_SHAPE_MESH) packed.mesh_root[m] = mesh_root[m];
         packed.blas_max_depth = max_depth;
         packed.blas_nodes = static_cast<uint64_t>(node_base) - packed.nodes.size();
-        packed.stack_entries = 3 * (packed.tlas_depth + max_depth) + 2;
+        {   // device-built trees: the per-level bound of each mesh's BLAS under the exact TLAS sum
+            const std::vector<DevNode> tl(packed.nodes.begin() + packed.tlas_base, packed.nodes.begin() + packed.tlas_base + static_cast<std::ptrdiff_t>(packed.tlas_nodes));
+            packed.stack_entries = scene_stack_entries(tl, packed.tlas_base, packed.tlas_root, packed.instances, packed.mesh_stack_need);
+        }
         packed.tris.resize(tri_cap);   // for gbl_info only
     }
     ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
@@ -551,6 +555,10 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     ctx->tlas_base = packed.tlas_base;
     ctx->tlas_capacity = packed.tlas_capacity;
     ctx->blas_depth = packed.blas_max_depth;
+    ctx->mesh_stack_need = packed.mesh_stack_need;
+    if (getenv("GBL_PROBE"))
+        fprintf(stderr, "probe: traversal stack entries %d (per-level bound %d: TLAS depth %d, BLAS depth %d)\n", packed.stack_entries,
+                3 * (packed.tlas_depth + packed.blas_max_depth) + 2, packed.tlas_depth, packed.blas_max_depth);
     for (uint32_t i = 0; i < desc->num_lights; ++i)
         if (desc->lights[i].type == GBL_LIGHT_DIRECTIONAL) ctx->has_directional = true;
     ctx->info.build_ms = ctx->build_ms;
@@ -611,7 +619,7 @@ static gbl_status gbl_update_instances_impl(gbl_ctx* ctx, uint32_t first, uint32
     if (!tlas.empty())
         HIP_TRY(ctx, hipMemcpy(const_cast<DevNode*>(sc.nodes) + ctx->tlas_base, tlas.data(), tlas.size() * sizeof(DevNode), hipMemcpyHostToDevice));
     sc.tlas_root = root;
-    sc.stack_entries = 3 * (depth + ctx->blas_depth) + 2;   // (the wavefront stack backing is re-checked at render time)
+    sc.stack_entries = scene_stack_entries(tlas, ctx->tlas_base, root, inst, ctx->mesh_stack_need);   // (the wavefront stack backing is re-checked at render time)
     ctx->info.tlas_depth = depth;
     ctx->info.tlas_nodes = tlas.size();
     ctx->h_instances.swap(edited);
@@ -854,19 +862,29 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
     // wavefront kernels handle masks -- same radiance -- but run the filtered MIS query and the attenuation walks inline in the
     // trace kernel: 48.6 ms against 16.1 ms on masked.json).
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
-    // The cliff: 3 * (TLAS + BLAS depth) + 2 stack entries per lane is 47 KB for the bunny (13 + 2 levels: three workgroups
-    // just fit, with the film tile or with the quads' records beside them), 50 KB one BLAS level deeper -- and a third fewer
-    // waves cost 28 % (bunny with 2-triangle leaves: 66 against 51 ms; the wavefront's trace kernel keeps 16 levels in LDS and
-    // the rest in a global backing column, and runs that scene in 56 ms).  Asked of the runtime for the kernel that would run.
+    // The deep-tree rule: would the lean megakernel fit three workgroups per CU if its LDS stacks held the PER-LEVEL bound,
+    // 3 * (TLAS + BLAS depth) + 2 entries per lane (47 for bunny.json: yes; 50 for the Cornell box, 53 for the grid: no)?
+    // When this rule was measured that bound sized the stacks, and a third fewer waves cost the megakernel 28 % (bunny with
+    // 2-triangle leaves: 66 against 51 ms, the wavefront 56).  The stacks now hold the exact need of the built trees
+    // (scene_prep.cpp scene_stack_entries; see DESIGN.md 3 for those three scenes' figures), which put the Cornell box back at three
+    // workgroups (101.6 -> 78.6 ms at depth 16) -- and still behind the wavefront's 66.7 ms: its paths are long and never
+    // leave the box.  The rule therefore stays on the per-level bound, as a proxy for scenes of many objects whose paths keep
+    // traversing; tools/auto_check.py re-measures the nine cases it was calibrated on.
     bool mk_lds_cliff = false;
     if (wf_capable && !stream_mode && p->schedule == GBL_SCHEDULE_AUTO && sc.extended == 0) {
         const bool quad = quad_wanted(false);
         gbl_render_kernel k = quad ? gbl_kernel_path_quad(replay, false, false) : gbl_kernel_path(replay, false, false);
-        const size_t l = quad ? (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t) : lds;
-        if (l > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l)));
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k), GBL_BLOCK, l) == hipSuccess) mk_lds_cliff = occ < GBL_PT_WAVES;
-        else mk_lds_cliff = l * 3 > 160 * 1024;
+        const size_t level_bound = static_cast<size_t>(3 * (ctx->info.tlas_depth + ctx->info.blas_depth) + 2);
+        const size_t l = (quad ? (gbl_quad_lds_words() + 4) * sizeof(uint32_t) : sizeof(float) * (4 * tp * tp + 256) + 4 * sizeof(uint32_t)) +
+                         level_bound * GBL_BLOCK * sizeof(uint32_t);
+        if (l > 160 * 1024) {
+            mk_lds_cliff = true;
+        } else {
+            if (l > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l)));
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k), GBL_BLOCK, l) == hipSuccess) mk_lds_cliff = occ < GBL_PT_WAVES;
+            else mk_lds_cliff = l * 3 > 160 * 1024;
+        }
     }
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS || mk_lds_cliff)));

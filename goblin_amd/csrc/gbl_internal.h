@@ -58,6 +58,7 @@ struct gbl_ctx {
     int32_t tlas_base = 0;
     uint32_t tlas_capacity = 0;
     int blas_depth = 0;
+    std::vector<int> mesh_stack_need;   // scene_prep.h PackedScene::mesh_stack_need
     bool has_directional = false;
     bool has_images = false;     // the scene holds MIP pyramids (image textures / image based lights)
     uint32_t* wf_host_flags = nullptr;   // pinned

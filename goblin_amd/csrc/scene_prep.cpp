@@ -177,6 +177,44 @@ int balanced_height(size_t n, int leaf) {
     return h;
 }
 
+// Most entries a ray can have on its traversal stack while inside the subtree of `ref` (kernels/trace.h trav_interior: a node
+// whose k children are all hit leaves k - 1 of them on the stack while the first is visited, and any child can be the first).
+// The 3-per-level bound assumes four children at every level of the deepest path; SAH trees of real meshes need about two
+// thirds of it, and the megakernel's LDS stacks are sized by this number (gbl_api.hip: three workgroups per CU or two).
+static int blas_stack_need(const std::vector<DevNode>& nodes, int32_t ref) {
+    if (ref < 0 || ref >= static_cast<int32_t>(nodes.size())) return 0;   // a leaf (or an analytic shape's root)
+    const DevNode& n = nodes[static_cast<size_t>(ref)];
+    int k = 0, deepest = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (n.child[c] == GBL_REF_NONE) continue;
+        ++k;
+        deepest = std::max(deepest, blas_stack_need(nodes, n.child[c]));
+    }
+    return k > 0 ? k - 1 + deepest : 0;
+}
+
+static int tlas_stack_need(const std::vector<DevNode>& tlas, int32_t tlas_base, int32_t ref, const std::vector<DevInstance>& instances,
+                           const std::vector<int>& mesh_need) {
+    if (ref == GBL_REF_NONE) return 0;
+    if (ref < 0) {   // an instance: its sentinel, then its BLAS (an analytic shape's "root" is a leaf)
+        const uint32_t i = (~static_cast<uint32_t>(ref)) >> 2;
+        if (i >= instances.size()) return 1;
+        const DevInstance& di = instances[i];
+        const bool mesh = di.shape == 0u && di.mesh >= 0 && static_cast<size_t>(di.mesh) < mesh_need.size();
+        return 1 + (mesh ? mesh_need[static_cast<size_t>(di.mesh)] : 0);
+    }
+    const size_t local = static_cast<size_t>(ref - tlas_base);
+    if (local >= tlas.size()) return 0;
+    const DevNode& n = tlas[local];
+    int k = 0, deepest = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (n.child[c] == GBL_REF_NONE) continue;
+        ++k;
+        deepest = std::max(deepest, tlas_stack_need(tlas, tlas_base, n.child[c], instances, mesh_need));
+    }
+    return k > 0 ? k - 1 + deepest : 0;
+}
+
 // SAH cost of visiting a node relative to one triangle test (tuning knob: GBL_SAH_CT)
 inline float sah_traversal_cost() {
     static const float ct = [] {
@@ -466,6 +504,11 @@ int ceil_i(float f) { return static_cast<int>(std::ceil(f)); }
 
 }  // namespace
 
+int scene_stack_entries(const std::vector<DevNode>& tlas, int32_t tlas_base, int32_t tlas_root, const std::vector<DevInstance>& instances,
+                        const std::vector<int>& mesh_stack_need) {
+    return 1 + tlas_stack_need(tlas, tlas_base, tlas_root, instances, mesh_stack_need) + 1;
+}
+
 // Instances (transforms in the reference's float order, world boxes by Transform::onBBox) and the TLAS over them.
 // TLAS node k gets device index tlas_base + k; sb_lo/hi return the union of the instance boxes.
 gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* meshes, const gbl_material* materials, const float* mesh_lo,
@@ -678,6 +721,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->tris.clear();
     out->tri_shade.assign(d->num_triangles, DevTriShade());
     out->blas_max_depth = 0;
+    out->mesh_stack_need.assign(d->num_meshes, 0);
     for (uint32_t mi = 0; mi < d->num_meshes; ++mi) {
         const gbl_mesh& gm = d->meshes[mi];
         if (gm.shape != GBL_SHAPE_MESH) {
@@ -736,6 +780,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         };
         mesh_root[mi] = f4.emit(root, 1, leaf_ref);
         out->blas_max_depth = std::max(out->blas_max_depth, f4.depth);
+        out->mesh_stack_need[mi] = blas_stack_need(out->nodes, mesh_root[mi]);
     }
     out->blas_nodes = out->nodes.size();
     out->mesh_lo.resize(3 * d->num_meshes);
@@ -767,8 +812,8 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     out->tlas_nodes = tlas.size();
     // room for any TLAS over the same instances (gbl_update_instances rebuilds it in place)
     out->nodes.resize(static_cast<size_t>(out->tlas_base) + out->tlas_capacity, DevNode());
-    // every 4-wide level can leave up to 3 siblings on the stack; + exit marker + instance sentinel
-    out->stack_entries = 3 * (out->tlas_depth + out->blas_max_depth) + 2;
+    // (with device-built BLASes the caller fills mesh_stack_need from their depths and calls scene_stack_entries again)
+    out->stack_entries = scene_stack_entries(tlas, out->tlas_base, out->tlas_root, out->instances, out->mesh_stack_need);
 
     // ---- materials
     out->materials.resize(d->num_materials);

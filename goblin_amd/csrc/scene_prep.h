@@ -33,6 +33,7 @@ struct PackedScene {
     DevVolume volume = {};
     uint64_t blas_nodes = 0, tlas_nodes = 0;
     int blas_max_depth = 0, tlas_depth = 0;
+    std::vector<int> mesh_stack_need;      // per mesh: most entries a ray can have on its stack inside its BLAS (exact for host-built trees)
     std::vector<float> mesh_lo, mesh_hi;   // 3 per mesh: object bounds
     std::vector<int32_t> mesh_root;        // per mesh: BLAS root reference
     int32_t tlas_base = 0;                 // device index of TLAS node 0
@@ -52,3 +53,9 @@ gbl_status build_tlas(const gbl_instance* inst, uint32_t n, const gbl_mesh* mesh
                       const float* mesh_hi, const int32_t* mesh_root, int32_t tlas_base, std::vector<DevInstance>* out_inst,
                       std::vector<DevNode>* out_nodes, int32_t* tlas_root, int* tlas_depth, float sb_lo[3], float sb_hi[3], std::string* err,
                       std::vector<DevInstanceBound>* bounds_out = nullptr);
+
+// Traversal stack entries a scene needs (kernels/trace.h): exit marker + the worst root-to-leaf sum over the TLAS nodes
+// (tlas[0..] are the nodes at absolute indices tlas_base + i) of (children - 1), + per instance its sentinel and what its
+// mesh's BLAS needs, + one spare.
+int scene_stack_entries(const std::vector<DevNode>& tlas, int32_t tlas_base, int32_t tlas_root, const std::vector<DevInstance>& instances,
+                        const std::vector<int>& mesh_stack_need);
