@@ -321,7 +321,8 @@ def main():
                 out = r
             elif r["stats"]:
                 for k, v in r["stats"].items():
-                    out["stats"][k] += v
+                    if k not in ("schedule", "reserved"):   # (what the call ran under: not a counter)
+                        out["stats"][k] += v
         return out
 
     # counters for the roofline (one instrumented launch, outside the timed region;

@@ -181,6 +181,11 @@ int balanced_height(size_t n, int leaf) {
 // whose k children are all hit leaves k - 1 of them on the stack while the first is visited, and any child can be the first).
 // The 3-per-level bound assumes four children at every level of the deepest path; SAH trees of real meshes need about two
 // thirds of it, and the megakernel's LDS stacks are sized by this number (gbl_api.hip: three workgroups per CU or two).
+// GBL_STACK_LEVEL_BOUND=1 (a test aid): count three siblings at every node, i.e. the per-level bound the stacks had before.
+static bool stack_level_bound() {
+    static const bool on = [] { const char* e = getenv("GBL_STACK_LEVEL_BOUND"); return e != nullptr && e[0] != '\0' && e[0] != '0'; }();
+    return on;
+}
 static int blas_stack_need(const std::vector<DevNode>& nodes, int32_t ref) {
     if (ref < 0 || ref >= static_cast<int32_t>(nodes.size())) return 0;   // a leaf (or an analytic shape's root)
     const DevNode& n = nodes[static_cast<size_t>(ref)];
@@ -190,7 +195,7 @@ static int blas_stack_need(const std::vector<DevNode>& nodes, int32_t ref) {
         ++k;
         deepest = std::max(deepest, blas_stack_need(nodes, n.child[c]));
     }
-    return k > 0 ? k - 1 + deepest : 0;
+    return k > 0 ? (stack_level_bound() ? 3 : k - 1) + deepest : 0;
 }
 
 static int tlas_stack_need(const std::vector<DevNode>& tlas, int32_t tlas_base, int32_t ref, const std::vector<DevInstance>& instances,
@@ -212,7 +217,7 @@ static int tlas_stack_need(const std::vector<DevNode>& tlas, int32_t tlas_base, 
         ++k;
         deepest = std::max(deepest, tlas_stack_need(tlas, tlas_base, n.child[c], instances, mesh_need));
     }
-    return k > 0 ? k - 1 + deepest : 0;
+    return k > 0 ? (stack_level_bound() ? 3 : k - 1) + deepest : 0;
 }
 
 // SAH cost of visiting a node relative to one triangle test (tuning knob: GBL_SAH_CT)

@@ -25,6 +25,7 @@ from goblin_amd import scene as gs
 
 pytestmark = pytest.mark.gpu
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LI_FLIP_TOL = 0.0
 LI_RELL2_TOL = 0.0
 FILM_RELL2_TOL = 2.5e-5
@@ -486,6 +487,36 @@ def test_workgroup_tracing_experiments_are_bit_identical(torch, monkeypatch, mod
         got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
         np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
         np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_exact_stack_entries_hold_every_ray(torch):
+    """The LDS traversal stacks hold what the built trees can need (scene_prep.cpp scene_stack_entries: 39 / 42 / 45 entries
+    for bunny / Cornell / grid) instead of three entries per level (47 / 50 / 53).  GBL_STACK_LEVEL_BOUND=1 restores the
+    per-level count; a stack that overflowed would lose nodes and change radiance -- it does not, on any kernel family.
+    (The knob is read once per process: the bounded renders run in a child process.)"""
+    import subprocess, sys, tempfile
+    from goblin_amd.renderer import HipPathTracer
+    cases = [("bunny", dict(resolution=(96, 96), spp=16, depth=8)), ("cornell", dict(resolution=(48, 48), spp=16, depth=12)),
+             ("grid", dict(resolution=(64, 64), spp=4, depth=6)), ("bunny", dict(resolution=(64, 64), spp=4, method="ao", ao_samples=9))]
+    with tempfile.TemporaryDirectory() as tmp:
+        child = (
+            "import sys, numpy as np\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from goblin_amd import scene as gs\n"
+            "from goblin_amd.renderer import HipPathTracer\n"
+            "cases = %r\n"
+            "for i, (name, kw) in enumerate(cases):\n"
+            "    r = HipPathTracer(gs.load_scene(name, gs.config_overrides(**kw)), 0)\n"
+            "    for s in (['megakernel', 'wavefront'] if 'method' not in kw else ['auto']):\n"
+            "        np.save(%r + '/%%d_%%s.npy' %% (i, s), r.render(seed=21, want_li=True, schedule=s)['li'].cpu().numpy())\n"
+        ) % (REPO, os.path.join(REPO, "tests"), cases, tmp)
+        env = dict(os.environ, GBL_STACK_LEVEL_BOUND="1")
+        subprocess.run([sys.executable, "-c", child], env=env, check=True, timeout=600)
+        for i, (name, kw) in enumerate(cases):
+            r = HipPathTracer(gs.load_scene(name, gs.config_overrides(**kw)), 0)
+            for s in (["megakernel", "wavefront"] if "method" not in kw else ["auto"]):
+                got = r.render(seed=21, want_li=True, schedule=s)["li"].cpu().numpy()
+                np.testing.assert_array_equal(got.view(np.uint32), np.load("%s/%d_%s.npy" % (tmp, i, s)).view(np.uint32))
 
 
 def test_auto_schedule_avoids_the_megakernels_lds_cliff(torch, monkeypatch):
