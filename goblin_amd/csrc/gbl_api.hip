@@ -886,8 +886,15 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             else mk_lds_cliff = l * 3 > 160 * 1024;
         }
     }
+    // A scene of many instanced triangles goes by the size of the call: the wavefront's hundreds of launches per frame and its
+    // 2^23-slot pool want work to amortise over -- the 15-bunny grid at 1024^2 x 256 spp (270 M paths): 297 against 301 ms for the
+    // megakernel; one rank's share of that frame under 2 / 4 / 8-way tile sharding (135 / 68 / 34 M paths): 154.2 / 84.6 / 44.2
+    // against 153.2 / 79.7 / 40.3 ms (tools/shard_check.py) -- so the strong-scaling ranks of section 8 run the megakernel.
+    const uint64_t call_paths = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * static_cast<uint64_t>(ra.window[3] - ra.window[2]) * ra.spp /
+                                static_cast<uint64_t>(ra.shard_count);
+    const bool auto_wavefront = ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS ? call_paths >= GBL_AUTO_WAVEFRONT_PATHS : mk_lds_cliff;
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
-                                    (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && (ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS || mk_lds_cliff)));
+                                    (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && auto_wavefront));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {
         ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;

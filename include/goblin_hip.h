@@ -416,9 +416,11 @@ typedef enum gbl_sample_mode {
  *  WAVEPOOL    one persistent kernel; every wave runs its own wavefront loop over a small cache-resident
  *              pool of path slots (trace with in-wave refill, shade in full batches; path tracer only,
  *              mask-free scenes, native / replay samplers) */
-/* AUTO: instanced triangles >= TRIS, or a traversal stack so deep that the megakernel's workgroups fit two to a CU
- * instead of three -> WAVEFRONT, else MEGAKERNEL (gbl_stats.schedule reports what a call ran under) */
+/* AUTO: instanced triangles >= TRIS and at least PATHS camera samples in the call (this rank's tiles x spp), or fewer
+ * triangles under trees so deep that the megakernel's workgroups would fit two to a CU at three stack entries per level
+ * -> WAVEFRONT, else MEGAKERNEL (gbl_stats.schedule reports what a call ran under) */
 #define GBL_AUTO_WAVEFRONT_TRIS 400000
+#define GBL_AUTO_WAVEFRONT_PATHS 150000000ull
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,
     GBL_SCHEDULE_MEGAKERNEL = 1,
