@@ -1,18 +1,20 @@
-// Quad-per-ray interior steps for the persistent megakernel: when at most GBL_QUAD_MAX lanes of a wave stand at interior
-// nodes, the wave's 64 lanes regroup as 16 quads, one quad per such ray, and every lane of a quad tests ONE of the node's
-// four children; the five compare-exchanges of trav_interior's sorting network run across the quad on DPP.
+// Quad-per-ray queries for the persistent megakernel and the AO kernel: once at most GBL_QUAD_MAX (16) of a wave's rays are
+// unfinished, the wave's 64 lanes regroup as 16 quads, one quad per ray, and every lane of a quad tests ONE of a node's four
+// children (the five compare-exchanges of trav_interior's sorting network run across the quad on DPP) or ONE of a leaf's
+// triangles.
 //
 // Why: the megakernel is bound by VALU issue, and 60 % of its interior wave-steps run with <= 4 of 64 lanes,
 // 83 % with <= 16 (the few rays of a wave that wander through the bunny's BLAS).  The round's earlier experiments made
 // those sparse steps RARE by moving rays between lanes, waves or iterations, and lost to the idle waves that creates; this
-// one leaves every ray in its lane and makes the sparse step CHEAP: a quad step is one box test per lane (~60 VALU
-// instructions with the sort) where the plain step is four (~150).  Occupancy, path state and the per-ray sequence of node
-// visits are untouched, so hits, ties and radiance are bit-identical (Scene::intersect / occluded, GoblinBVH.cpp:189-280).
+// one leaves occupancy and the path state alone and makes the sparse step CHEAP: a quad step is one box test per lane (64
+// VALU instructions with the sort) where the plain step is four (~150).  A ray's sequence of node visits and triangle tests
+// is untouched, so hits, ties and radiance are bit-identical (Scene::intersect / occluded, GoblinBVH.cpp:189-280).
 //
 // A query starts as trace() does, one ray per lane.  Once at most 16 of the wave's rays are unfinished they MIGRATE: each
 // publishes its traversal state to a record of the wave's LDS slab (rank order), quad q takes record q and owns that ray for
-// the rest of the query -- interior steps with one child per lane, leaf / instance steps replicated in its four lanes,
-// pushing to and popping from the ray's own LDS stack column -- and hands the hit back through the record at the end.
+// the rest of the query -- interior steps with one child per lane, leaves with one triangle per lane (the tie-rule builds:
+// trav_other's own loop, replicated in the four lanes), instance entry / exit from the world ray left in the record, pushing
+// to and popping from the ray's own LDS stack column -- and hands the hit back through the record at the end.
 // (A first form returned every ray to its lane after each run of interior steps: 27 % fewer VALU instructions and no
 // faster -- two LDS round trips per run on a chain that is latency bound once the VALU work shrinks.)  LDS operations of
 // one wave execute in order, so the slab and the foreign stack columns need no barrier, only compiler fences.
@@ -20,7 +22,7 @@
 #include "trace.h"
 
 #ifndef GBL_QUAD_MAX
-#define GBL_QUAD_MAX 16           // rays per run: 64 lanes / 4
+#define GBL_QUAD_MAX 16           // rays that migrate: 64 lanes / 4
 #endif
 // record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8)
 // result (written by the quad's first lane when the ray is done): words 0-5 = hit.inst hit.tri hit.b1 hit.b2 hit.t occluded, 12 = steps
