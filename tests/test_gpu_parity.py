@@ -520,10 +520,11 @@ def test_exact_stack_entries_hold_every_ray(torch):
 
 
 def test_auto_schedule_avoids_the_megakernels_lds_cliff(torch, monkeypatch):
-    """GBL_SCHEDULE_AUTO: bunny.json at depth 8 runs the megakernel (47 stack entries per lane: three workgroups per CU just
-    fit); the same scene built with 2-triangle leaves (GBL_MAX_LEAF=2: one BLAS level more, 50 entries) would leave room for
-    two, so AUTO takes the wavefront schedule there (56 against 66 ms at full size).  gbl_stats reports what ran; the
-    radiance is the same either way."""
+    """GBL_SCHEDULE_AUTO's deep-tree rule goes by three stack entries per tree level: bunny.json at depth 8 runs the
+    megakernel (47 entries by that count: three workgroups per CU would just fit); the same scene built with 2-triangle leaves
+    (GBL_MAX_LEAF=2: one BLAS level more, 50) would leave room for two, so AUTO takes the wavefront schedule there (56
+    against 66 ms at full size when the rule was calibrated; the stacks themselves now hold the trees' exact need, DESIGN.md
+    3).  gbl_stats reports what ran; the radiance is the same either way."""
     from goblin_amd.renderer import HipPathTracer
     ov = gs.config_overrides(resolution=(96, 96), spp=16, depth=8)
     monkeypatch.delenv("GBL_MAX_LEAF", raising=False)
