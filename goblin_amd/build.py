@@ -19,7 +19,7 @@ HOST_DEPS = HOST_SOURCES + [os.path.join(CSRC, "host", "json_lite.h"), os.path.j
 # (a single unit took 3.6 minutes; these take about one on 8 cores, and an edit rebuilds only the units that include
 # what changed -- hipcc's depfiles decide).
 HIP_SOURCES = [os.path.join(CSRC, f) for f in
-               ("gbl_api.hip", "kernels_path.hip", "kernels_pair.hip", "kernels_block.hip", "kernels_exchange.hip", "kernels_suspend.hip", "kernels_quad.hip", "kernels_stream.hip", "kernels_wavefront.hip", "kernels_wavepool.hip",
+               ("gbl_api.hip", "kernels_path.hip", "kernels_quad.hip", "kernels_stream.hip", "kernels_wavefront.hip",
                 "kernels_whitted.hip", "kernels_aux.hip", "scene_prep.cpp")]
 OBJ = os.path.join(LIB, "obj")
 

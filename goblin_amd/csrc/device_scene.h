@@ -275,8 +275,5 @@ struct RenderArgs {
                                 // and a separate splat kernel filters it into the film afterwards
     float* film;                // xres*yres float4 accumulators
     uint32_t* work_counter;     // zeroed before each launch
-    void* wp_pool;              // wave-pool schedule: path state of the persistent waves (kernels/wavepool.h), or null
-    uint32_t* bt_spill;         // workgroup-level tracing (kernels/blocktrace.h): global backing of the stacks beyond GBL_WF_STACK_LDS levels
-    uint32_t bt_spill_stride;   // ... threads of the grid
     unsigned long long* stats;  // 8 counters
 };

@@ -143,25 +143,12 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
     return ctx->li_budget;
 }
 
-// Experiment switch of the megakernel's workgroup-level tracing (kernels/blocktrace.h)
 // Quad-per-ray steps of the megakernel (kernels/quadtrace.h): on unless GBL_MK_QUAD=0 for the lean kernels (-9 ... -11 % on
 // the BASELINE scenes), off unless GBL_MK_QUAD=1 for the EXT ones (two waves per SIMD, mostly small scenes: +1 ... +14 %)
 static bool quad_wanted(bool ext) {
     const char* e = getenv("GBL_MK_QUAD");
     if (e == nullptr || e[0] == '\0') return !ext;
     return e[0] != '0';
-}
-static bool quad_park_wanted() {   // GBL_MK_QUAD=2: the quads' extension queries park their stragglers (experiment)
-    const char* e = getenv("GBL_MK_QUAD");
-    return e != nullptr && e[0] == '2';
-}
-static bool suspend_wanted() {   // kernels/suspend.h
-    const char* e = getenv("GBL_MK_SUSPEND");
-    return e != nullptr && atoi(e) != 0;
-}
-static int block_trace_wanted() {   // 1: blocktrace.h, 2: rayexchange.h
-    const char* e = getenv("GBL_MK_BLOCKTRACE");
-    return e != nullptr ? atoi(e) : 0;
 }
 
 // Random numbers one camera sample's transmittance + Lv may draw (GBL_SAMPLES_STREAM sizes a pixel's tail with it): 9 per light
@@ -640,7 +627,6 @@ void gbl_destroy(gbl_ctx* ctx) {
     if (ctx->stream_scratch) (void)hipFree(ctx->stream_scratch);
     if (ctx->stream_xy) (void)hipFree(ctx->stream_xy);
     if (ctx->wf_spill) (void)hipFree(ctx->wf_spill);
-    if (ctx->wp_pool) (void)hipFree(ctx->wp_pool);
     if (ctx->wf_ev_shade) (void)hipEventDestroy(ctx->wf_ev_shade);
     if (ctx->wf_ev_shadow) (void)hipEventDestroy(ctx->wf_ev_shadow);
     if (ctx->wf_aux) (void)hipStreamDestroy(ctx->wf_aux);
@@ -703,6 +689,10 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
     }
     if (p->sample_per_pixel < 1 || p->max_ray_depth < 1) {
         ctx->error = "sample_per_pixel and max_ray_depth must be >= 1";
+        return GBL_ERR_INVALID;
+    }
+    if (p->schedule > GBL_SCHEDULE_WAVEFRONT) {
+        ctx->error = "unknown schedule " + std::to_string(p->schedule);
         return GBL_ERR_INVALID;
     }
     ra.integrator = static_cast<int32_t>(p->integrator);
@@ -899,14 +889,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         ctx->error = "the wavefront schedule covers the path tracer only";
         return GBL_ERR_UNSUPPORTED;
     }
-    bool wavepool = p->schedule == GBL_SCHEDULE_WAVEPOOL;
-    if (wavepool && (!wf_capable || stream_mode || sc.has_masks)) {
-        ctx->error = "the wave-pool schedule covers the path tracer on scenes without mask materials, under the native and replay samplers";
-        return GBL_ERR_UNSUPPORTED;
-    }
-    // the wave-pool kernel writes per-sample radiance only (no LDS film tile): a call whose radiance buffer exceeds the
-    // budget runs the megakernel, which then splats through its tile -- same arithmetic, same film
-    if (wavepool && !ra.li_out && (npix * ra.spp * 16 > li_budget_bytes(ctx) || npix * ra.spp >= (1ull << 32))) wavepool = false;
     int per_cu = static_cast<int>(std::min<size_t>(8, (160 * 1024) / lds));
     per_cu = std::max(1, per_cu);
     if (stats) HIP_TRY(ctx, hipEventRecord(ctx->ev0, stream));
@@ -1088,7 +1070,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         dim3 grid(static_cast<unsigned>(grid64)), block(GBL_BLOCK);
         const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
-        bool pair_candidate = false;   // mask-free path tracing: the paired-query megakernel once the radiance buffer is known to fit
         if (stream_mode) {
             kernel = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_stream(want_stats, ext || want_stats)
                                                         : gbl_kernel_path_stream(want_stats, ext || want_stats);
@@ -1103,40 +1084,8 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             ra.stream_tail_cap = L.S * tail_words;
             gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail_words), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;
-        } else if (wavepool) {
-            // every wave of the persistent grid owns WP_SLOTS path slots (kernels/wavepool.h); the grid is exactly what is
-            // resident, so the pool is a few tens of MB and stays in L2 / Infinity Cache
-            kernel = gbl_kernel_wavepool(replay, want_stats, ext || want_stats);
-            if (!kernel) {
-                ctx->error = "wave-pool kernel variant not built";
-                return GBL_ERR_UNSUPPORTED;
-            }
-            lds = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t) + (GBL_BLOCK / 64) * 2 * gbl_wavepool_slots() * sizeof(uint32_t);
-            if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-            int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kernel), GBL_BLOCK, lds) != hipSuccess || occ < 1) occ = 1;
-            if (const char* e = getenv("GBL_WP_OCC")) occ = std::max(1, std::min(occ, atoi(e)));
-            // a wave keeps WP_SLOTS paths in flight: no more waves than the launch has paths for
-            const uint64_t paths_total = static_cast<uint64_t>(ra.local_tiles) * 64 * ra.spp;
-            const uint64_t wg_cap = std::max<uint64_t>(1, paths_total / (static_cast<uint64_t>(gbl_wavepool_slots()) * (GBL_BLOCK / 64)));
-            grid64 = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_items, wg_cap), static_cast<uint64_t>(ctx->num_cus) * occ));
-            grid = dim3(static_cast<unsigned>(grid64));
-            const uint64_t need = grid64 * (GBL_BLOCK / 64) * gbl_wavepool_bytes_per_wave();
-            if (need > ctx->wp_pool_bytes) {
-                if (ctx->wp_pool) (void)hipFree(ctx->wp_pool);
-                ctx->wp_pool = nullptr;
-                ctx->wp_pool_bytes = 0;
-                if (hipMalloc(&ctx->wp_pool, need) != hipSuccess) {
-                    ctx->error = "hipMalloc(wave-pool path state) failed";
-                    return GBL_ERR_OOM;
-                }
-                ctx->wp_pool_bytes = need;
-            }
-            ra.wp_pool = ctx->wp_pool;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
             kernel = gbl_kernel_path(replay, want_stats, ext || want_stats);
-            pair_candidate = !sc.has_masks;
         } else {
             kernel = gbl_kernel_ao(replay, want_stats, ext || want_stats);
         }
@@ -1163,67 +1112,26 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             ctx->error = "a scene with a participating medium needs the per-sample radiance buffer: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
         }
-        if (pair_candidate && defer && getenv("GBL_MK_PAIRED")) {
-            // kernels/pairkernel.h: shadow + extension ray as one job per lane (it writes per-sample radiance only).
-            // Opt-in: 30 % fewer traversal iterations but no faster on config 2 (52.2 against 51.3 ms)
-            kernel = gbl_kernel_pair(replay, want_stats, ext || want_stats);
-            lds = 4 * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        }
-        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted()) {
-            // kernels/blocktrace.h: the workgroup traces its rays in rounds and packs the survivors into fewer waves;
-            // kernels/rayexchange.h (2): the waves hand their long rays to one another through LDS, no barriers
-            const bool exchange = block_trace_wanted() == 2;
-            kernel = exchange ? gbl_kernel_path_exchange(replay, want_stats, ext || want_stats) : gbl_kernel_path_block(replay, want_stats, ext || want_stats);
-            gbl_status sst = wf_ensure_spill(ctx);
-            if (sst != GBL_OK) return sst;
-            ra.bt_spill = ctx->wf_spill;
-            lds = sizeof(float) * (4 * tp * tp + 256) + 4 * sizeof(uint32_t) +
-                  static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t) +
-                  static_cast<size_t>(exchange ? gbl_ray_exchange_lds_words() : gbl_block_trace_lds_words()) * sizeof(uint32_t);
-            if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-            grid64 = std::min<uint64_t>(n_items, static_cast<uint64_t>(ctx->num_cus) * 8);   // (the occupancy query below trims it; the stack backing holds 8 per CU)
-            grid = dim3(static_cast<unsigned>(grid64));
-        }
-        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted() == 0 && suspend_wanted()) {
-            // kernels/suspend.h: the extension query parks its last stragglers (16 words per thread, in the stack backing buffer)
-            kernel = gbl_kernel_path_suspend(replay, want_stats, ext || want_stats);
-            gbl_status sst = wf_ensure_spill(ctx, static_cast<int>(gbl_suspend_park_words()));
-            if (sst != GBL_OK) return sst;
-            ra.bt_spill = ctx->wf_spill;
-        }
-        if (p->integrator == GBL_INTEGRATOR_AO && !stream_mode && defer && !ext && !want_stats && quad_wanted(false)) {
-            kernel = gbl_kernel_ao_quad(replay);
-            lds = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        }
-        if (p->integrator == GBL_INTEGRATOR_PATH && !stream_mode && !wavepool && block_trace_wanted() == 0 && !suspend_wanted() && defer && quad_wanted(ext || want_stats) &&
-            !(pair_candidate && getenv("GBL_MK_PAIRED"))) {
-            // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records
-            // take the LDS film tile's place
-            kernel = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
-            if (quad_park_wanted() && !ext && !want_stats) {   // the stragglers' state: 14 words per thread in the stack backing buffer
-                kernel = gbl_kernel_path_quad_park(replay);
-                gbl_status sst = wf_ensure_spill(ctx, static_cast<int>(gbl_quad_park_words()));
-                if (sst != GBL_OK) return sst;
-                ra.bt_spill = ctx->wf_spill;
+        // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records take
+        // the LDS film tile's place.  Its LDS need differs from the film-tile formula checked above: checked again here, and a
+        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.
+        if (!stream_mode && defer) {
+            const size_t lds_quad = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            gbl_render_kernel k_quad = nullptr;
+            if (p->integrator == GBL_INTEGRATOR_AO && !ext && !want_stats && quad_wanted(false)) k_quad = gbl_kernel_ao_quad(replay);
+            if (p->integrator == GBL_INTEGRATOR_PATH && quad_wanted(ext || want_stats)) k_quad = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
+            if (k_quad && lds_quad <= 160 * 1024) {
+                kernel = k_quad;
+                lds = lds_quad;
+                if (lds > 64 * 1024)
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
             }
-            lds = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        }
-        if (wavepool && !defer) {
-            ctx->error = "the wave-pool schedule keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
-            return GBL_ERR_UNSUPPORTED;
         }
         if (stream_mode && !defer) {
             ctx->error = "GBL_SAMPLES_STREAM keeps 16 bytes per camera sample of the call: render this window in smaller pieces";
             return GBL_ERR_UNSUPPORTED;
         }
-        if (!wavepool) {
+        {
             // the persistent grid is what is resident: registers may allow fewer workgroups per CU than LDS does (EXT builds)
             int occ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kernel), GBL_BLOCK, lds) == hipSuccess && occ >= 1) {
@@ -1231,7 +1139,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 if (!stream_mode) grid = dim3(static_cast<unsigned>(grid64));   // (stream mode sized its scratch for the original grid)
             }
         }
-        ra.bt_spill_stride = static_cast<uint32_t>(grid64 * GBL_BLOCK);
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(tev[1], stream));
@@ -1261,7 +1168,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         memset(stats, 0, sizeof(*stats));
         stats->kernel_ms = ms;
-        stats->schedule = wavefront ? GBL_SCHEDULE_WAVEFRONT : (wavepool ? GBL_SCHEDULE_WAVEPOOL : GBL_SCHEDULE_MEGAKERNEL);
+        stats->schedule = wavefront ? GBL_SCHEDULE_WAVEFRONT : GBL_SCHEDULE_MEGAKERNEL;
         uint64_t shard_pixels = 0;
         for (int t = ra.shard_index; t < total_tiles; t += ra.shard_count) {
             int tx = t % ra.tiles_x, ty = t / ra.tiles_x;
@@ -1288,14 +1195,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 fprintf(stderr, "probe: stream sampler phases (share of the workgroups' time): emit %.1f%% permute %.1f%% assemble %.1f%% paths %.1f%% skip %.1f%%\n",
                         100.0 * h[25] / tot, 100.0 * h[26] / tot, 100.0 * h[27] / tot, 100.0 * h[28] / tot, 100.0 * h[29] / tot);
             }
-            if (getenv("GBL_PROBE") && wavepool) {
-                fprintf(stderr, "probe: wave-pool refill events %llu, shade batches %llu with %.1f slots each, traversal iterations %llu with %.1f busy lanes each\n",
-                        h[11], h[12], h[12] ? static_cast<double>(h[13]) / h[12] : 0.0, h[14], h[14] ? static_cast<double>(h[15]) / h[14] : 0.0);
-                const double tt = static_cast<double>(h[18] + h[19] + h[20]);
-                if (tt > 0.0)
-                    fprintf(stderr, "probe: wave-pool time per phase (share of the waves' time): publish + shade %.1f%% refill %.1f%% traverse %.1f%%\n",
-                            100.0 * h[18] / tt, 100.0 * h[19] / tt, 100.0 * h[20] / tt);
-            } else if (getenv("GBL_PROBE") && h[11] + h[12] + h[13] + h[14] + h[15] + h[16] + h[17]) {
+            if (getenv("GBL_PROBE") && h[11] + h[12] + h[13] + h[14] + h[15] + h[16] + h[17]) {
                 const char* names[7] = {"<=3", "4-7", "8-15", "16-31", "32-63", "64-127", ">=128"};
                 unsigned long long rays = 0, steps = 0;
                 for (int i = 0; i < 7; ++i) {

@@ -44,9 +44,6 @@ struct gbl_ctx {
     uint64_t vol_entries = 0;
     float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
     uint64_t sss_entries = 0;
-    // wave-pool schedule (kernels/wavepool.h): path-state pool of the persistent waves, grown on demand
-    void* wp_pool = nullptr;
-    uint64_t wp_pool_bytes = 0;
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;
@@ -85,22 +82,9 @@ typedef void (*gbl_li_kernel)(DevScene, RenderArgs, float4*);
 // kernels_path.hip: the persistent megakernel and the AO kernel (kernels/render_kernels.h), native / replay samplers
 gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext);
-// kernels_pair.hip: the megakernel that traces a vertex's shadow and extension ray as one job per lane (kernels/pairkernel.h)
-gbl_render_kernel gbl_kernel_pair(bool replay, bool stats, bool ext);
-// kernels_block.hip: the megakernel whose workgroups trace their rays together (kernels/blocktrace.h)
-gbl_render_kernel gbl_kernel_path_block(bool replay, bool stats, bool ext);
-uint32_t gbl_block_trace_lds_words(void);   // LDS words of the exchange area, behind the stacks
-// kernels_exchange.hip: the megakernel whose waves hand their long rays to one another through LDS (kernels/rayexchange.h)
-gbl_render_kernel gbl_kernel_path_exchange(bool replay, bool stats, bool ext);
-uint32_t gbl_ray_exchange_lds_words(void);
-// kernels_suspend.hip: the megakernel whose extension queries park their last stragglers (kernels/suspend.h)
-gbl_render_kernel gbl_kernel_path_suspend(bool replay, bool stats, bool ext);
-uint32_t gbl_suspend_park_words(void);   // words of parked traversal state per thread
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
 gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao_quad(bool replay);
-gbl_render_kernel gbl_kernel_path_quad_park(bool replay);   // ... and park their queries' last stragglers
-uint32_t gbl_quad_park_words(void);
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);
@@ -109,10 +93,6 @@ gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext);
 gbl_wf_kernel gbl_kernel_wf_trace(bool any, bool stats, bool ext, bool masks, bool ties);
 gbl_wf_kernel gbl_kernel_wf_shade(bool replay, bool stats, bool ext);
 gbl_wf_kernel gbl_kernel_wf_splat(bool replay, bool stats);
-// kernels_wavepool.hip (kernels/wavepool.h)
-gbl_render_kernel gbl_kernel_wavepool(bool replay, bool stats, bool ext);
-uint32_t gbl_wavepool_slots(void);          // path slots per wave
-uint64_t gbl_wavepool_bytes_per_wave(void); // bytes of pool state per wave
 // kernels_whitted.hip (kernels/whitted.h)
 gbl_li_kernel gbl_kernel_whitted(bool replay, bool stats);
 gbl_li_kernel gbl_kernel_whitted_stream(bool stats);

@@ -203,32 +203,15 @@ __device__ __forceinline__ void quad_transition(const DevScene& sc, TravState& s
 // trace() for a whole wave: every lane of the wave calls it (`want`: the lane has a ray); the exits are wave-uniform.
 // `slab`: this wave's 16 records; `wave_stack`: the LDS stack column of the wave's lane 0 (LdsStack layout).
 // ANY = true : Scene::occluded;  ANY = false: Scene::intersect -- as trace() (trace.h).
-//
-// PARK (closest-hit queries of the path tracer): the query returns while its last <= GBL_QUAD_PARK_T rays are still on their way,
-// once at least GBL_QUAD_PARK_READY of its rays have a result to shade.  A straggler's quad writes the ray's traversal state
-// to the ray's own lane's column of a global buffer (`park`, GBL_QUAD_PARK_WORDS words `pstride` apart; the ray's LDS stack
-// column stays as it is), the lane sits the shading pass out (*parked) and passes `resume` to the wave's next query, which
-// gives the ray a quad again as soon as that query's rays migrate.  (o, d, mint) of a resumed ray are the ones it started
-// with -- the caller's path state still holds them.  What kernels/suspend.h tried one ray per lane, where the stragglers
-// then ran beside a full wave's leaf and interior code; here they wait for the next quad phase.
 #ifndef GBL_QUAD_PRIO
 #define GBL_QUAD_PRIO 3          // s_setprio of a wave in its quad phase ...
 #endif
 #ifndef GBL_QUAD_PRIO_DENSE
 #define GBL_QUAD_PRIO_DENSE 2    // ... and in the one-ray-per-lane phase of a query (shading runs at 0)
 #endif
-#ifndef GBL_QUAD_PARK_T
-#define GBL_QUAD_PARK_T 4
-#endif
-#ifndef GBL_QUAD_PARK_READY
-#define GBL_QUAD_PARK_READY 32
-#endif
-#define GBL_QUAD_PARK_WORDS 14   // r.o r.d maxt cur sp inst hit.inst hit.tri hit.b1 hit.b2
-template <bool ANY, bool STATS, bool EXT, bool TIES, bool PARK = false>
+template <bool ANY, bool STATS, bool EXT, bool TIES>
 __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, F3 d, float mint, float maxt, const LdsStack& stk, gbl_lds_u32* slab,
-                                           gbl_lds_u32* wave_stack, Hit& hit, LaneCounters& cnt, int filter = GBL_FILTER_NONE, bool resume = false,
-                                           gbl_glb_u32* park = nullptr, uint32_t pstride = 0, bool* parked = nullptr) {
-    static_assert(!(PARK && ANY), "only closest-hit queries leave stragglers behind");
+                                           gbl_lds_u32* wave_stack, Hit& hit, LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
     TravState st;
     if (want) {
         trav_begin(sc, st, o, d, mint, maxt, stk);
@@ -252,14 +235,12 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
     // 77.4, grid 23.0 -> 22.6 (quad phase alone at 3: 44.8; at 1 or 2: 44.9).
     __builtin_amdgcn_s_setprio(GBL_QUAD_PRIO_DENSE);
     // ---- more than 16 rays in flight: one ray per lane, as trace()
-    const int n_resume = PARK ? __popcll(__ballot(resume)) : 0;            // rays parked by the previous query: they take a quad each
-    const int entered = PARK ? __popcll(__ballot(want)) + n_resume : 0;    // rays of this call
     unsigned long long live = __ballot(!done);
     // (Holding the migration back for a query's first 4 / 8 / 12 steps, so that short rays never pay for it, was measured:
     //  slower on every scene -- config [1] 50.3 / 50.4 / 51.5 against 46.5 ms.)
     // (So was making it wait for a ray with 3 / 5 / 8 entries on its stack -- one with work ahead of it: 50.0 / 50.8 / 54.2 ms.
     //  The scenes the EXT builds run, small ones, are slower under this kernel whether or not their rays ever migrate.)
-    while (__popcll(live) + n_resume > GBL_QUAD_MAX) {
+    while (__popcll(live) > GBL_QUAD_MAX) {
         if (!done) {
             if (trav_at_interior(st)) {
                 trav_interior<STATS, !ANY>(sc, st, stk, cnt);
@@ -271,27 +252,13 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         live = __ballot(!done);
     }
     Hit res = st.hit;   // (of the lanes that are done)
-    if (PARK) {
-        live = __ballot(!done || resume);
-        *parked = false;
-    }
     if (live != 0ull) {
         // ---- migration: ray of rank k -> record k -> quad k
         const uint32_t lane = threadIdx.x & 63u, q = lane >> 2;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
         const uint32_t nl = static_cast<uint32_t>(__popcll(live));
-        const bool owner = PARK ? (!done || resume) : !done;
-        if (PARK && resume) {   // the parked state goes straight into the record
-            gbl_lds_u32* rec = slab + rank * GBL_QUAD_REC_WORDS;
-            for (int w = 0; w < 6; ++w) rec[w] = park[w * pstride];
-            rec[6] = __float_as_uint(o.x); rec[7] = __float_as_uint(o.y); rec[8] = __float_as_uint(o.z);
-            rec[9] = __float_as_uint(d.x); rec[10] = __float_as_uint(d.y); rec[11] = __float_as_uint(d.z);
-            rec[12] = __float_as_uint(mint); rec[13] = park[6 * pstride];
-            rec[14] = park[7 * pstride]; rec[15] = park[9 * pstride];
-            rec[16] = park[10 * pstride]; rec[17] = park[11 * pstride];
-            rec[18] = park[12 * pstride]; rec[19] = park[13 * pstride];
-            rec[20] = park[8 * pstride] | (lane << 8);
-        } else if (owner) {
+        const bool owner = !done;
+        if (owner) {
             gbl_lds_u32* rec = slab + rank * GBL_QUAD_REC_WORDS;
             rec[0] = __float_as_uint(st.r.o.x); rec[1] = __float_as_uint(st.r.o.y); rec[2] = __float_as_uint(st.r.o.z);
             rec[3] = __float_as_uint(st.r.d.x); rec[4] = __float_as_uint(st.r.d.y); rec[5] = __float_as_uint(st.r.d.z);
@@ -399,10 +366,6 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 }
             }
 #endif
-            if (PARK) {   // few stragglers and a wave-load of results: leave them for the next query
-                const int running = __popcll(__ballot(!qdone)) >> 2;
-                if (running <= GBL_QUAD_PARK_T && entered - running >= GBL_QUAD_PARK_READY) break;
-            }
         }
         __builtin_amdgcn_s_setprio(GBL_QUAD_PRIO_DENSE);
         if (STATS && ql.c != 0u) {   // leaf / instance steps ran in all four lanes: count them once
@@ -410,20 +373,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             cnt.oth_lane = keep_ol;
             cnt.oth_wave = keep_ow;
         }
-        if (PARK && !qdone && ql.c == 0u) {   // a straggler: its state to its lane's park column, a note to the lane
-            gbl_glb_u32* pc = park - lane + static_cast<uint32_t>(ql.col - wave_stack);
-            pc[0 * pstride] = __float_as_uint(st.r.o.x); pc[1 * pstride] = __float_as_uint(st.r.o.y); pc[2 * pstride] = __float_as_uint(st.r.o.z);
-            pc[3 * pstride] = __float_as_uint(st.r.d.x); pc[4 * pstride] = __float_as_uint(st.r.d.y); pc[5 * pstride] = __float_as_uint(st.r.d.z);
-            pc[6 * pstride] = __float_as_uint(st.maxt);
-            pc[7 * pstride] = static_cast<uint32_t>(st.cur);
-            pc[8 * pstride] = static_cast<uint32_t>(st.sp);
-            pc[9 * pstride] = static_cast<uint32_t>(st.inst);
-            pc[10 * pstride] = static_cast<uint32_t>(st.hit.inst);
-            pc[11 * pstride] = st.hit.tri;
-            pc[12 * pstride] = __float_as_uint(st.hit.b1);
-            pc[13 * pstride] = __float_as_uint(st.hit.b2);
-            qrec[5] = 2u;
-        } else if (qlive && ql.c == 0u) {
+        if (qlive && ql.c == 0u) {
             qrec[0] = static_cast<uint32_t>(st.hit.inst);
             qrec[1] = st.hit.tri;
             qrec[2] = __float_as_uint(st.hit.b1);
@@ -441,17 +391,13 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             res.b2 = __uint_as_float(rec[3]);
             res.t = __uint_as_float(rec[4]);
             occluded = rec[5] != 0u;
-            if (PARK && rec[5] == 2u) {
-                *parked = true;
-                res.inst = -1;
-            }
             if (STATS) steps += rec[12];
         }
         quad_fence();   // the slab is free for the next query
     }
     __builtin_amdgcn_s_setprio(0);
 #ifndef GBL_PROBE_OCC
-    if (STATS && !ANY && want && !PARK) {
+    if (STATS && !ANY && want) {
         int b = steps <= 3 ? 0 : min(6, 30 - __clz(static_cast<int>(steps)));
         cnt.hist[b] += 1;
         cnt.hist_steps[b] += steps;

@@ -22,9 +22,6 @@
 #include "bssrdf.h"
 #include "medium.h"
 #include "trace.h"
-#include "blocktrace.h"
-#include "rayexchange.h"
-#include "suspend.h"
 #include "quadtrace.h"
 #include "vecmath.h"
 
@@ -415,68 +412,31 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
     __syncthreads();
 }
 
-// STREAM (implies REPLAY): the records are the reference's own, generated per pixel from the tile's mt19937
-// (kernels/stream.h); a work item is then a whole tile, walked pixel by pixel.
-// BT: the extension and the shadow ray of a vertex are traced by the whole workgroup together (kernels/blocktrace.h: rounds of a
-// few node visits, the surviving rays packed into as few waves as hold them in between); everything else is unchanged.
-// RX: the same two rays go through the workgroup's ray exchange instead (kernels/rayexchange.h: no barriers; the waves hand
-// their long rays to one another through LDS and help with whatever waits there while their own results are out).
-// SUSP: the extension query leaves its last few stragglers for the next iteration (kernels/suspend.h).
+// SAMPLER: where a path's Sample record comes from -- GBL_SRC_NATIVE (counter-based law, kernels/sampler.h), GBL_SRC_REPLAY
+// (caller's records) or GBL_SRC_STREAM (the reference's own records, generated per pixel from the tile's mt19937,
+// kernels/stream.h; a work item is then a whole tile, walked pixel by pixel).
 // QUAD: both queries run as wave-wide calls whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h);
 // the kernel writes per-sample radiance only (ra.li_defer), so the LDS film tile's place holds the quads' records.
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool BT = false, bool RX = false, bool SUSP = false, bool QUAD = false>
+#define GBL_SRC_NATIVE 0
+#define GBL_SRC_REPLAY 1
+#define GBL_SRC_STREAM 2
+template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
+    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = QUAD ? reinterpret_cast<uint32_t*>(smem) + GBL_QUAD_LDS_WORDS : reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
-    static_assert(!(BT && STREAM), "workgroup-level tracing is built for the native / replay samplers");
-    static_assert(!(QUAD && (STREAM || BT || RX)), "quad-per-ray steps are built for the plain megakernel under the native / replay samplers");
+    static_assert(!(QUAD && STREAM), "quad-per-ray steps are built for the native / replay samplers");
     // QUAD: LDS = 16 records per wave | ctrl | stacks
     gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
     gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
-    BlockXch bx = {};
-    uint32_t bt_phase = 0;
-    if constexpr (BT) {   // LDS: ... | stacks: min(stack_entries, GBL_WF_STACK_LDS) levels | exchange area (blocktrace.h)
-        const int lds_levels = sc.stack_entries < GBL_WF_STACK_LDS ? sc.stack_entries : GBL_WF_STACK_LDS;
-        bx.stack = gbl_as_lds(stack);
-        bx.state = gbl_as_lds(stack + lds_levels * GBL_BLOCK);
-        bx.owner = bx.state + GBL_BT_STATE_WORDS * GBL_BLOCK;
-        bx.ctrl = bx.owner + GBL_BT_OWNER_WORDS * GBL_BLOCK;
-        bx.spill = gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK);
-        bx.spill_stride = ra.bt_spill_stride;
-    }
-    static_assert(!(RX && (STREAM || BT)), "the ray exchange is built for the native / replay samplers");
-    static_assert(!(SUSP && (STREAM || BT || RX)), "suspendable queries are built for the plain megakernel under the native / replay samplers");
-    // (SUSP with QUAD: the quads' extension queries park their stragglers, kernels/quadtrace.h)
-    gbl_glb_u32* const susp_park = SUSP ? gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK + threadIdx.x) : nullptr;
-    bool susp = false;   // SUSP: this lane's extension ray is parked
-    RayXch rx = {};
-    if constexpr (RX) {   // LDS: ... | stacks: min(stack_entries, GBL_WF_STACK_LDS) levels | records | owner columns | flags | ring | counters
-        const int lds_levels = sc.stack_entries < GBL_WF_STACK_LDS ? sc.stack_entries : GBL_WF_STACK_LDS;
-        rx.stack = gbl_as_lds(stack);
-        rx.rec = gbl_as_lds(stack + lds_levels * GBL_BLOCK);
-        rx.own = rx.rec + GBL_RX_REC_WORDS * GBL_BLOCK;
-        rx.flag = rx.own + GBL_RX_OWN_WORDS * GBL_BLOCK;
-        rx.ring = rx.flag + GBL_BLOCK;
-        rx.ctl = rx.ring + GBL_BLOCK;
-        rx.spill = gbl_as_global(ra.bt_spill + static_cast<size_t>(blockIdx.x) * GBL_BLOCK);
-        rx.spill_stride = ra.bt_spill_stride;
-        rx_init(rx);
-    }
-    typedef typename std::conditional<BT || RX, SplitStack, LdsStack>::type PathStack;
-    PathStack stk;
-    if constexpr (RX) {
-        stk = rx_stack(rx, threadIdx.x);
-    } else if constexpr (BT) {
-        stk = bt_stack(bx, threadIdx.x);
-    } else {
-        stk.p = gbl_as_lds(stack + threadIdx.x);
-    }
+    LdsStack stk;
+    stk.p = gbl_as_lds(stack + threadIdx.x);
     if (!QUAD)
         for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     StreamCtx scx = {};
@@ -599,42 +559,12 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     exhausted = true;
                 }
             }
-            if (!BT && __ballot(active) == 0ull) break;
+            if (__ballot(active) == 0ull) break;
 
             bool finished = false;
             Hit hit;
             bool got = false;
-            if constexpr (BT) {
-                // (the workgroup leaves the loop together: "some wave still has a path in flight" rides on the trace's first barrier)
-                bool any_active = false;
-                const bool want = active && sc.num_lights != 0;
-                got = trace_block<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, bx, hit, cnt, GBL_FILTER_NONE, bt_phase,
-                                                                        active, &any_active);
-                if (!any_active) break;
-                if (active && !want) finished = true;
-                if (STATS && want) cnt.ext += 1;
-            } else if constexpr (RX) {
-                const bool want = active && sc.num_lights != 0;
-                got = trace_rx<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, rx, hit, cnt, GBL_FILTER_NONE);
-                if (active && !want) finished = true;
-                if (STATS && want) cnt.ext += 1;
-            } else if constexpr (QUAD && SUSP) {
-                const bool want = active && sc.num_lights != 0;
-                bool parked = false;
-                got = trace_quad<false, STATS, EXT, REPLAY || STATS, true>(sc, want && !susp, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt,
-                                                                            GBL_FILTER_NONE, want && susp, susp_park, ra.bt_spill_stride, &parked);
-                if (STATS && want && !susp) cnt.ext += 1;
-                susp = parked;
-                if (active && !want) finished = true;
-            } else if constexpr (SUSP) {
-                const bool want = active && sc.num_lights != 0;
-                bool done = false, parked = false;
-                got = trace_suspendable<STATS, EXT, REPLAY || STATS>(sc, want && !susp, want && susp, ps.o, ps.d, ps.mint, susp_park, ra.bt_spill_stride, stk,
-                                                                       hit, cnt, &done, &parked);
-                if (STATS && want && !susp) cnt.ext += 1;
-                susp = parked;
-                if (active && !want) finished = true;
-            } else if constexpr (QUAD) {
+            if constexpr (QUAD) {
                 const bool want = active && sc.num_lights != 0;
                 got = trace_quad<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
                 if (active && !want) finished = true;
@@ -647,8 +577,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     if (STATS) cnt.ext += 1;
                 }
             }
-            // (SUSP: a lane whose ray is parked sits this iteration's shading out; its path state is untouched)
-            const bool vis = SUSP ? (active && !susp) : active;
+            const bool vis = active;
             Frag fr;
             TexFrag tf;
             if (vis && !finished) {
@@ -807,30 +736,18 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 }
             }
             // ---- shadow query (any-hit)
-            bool bt_occluded = false;
-            if constexpr (BT) {
-                Hit dummy;
-                bt_occluded = trace_block<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, bx, dummy, cnt,
-                                                                  (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE, bt_phase, false, nullptr);
-            }
-            if constexpr (RX) {
-                if (__ballot(need_shadow) != 0ull) {
-                    Hit dummy;
-                    bt_occluded = trace_rx<true, STATS, EXT, REPLAY || STATS>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, rx, dummy, cnt,
-                                                                               (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
-                }
-            }
+            bool quad_occluded = false;
             if constexpr (QUAD) {
                 if (__ballot(need_shadow) != 0ull) {
                     Hit dummy;
-                    bt_occluded = trace_quad<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, stk, quad_slab, quad_stack, dummy, cnt,
+                    quad_occluded = trace_quad<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, stk, quad_slab, quad_stack, dummy, cnt,
                                                                      (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 }
             }
             if (need_shadow) {
                 Hit dummy;
                 const bool masks = EXT && sc.has_masks != 0;
-                bool occluded = (BT || RX || QUAD) ? bt_occluded
+                bool occluded = QUAD ? quad_occluded
                                    : trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
                                                              masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 if (STATS) cnt.shadow += 1;
@@ -950,8 +867,9 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 // ---------------------------------------------------------------------------
 // QUAD: the camera ray and the occlusion rays run as wave-wide queries whose last <= 16 rays migrate to quads of lanes
 // (kernels/quadtrace.h); per-sample radiance only (ra.li_defer), LDS = quads' records | ctrl | stacks.
-template <bool REPLAY, bool STATS, bool EXT, bool STREAM = false, bool QUAD = false>
+template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false>
 __global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs ra) {
+    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);

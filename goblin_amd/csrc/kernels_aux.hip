@@ -139,6 +139,83 @@ gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_
     return GBL_OK;
 }
 
+// ---------------------------------------------------------------------------
+// VALU issue-rate microbenchmark (no memory traffic): every wave runs `iters` x 64 instructions of ONE kind over 16
+// independent register chains, with w = blockDim.x / 256 waves resident on each SIMD of each CU (one workgroup per CU:
+// the launch asks for more than half of a CU's LDS).  What the roofline of the traversal kernels is priced against
+// (bench.py): the measured cost of a wave64 instruction in SIMD cycles, alone on its SIMD and beside 1-3 other waves.
+// ---------------------------------------------------------------------------
+typedef float gbl_f2 __attribute__((ext_vector_type(2)));
+#define GBL_VI_16(STMT) STMT(0) STMT(1) STMT(2) STMT(3) STMT(4) STMT(5) STMT(6) STMT(7) STMT(8) STMT(9) STMT(10) STMT(11) STMT(12) STMT(13) STMT(14) STMT(15)
+template <int OP>
+__device__ __forceinline__ void valu_issue_loop(float (&a)[16], gbl_f2 (&p)[16], uint32_t (&u)[16], float b, float c, gbl_f2 pb, gbl_f2 pc, uint32_t ub, uint32_t iters);
+__global__ __launch_bounds__(1024) void valu_issue_kernel(float* out, int op, uint32_t iters, unsigned long long* ticks) {
+    extern __shared__ __align__(16) unsigned char vi_smem[];
+    float a[16];
+    gbl_f2 p[16];
+    uint32_t u[16];
+    const float b = 1.0f + 1e-7f * threadIdx.x, c = 1e-9f * blockIdx.x;
+    const gbl_f2 pb = {b, b}, pc = {c, c};
+    const uint32_t ub = 0x03020100u + threadIdx.x;
+    for (int i = 0; i < 16; ++i) {
+        a[i] = 0.001f * (i + 1);
+        p[i] = gbl_f2{a[i], a[i]};
+        u[i] = threadIdx.x * 16u + i;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    switch (op) {   // (wave-uniform: one scalar branch in front of the measured loop)
+        case 0: valu_issue_loop<0>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 1: valu_issue_loop<1>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 2: valu_issue_loop<2>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 3: valu_issue_loop<3>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 4: valu_issue_loop<4>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 5: valu_issue_loop<5>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 6: valu_issue_loop<6>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 7: valu_issue_loop<7>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 8: valu_issue_loop<8>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 9: valu_issue_loop<9>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 10: valu_issue_loop<10>(a, p, u, b, c, pb, pc, ub, iters); break;
+        default: valu_issue_loop<11>(a, p, u, b, c, pb, pc, ub, iters); break;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.0f;
+    for (int i = 0; i < 16; ++i) sum += a[i] + p[i].x + p[i].y + __uint_as_float(u[i] & 0x3fffffffu);
+    if (sum == 12345.678f) out[0] = sum + vi_smem[threadIdx.x];   // keeps the chains alive; never true
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(ticks, t1 - t0);
+}
+template <int OP>
+__device__ __forceinline__ void valu_issue_loop(float (&a)[16], gbl_f2 (&p)[16], uint32_t (&u)[16], float b, float c, gbl_f2 pb, gbl_f2 pc, uint32_t ub, uint32_t iters) {
+#pragma unroll 1
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+#define GBL_VI_FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define GBL_VI_PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pc));
+#define GBL_VI_ADD(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+#define GBL_VI_MAX3(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define GBL_VI_CVT(i) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(u[i]));
+#define GBL_VI_PERM(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(ub), "v"(ub));
+#define GBL_VI_DPP(i) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(u[i]));
+#define GBL_VI_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(ub) : );
+#define GBL_VI_AND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_RCP(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+#define GBL_VI_MED3(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define GBL_VI_CMP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+            if constexpr (OP == 0) { GBL_VI_16(GBL_VI_FMA) }
+            if constexpr (OP == 1) { GBL_VI_16(GBL_VI_PKFMA) }
+            if constexpr (OP == 2) { GBL_VI_16(GBL_VI_ADD) }
+            if constexpr (OP == 3) { GBL_VI_16(GBL_VI_MAX3) }
+            if constexpr (OP == 4) { GBL_VI_16(GBL_VI_CVT) }
+            if constexpr (OP == 5) { GBL_VI_16(GBL_VI_PERM) }
+            if constexpr (OP == 6) { GBL_VI_16(GBL_VI_DPP) }
+            if constexpr (OP == 7) { GBL_VI_16(GBL_VI_CNDMASK) }
+            if constexpr (OP == 8) { GBL_VI_16(GBL_VI_AND) }
+            if constexpr (OP == 9) { GBL_VI_16(GBL_VI_RCP) }
+            if constexpr (OP == 10) { GBL_VI_16(GBL_VI_MED3) }
+            if constexpr (OP == 11) { GBL_VI_16(GBL_VI_CMP) }
+        }
+    }
+}
 extern "C" {
 
 __global__ void selftest_sincos_kernel(const float* in, float* s, float* c, uint64_t n) {
@@ -249,6 +326,47 @@ static gbl_status gbl_selftest_libm_impl(gbl_ctx* ctx, int fn, const float* a, c
 }
 gbl_status gbl_selftest_libm(gbl_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n) {
     return gbl_guard([&] { return gbl_selftest_libm_impl(ctx, fn, a, b, out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
+}
+
+static gbl_status gbl_selftest_valu_issue_impl(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out) {
+    if (!ctx || !out || op < 0 || op >= GBL_VALU_OP_COUNT || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return GBL_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void (*const k)(float*, int, uint32_t, unsigned long long*) = valu_issue_kernel;
+    const size_t lds = 96 * 1024;   // more than half of a CU's 160 KB: one workgroup per CU
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    float* d_out = nullptr;
+    unsigned long long* d_ticks = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), 64));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_ticks), 8));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    const dim3 grid(ctx->num_cus), block(256 * waves_per_simd);
+    float ms = 0.0f;
+    unsigned long long ticks = 0;
+    for (int pass = 0; pass < 2; ++pass) {   // the second launch is the measured one
+        HIP_TRY(ctx, hipMemset(d_ticks, 0, 8));
+        HIP_TRY(ctx, hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(k, grid, block, lds, nullptr, d_out, op, iters, d_ticks);
+        HIP_TRY(ctx, hipEventRecord(e1, nullptr));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        HIP_TRY(ctx, hipMemcpy(&ticks, d_ticks, 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    (void)hipFree(d_ticks);
+    const double waves = static_cast<double>(ctx->num_cus) * 4.0 * waves_per_simd;
+    out[0] = ms;                                             // the launch, HIP events
+    out[1] = waves * 64.0 * iters;                           // wave-instructions of the measured kind, whole launch
+    out[2] = static_cast<double>(ticks) / waves;             // s_memtime ticks per wave, first to last instruction
+    out[3] = out[2] / (64.0 * iters);                        // ... per instruction of that wave
+    return GBL_OK;
+}
+gbl_status gbl_selftest_valu_issue(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out) {
+    return gbl_guard([&] { return gbl_selftest_valu_issue_impl(ctx, op, waves_per_simd, iters, out); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
 }
 
 static gbl_status gbl_selftest_sincos_impl(gbl_ctx* ctx, const float* in, float* sin_out, float* cos_out, uint64_t n) {

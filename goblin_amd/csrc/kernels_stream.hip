@@ -4,11 +4,11 @@
 #include "kernels/render_kernels.h"
 
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext) {
-    if (stats) return path_trace_kernel<true, true, true, true>;
-    return ext ? path_trace_kernel<true, false, true, true> : path_trace_kernel<true, false, false, true>;
+    if (stats) return path_trace_kernel<GBL_SRC_STREAM, true, true>;
+    return ext ? path_trace_kernel<GBL_SRC_STREAM, false, true> : path_trace_kernel<GBL_SRC_STREAM, false, false>;
 }
 
 gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext) {
-    if (stats) return ao_kernel<true, true, true, true>;
-    return ext ? ao_kernel<true, false, true, true> : ao_kernel<true, false, false, true>;
+    if (stats) return ao_kernel<GBL_SRC_STREAM, true, true>;
+    return ext ? ao_kernel<GBL_SRC_STREAM, false, true> : ao_kernel<GBL_SRC_STREAM, false, false>;
 }

@@ -95,6 +95,14 @@ class HipPathTracer:
         got = self.lib.gbl_get_timings(self.handle, n, buf)
         return [(buf[i].main_kernel_ms, buf[i].total_ms) for i in range(got)]
 
+    def valu_issue(self, op, waves_per_simd, iters=4096):
+        """gbl_selftest_valu_issue: {ms, wave_instructions, ticks_per_wave, ticks_per_instruction} of one launch."""
+        out = (C.c_double * 4)()
+        st = self.lib.gbl_selftest_valu_issue(self.handle, int(op), int(waves_per_simd), int(iters), out)
+        if st != _abi.GBL_OK:
+            raise _abi.GoblinError(st, self.lib.gbl_last_error(self.handle).decode())
+        return {"ms": out[0], "wave_instructions": out[1], "ticks_per_wave": out[2], "ticks_per_instruction": out[3]}
+
     def new_film(self):
         return Film(self.info.xres, self.info.yres, self.device)
 
@@ -119,7 +127,7 @@ class HipPathTracer:
         p.li_out = li_out.data_ptr() if li_out is not None else None
         p.russian_roulette = 1 if rr else 0
         p.collect_stats = 1 if stats else 0
-        p.schedule = {"auto": 0, "megakernel": 1, "wavefront": 2, "wavepool": 3}.get(schedule, schedule)
+        p.schedule = {"auto": 0, "megakernel": 1, "wavefront": 2}.get(schedule, schedule)
         torch = _torch()
         p.stream = torch.cuda.current_stream(self.device).cuda_stream
         return p

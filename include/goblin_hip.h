@@ -412,10 +412,7 @@ typedef enum gbl_sample_mode {
 
 /* How the device schedules the same arithmetic (identical per-sample radiance):
  *  WAVEFRONT   path pool in HBM, compacted ray queues, extend / shade / shadow kernels
- *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration
- *  WAVEPOOL    one persistent kernel; every wave runs its own wavefront loop over a small cache-resident
- *              pool of path slots (trace with in-wave refill, shade in full batches; path tracer only,
- *              mask-free scenes, native / replay samplers) */
+ *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration */
 /* AUTO: instanced triangles >= TRIS and at least PATHS camera samples in the call (this rank's tiles x spp), or fewer
  * triangles under trees so deep that the megakernel's workgroups would fit two to a CU at three stack entries per level
  * -> WAVEFRONT, else MEGAKERNEL (gbl_stats.schedule reports what a call ran under) */
@@ -424,8 +421,7 @@ typedef enum gbl_sample_mode {
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,
     GBL_SCHEDULE_MEGAKERNEL = 1,
-    GBL_SCHEDULE_WAVEFRONT = 2,
-    GBL_SCHEDULE_WAVEPOOL = 3
+    GBL_SCHEDULE_WAVEFRONT = 2
 } gbl_schedule;
 
 typedef struct gbl_render_params {
@@ -543,6 +539,17 @@ gbl_status gbl_selftest_arith(gbl_ctx* ctx, const float* a, const float* b, floa
 /* Self-test hook: scene queries for n device rays {kind (0 Scene::intersect, 1 Scene::occluded), o(3), d(3), mint, maxt}
  * -> out n x 8 floats {hit t or -1 | 1 occluded or 0, hit instance or -1, shading normal(3), tangent(3)}. */
 gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint32_t n);
+
+/* Self-test hook: VALU issue-rate microbenchmark, no memory traffic.  Every CU runs one workgroup of 4 * waves_per_simd
+ * waves (waves_per_simd 1..4 resident on each SIMD), every wave `iters` x 64 instructions of kind `op` over 16 independent
+ * register chains.  out[4] = {launch ms (HIP events), wave-instructions of the launch, s_memtime ticks per wave, ticks per
+ * instruction of a wave}.  The peak the traversal kernels' VALU roofline is priced against comes from this measurement. */
+typedef enum gbl_valu_op {
+    GBL_VALU_FMA_F32 = 0, GBL_VALU_PK_FMA_F32 = 1, GBL_VALU_ADD_F32 = 2, GBL_VALU_MAX3_F32 = 3, GBL_VALU_CVT_UBYTE = 4,
+    GBL_VALU_PERM_B32 = 5, GBL_VALU_MOV_DPP = 6, GBL_VALU_CNDMASK = 7, GBL_VALU_AND_B32 = 8, GBL_VALU_RCP_F32 = 9,
+    GBL_VALU_MED3_F32 = 10, GBL_VALU_CMP_F32 = 11, GBL_VALU_OP_COUNT = 12
+} gbl_valu_op;
+gbl_status gbl_selftest_valu_issue(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out);
 
 void gbl_destroy(gbl_ctx* ctx);
 /* Message for the last failing call on ctx (or on creation when ctx == NULL). */

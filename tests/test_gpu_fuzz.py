@@ -38,12 +38,8 @@ def test_random_scene_matches_oracle(seed):
     masks_in_use = any(scene.desc.materials[scene.desc.instances[i].material].type == _abi.GBL_MAT_MASK for i in range(scene.desc.num_instances))
     for bvh in ("host", "device"):
         r = HipPathTracer(scene, 0, bvh=bvh)
-        for schedule in ("megakernel", "wavefront", "wavepool"):
-            try:
-                li = r.render(seed=rseed, want_li=True, schedule=schedule)["li"].cpu().numpy()
-            except _abi.GoblinError as e:   # the wave-pool kernel refuses scenes with mask / subsurface materials
-                assert schedule == "wavepool" and e.status == _abi.GBL_ERR_UNSUPPORTED, (seed, schedule, str(e))
-                continue
+        for schedule in ("megakernel", "wavefront"):
+            li = r.render(seed=rseed, want_li=True, schedule=schedule)["li"].cpu().numpy()
             assert np.isfinite(li).all(), (seed, bvh, schedule)
             flips = helpers.li_mismatch_fraction(li, li_ref)
             rel = helpers.rel_l2(li[:, :3], li_ref[:, :3])

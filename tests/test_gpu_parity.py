@@ -38,17 +38,10 @@ def torch():
     return torch
 
 
-@pytest.fixture(params=["wavefront", "megakernel", "wavepool"])
+@pytest.fixture(params=["wavefront", "megakernel"])
 def schedule(request):
     """The device schedules run the same arithmetic and must each match the reference."""
     return request.param
-
-
-def scene_has_masks(scene):
-    """What the wave-pool kernel refuses: materials whose type carries BSDFnullptr -- masks, and subsurface materials
-    (BSDFAll), DevScene::has_masks."""
-    d = scene.desc
-    return any(d.materials[i].type in (_abi.GBL_MAT_MASK, _abi.GBL_MAT_SUBSURFACE) for i in range(d.num_materials))
 
 
 class _Scheduled:
@@ -62,8 +55,6 @@ class _Scheduled:
 
     def render(self, **kw):
         s = kw.get("setting") or self._t.scene.desc.setting
-        if self._schedule == "wavepool" and s.integrator == _abi.GBL_INTEGRATOR_PATH and scene_has_masks(self._t.scene):
-            pytest.skip("the wave-pool kernel refuses this scene (masks / subsurface / images): megakernel and wavefront cover it")
         kw.setdefault("schedule", "auto" if s.integrator != _abi.GBL_INTEGRATOR_PATH else self._schedule)
         return self._t.render(**kw)
 
@@ -392,26 +383,9 @@ def test_auto_schedule_at_config3_depth_is_the_wavefront(golden, torch):
     scene = gs.load_scene(meta["scene"], meta["overrides"])
     r = HipPathTracer(scene, 0)
     seed = 5
-    li = {s: r.render(seed=seed, want_li=True, schedule=s)["li"].cpu().numpy() for s in ("auto", "wavefront", "megakernel", "wavepool")}
-    for s in ("wavefront", "megakernel", "wavepool"):
+    li = {s: r.render(seed=seed, want_li=True, schedule=s)["li"].cpu().numpy() for s in ("auto", "wavefront", "megakernel")}
+    for s in ("wavefront", "megakernel"):
         np.testing.assert_array_equal(li["auto"].view(np.uint32), li[s].view(np.uint32))
-
-
-def test_paired_query_megakernel_is_bit_identical(torch, monkeypatch):
-    """GBL_MK_PAIRED=1 selects kernels/pairkernel.h (a vertex's shadow and extension ray traced as one job per lane, one
-    kind of traversal step per iteration): another order of the same arithmetic."""
-    from goblin_amd.renderer import HipPathTracer
-    for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=8)),
-                     ("cornell", gs.config_overrides(resolution=(48, 48), spp=16, depth=12)),
-                     ("shapes", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
-                     ("textured", gs.config_overrides(resolution=(48, 48), spp=9, depth=5))):
-        scene = gs.load_scene(name, ov)
-        monkeypatch.delenv("GBL_MK_PAIRED", raising=False)
-        ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        monkeypatch.setenv("GBL_MK_PAIRED", "1")
-        got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
-        np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_quad_per_ray_megakernel_is_bit_identical(golden, torch, monkeypatch):
@@ -437,10 +411,6 @@ def test_quad_per_ray_megakernel_is_bit_identical(golden, torch, monkeypatch):
         got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
         np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
         np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
-        # GBL_MK_QUAD=2 (experiment, lean path tracer only): an extension query leaves its last <= 4 rays parked until the wave's next one
-        monkeypatch.setenv("GBL_MK_QUAD", "2")
-        got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
     # replayed reference samples (the tie-rule builds): the quads run trav_other's own leaf loop there
     for fixture in ("bunny_pt", "cornell_pt", "grid_pt", "bunny_ao"):
         meta, data = golden(fixture)
@@ -460,33 +430,6 @@ def test_quad_per_ray_megakernel_is_bit_identical(golden, torch, monkeypatch):
             monkeypatch.setenv("GBL_MK_QUAD", mode)
             li[mode] = r.render(window=win, replay_samples=samples, want_li=True, schedule="megakernel")["li"].cpu().numpy()
         np.testing.assert_array_equal(li["0"].view(np.uint32), li["1"].view(np.uint32))
-
-
-@pytest.mark.parametrize("mode", ["1", "2", "suspend"])
-def test_workgroup_tracing_experiments_are_bit_identical(torch, monkeypatch, mode):
-    """GBL_MK_BLOCKTRACE=1 (kernels/blocktrace.h: the workgroup's rays traced in rounds, survivors packed into fewer waves at
-    barriers) and =2 (kernels/rayexchange.h: waves hand their long rays to one another through an LDS ring) move rays between
-    lanes, GBL_MK_SUSPEND=1 (kernels/suspend.h) parks a wave's last stragglers until its next extension query; none of them
-    changes a ray's own sequence of node visits: same radiance bit for bit, masks / shapes / textures / image lookups /
-    medium and the film included.  (Measured slower than the plain megakernel, DESIGN.md 4.1: kept as experiments.)"""
-    from goblin_amd.renderer import HipPathTracer
-    for name, ov in (("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=8)),
-                     ("cornell", gs.config_overrides(resolution=(48, 48), spp=16, depth=12)),
-                     ("grid", gs.config_overrides(resolution=(64, 64), spp=4, depth=5)),
-                     ("masked", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
-                     ("imagetex", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
-                     ("volume", gs.config_overrides(resolution=(32, 32), spp=4, depth=4))):
-        scene = gs.load_scene(name, ov)
-        monkeypatch.delenv("GBL_MK_BLOCKTRACE", raising=False)
-        monkeypatch.delenv("GBL_MK_SUSPEND", raising=False)
-        ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        if mode == "suspend":
-            monkeypatch.setenv("GBL_MK_SUSPEND", "1")
-        else:
-            monkeypatch.setenv("GBL_MK_BLOCKTRACE", mode)
-        got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
-        np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_exact_stack_entries_hold_every_ray(torch):

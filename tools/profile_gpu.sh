@@ -18,8 +18,11 @@ for a in "$@"; do
 done
 cd /tmp
 echo "${CMD[@]}" > $OUT/command.txt
+# the tree the counters come from (bench.py only quotes counters whose stamp is the running tree's): recorded HERE, on the box
+(cd $ROOT && python3 -c "from goblin_amd import build; print(build.source_stamp())") > $OUT/stamp.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- "${CMD[@]}" > $OUT/stats.log 2>&1 || echo "stats pass failed" >&2
-for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+# (the second SQ group: where a wave's cycles go -- parked at s_waitcnt / issue stall / issuing -- and the lanes its VALU instructions had switched on)
+for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
   timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- "${CMD[@]}" > $OUT/pmc_$N.log 2>&1 || echo "pmc pass $N failed" >&2
 done

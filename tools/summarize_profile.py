@@ -27,7 +27,16 @@ stats = max(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), rec
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 cmd = open(os.path.join(src, "command.txt")).read().strip().replace(REPO + "/", "") if os.path.exists(os.path.join(src, "command.txt")) else ""
-summary = {"name": name, "source_stamp": build.source_stamp(),
+# the stamp of the tree the passes ran on, written on the GPU box by tools/profile_gpu.sh; a summary made from a tree that has
+# moved on since is refused rather than stamped with the wrong sources
+stamp_file = os.path.join(src, "stamp.txt")
+stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
+if stamp is None:
+    sys.exit("no %s: re-collect with tools/profile_gpu.sh (it records the source stamp at collection time)" % stamp_file)
+if stamp != build.source_stamp():
+    print("warning: counters were collected from source stamp %s, this tree is %s -- the summary keeps the COLLECTED stamp, bench.py will not quote it" %
+          (stamp, build.source_stamp()), file=sys.stderr)
+summary = {"name": name, "source_stamp": stamp,
            "command": "tools/profile_gpu.sh %s %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group)" % (tag, cmd),
            "workload": what,
            "kernel_avg_ms": {r["Name"]: round(float(r["AverageNs"]) * 1e-6, 4) for r in rows if float(r["Percentage"]) > 0.05},
@@ -64,6 +73,14 @@ for k, c in summary["counters_per_launch"].items():
         c["hbm_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
         c["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
+    if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
+        # active-lane fraction of the VALU instructions: thread-cycles over 64 x the instructions' own (quad-)cycles
+        c["lane_util_pmc"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+    if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+        # MI355X_MICROARCH.md: WAIT_ANY (parked at s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES
+        for key, out in (("SQ_WAIT_ANY", "wait_frac_pmc"), ("SQ_WAIT_INST_ANY", "issue_stall_frac_pmc"), ("SQ_ACTIVE_INST_ANY", "active_frac_pmc")):
+            if key in c:
+                c[out] = c[key] / c["SQ_WAVE_CYCLES"]
 json.dump(summary, open(os.path.join(dst, name + ".json"), "w"), indent=1)
 print(json.dumps({k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items()} for k, v in summary["counters_per_launch"].items()
                   if summary["kernel_avg_ms"].get(k, 0) > 0.2}, indent=1))
