@@ -1139,9 +1139,29 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 if (!stream_mode) grid = dim3(static_cast<unsigned>(grid64));   // (stream mode sized its scratch for the original grid)
             }
         }
+        const bool phase_clock = getenv("GBL_PHASE_CLOCK") != nullptr && !want_stats;   // measurement builds (-DGBL_PHASE_CLOCK, tools/phase_clock.py)
+        if (phase_clock) HIP_TRY(ctx, hipMemsetAsync(ctx->stats, 0, 32 * sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, ra);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(tev[1], stream));
+        if (phase_clock) {
+            unsigned long long h[24];
+            HIP_TRY(ctx, hipStreamSynchronize(stream));
+            HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));
+            if (h[8]) {
+                const double k = static_cast<double>(h[8]);
+                fprintf(stderr, "phase clock (share of the waves' ticks): closest-hit query %.1f%% = dense %.1f%% + migrate %.1f%% + quad %.1f%% | any-hit query %.1f%% = dense "
+                        "%.1f%% + migrate %.1f%% + quad %.1f%% | rest (shading, regeneration, item fetch) %.1f%% | dense iterations %llu, quad iterations %llu, "
+                        "wave ticks %llu\n", 100 * h[0] / k, 100 * h[1] / k, 100 * h[2] / k, 100 * h[3] / k, 100 * h[4] / k, 100 * h[5] / k, 100 * h[6] / k, 100 * h[7] / k,
+                        100 * (k - h[0] - h[4]) / k, h[9], h[10], h[8]);
+                fprintf(stderr, "phase clock, dense loop: interior blocks %llu (%.0f ticks, %.1f lanes each, %.1f%% of the kernel), leaf / instance blocks %llu (%.0f ticks, %.1f lanes, %.1f%%)\n",
+                        h[13], h[13] ? double(h[11]) / h[13] : 0.0, h[13] ? double(h[15]) / h[13] : 0.0, 100 * h[11] / k, h[14], h[14] ? double(h[12]) / h[14] : 0.0,
+                        h[14] ? double(h[16]) / h[14] : 0.0, 100 * h[12] / k);
+                fprintf(stderr, "phase clock, quad loop: interior iterations %llu (%.0f ticks each, %.1f%%), leaf %llu (%.0f ticks, %.1f%%), transitions / exit %llu (%.0f ticks, %.1f%%); %.2f rays per iteration\n",
+                        h[20], h[20] ? double(h[17]) / h[20] : 0.0, 100 * h[17] / k, h[21], h[21] ? double(h[18]) / h[21] : 0.0, 100 * h[18] / k, h[22],
+                        h[22] ? double(h[19]) / h[22] : 0.0, 100 * h[19] / k, h[10] ? double(h[23]) / h[10] : 0.0);
+            }
+        }
         if (defer) {
             WfArgs wa;
             memset(&wa, 0, sizeof(wa));

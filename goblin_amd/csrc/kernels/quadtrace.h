@@ -138,10 +138,11 @@ __device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, Lan
     bool ok = false;
     if (ql.c < count) {
         if (STATS) cnt.tris += 1;
-        ok = tri_test_regs(make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), 0.0f),
-                           make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), 0.0f),
-                           make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), 0.0f), st.r.o, st.r.d, st.mint, st.maxt, &t,
-                           &b1, &b2);
+        float4 q0 = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), 0.0f);
+        float4 q1 = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), 0.0f);
+        float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), 0.0f);
+        tri_fetch_together(q0, q1, q2);   // one memory round trip (trace.h)
+        ok = tri_test_regs(q0, q1, q2, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2);
     }
     const float tq = ok ? t : INFINITY;
     float m = fminf(tq, quad_dpp_f<GBL_QP_XOR1>(tq));
@@ -229,6 +230,10 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
     }
     bool done = !want, occluded = false;
     uint32_t steps = 0;
+#ifdef GBL_PHASE_CLOCK
+    const unsigned long long pc_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pc_t1 = pc_t0, pc_t2 = pc_t0, pc_t3 = pc_t0;
+#endif
     // Wave priority: a wave inside a query outranks the waves that shade (2 over 0), one in its quad phase -- a chain of
     // dependent node fetches with a few instructions between them -- outranks both (3): its instructions issue the moment
     // their operands arrive instead of queueing behind a shading wave's.  45.6 -> 44.5 ms on config [1], Cornell 78.7 ->
@@ -242,16 +247,56 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
     //  The scenes the EXT builds run, small ones, are slower under this kernel whether or not their rays ever migrate.)
     while (__popcll(live) > GBL_QUAD_MAX) {
         if (!done) {
-            if (trav_at_interior(st)) {
-                trav_interior<STATS, !ANY>(sc, st, stk, cnt);
-                if (STATS) ++steps;
-            } else {
-                done = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, stk, cnt, &occluded, filter);
+#ifdef GBL_PHASE_CLOCK
+            {
+                const bool at_int = trav_at_interior(st);
+                if (__ballot(at_int) != 0ull && at_int) {
+                    const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+                    trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+                    asm volatile("" ::"v"(st.cur), "v"(st.sp));
+                    cnt.pc[11] += __builtin_amdgcn_s_memtime() - a0;
+                    cnt.pc[13] += 1;
+                    cnt.pc[15] += __popcll(__ballot(1));
+                }
+                if (!at_int) {
+                    const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, stk, cnt, &occluded, filter);
+                    asm volatile("" ::"v"(st.cur), "v"(st.sp));
+                    cnt.pc[12] += __builtin_amdgcn_s_memtime() - b0;
+                    cnt.pc[14] += 1;
+                    cnt.pc[16] += __popcll(__ballot(1));
+                }
             }
+#else
+            // Lean builds: the leaf / instance step first (a leaf whose pop uncovers the sentinel and the exit marker takes those
+            // at once, trav_other<FUSE>), then the interior step of whoever stands at an interior node by then -- bunny -1 %,
+            // Cornell -5 %, grid -3 % against one step of either kind per iteration, which the EXT builds keep (register pressure).
+            if constexpr (EXT) {
+                if (trav_at_interior(st)) {
+                    trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+                    if (STATS) ++steps;
+                } else {
+                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, stk, cnt, &occluded, filter);
+                }
+            } else {
+                if (!trav_at_interior(st)) done = trav_other<ANY, STATS, EXT, LdsStack, TIES, true>(sc, st, stk, cnt, &occluded, filter);
+                if (!done && trav_at_interior(st)) {
+                    trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+                    if (STATS) ++steps;
+                }
+            }
+#endif
         }
         live = __ballot(!done);
+#ifdef GBL_PHASE_CLOCK
+        cnt.pc[9] += 1;
+#endif
     }
     Hit res = st.hit;   // (of the lanes that are done)
+#ifdef GBL_PHASE_CLOCK
+    asm volatile("" ::"v"(st.cur), "v"(st.sp));
+    pc_t1 = pc_t2 = pc_t3 = __builtin_amdgcn_s_memtime();
+#endif
     if (live != 0ull) {
         // ---- migration: ray of rank k -> record k -> quad k
         const uint32_t lane = threadIdx.x & 63u, q = lane >> 2;
@@ -305,16 +350,22 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         // ---- a quad per ray until the ray is done
         __builtin_amdgcn_s_setprio(GBL_QUAD_PRIO);
         const LdsStack qstk = {ql.col};
+#ifdef GBL_PHASE_CLOCK
+        pc_t2 = __builtin_amdgcn_s_memtime();
+#endif
         uint32_t keep_tris = cnt.tris, keep_ol = cnt.oth_lane, keep_ow = cnt.oth_wave;
         int sel_inst = -2;   // the instance space the v_perm selectors were made for
         while (!qdone) {
-#ifdef GBL_PROBE_OCC
-            // experiment build: shader-clock ticks per kind of quad iteration in hist_steps[0..2] (interior, quad leaf, other), their counts in hist_steps[3..5]
-            const unsigned long long pt0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-            int pkind;
+#ifdef GBL_PHASE_CLOCK
+            cnt.pc[10] += 1;
+            cnt.pc[23] += __popcll(__ballot(1)) >> 2;
+            const unsigned long long q0t = __builtin_amdgcn_s_memtime();
+            const int qkind = trav_at_interior(st) ? 0 : ((st.cur < 0 && st.inst >= 0 && st.cur != GBL_STACK_SENTINEL && st.cur != GBL_STACK_EXIT) ? 1 : 2);
 #endif
             // (Fetching the step's record -- node or triangle -- ahead of the branch on the kind of step, so that the two kinds'
-            //  loads travel together, was measured: 49.5 against 48.8 ms.)
+            //  loads travel together, was measured: 49.5 against 48.8 ms.  Letting a ray take up to three steps of different kinds
+            //  per iteration -- sequential tests instead of this chain, in the orders transition / interior / leaf, interior / leaf /
+            //  transition and leaf / transition / interior: 45.0 / 43.5 / 44.6 against 43.8 ms.)
             if (trav_at_interior(st)) {
                 const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
                 const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
@@ -326,9 +377,6 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 }
                 quad_interior<!ANY, STATS>(st, ql, cnt, w0, w1, w2, w3, popped);
                 if (STATS) ++qsteps;
-#ifdef GBL_PROBE_OCC
-                pkind = 0;
-#endif
             } else if ((ANY ? !STATS : !TIES) && st.cur < 0 && st.inst >= 0 &&
                        (!EXT || (~static_cast<uint32_t>(st.cur) >> 2) < GBL_SHAPE_FIRST_DISK)) {
                 const uint32_t lref = ~static_cast<uint32_t>(st.cur);
@@ -336,37 +384,27 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 const uint4 w0 = tp[0], w1 = tp[1], w2 = tp[2];
                 const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
                 qdone = quad_leaf<ANY, STATS>(st, ql, cnt, &qocc, w0, w1, w2, popped);
-#ifdef GBL_PROBE_OCC
-                pkind = 1;
-#endif
             } else if (st.cur == GBL_STACK_SENTINEL || (st.cur < 0 && st.inst < 0)) {
                 quad_transition<STATS, EXT>(sc, st, qstk, qrec, cnt, filter);
-#ifdef GBL_PROBE_OCC
-                pkind = 2;
-#endif
             } else if (!EXT && (ANY ? !STATS : !TIES)) {   // lean builds: all that is left is the exit marker
                 qdone = true;
                 (void)qstk;
-#ifdef GBL_PROBE_OCC
-                pkind = 2;
-#endif
             } else {   // the exit marker; analytic shapes; leaves under the reference's tie rule
                 qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, qstk, cnt, &qocc, filter);
-#ifdef GBL_PROBE_OCC
-                pkind = 2;
-#endif
             }
-#ifdef GBL_PROBE_OCC
-            if (STATS) {
-                asm volatile("" ::"v"(st.cur), "v"(st.sp));   // the step's results are in before the clock is read
-                const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
-                if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(__ballot(1)))) - 1u) {
-                    cnt.hist_steps[pkind] += static_cast<uint32_t>(pt1 - pt0);
-                    cnt.hist_steps[3 + pkind] += 1;
-                }
+#ifdef GBL_PHASE_CLOCK
+            {   // wave-level: the iteration's time goes to the kind of the wave's first live quad
+                asm volatile("" ::"v"(st.cur), "v"(st.sp));
+                const int k0 = __builtin_amdgcn_readfirstlane(qkind);
+                cnt.pc[17 + k0] += __builtin_amdgcn_s_memtime() - q0t;
+                cnt.pc[20 + k0] += 1;
             }
 #endif
         }
+#ifdef GBL_PHASE_CLOCK
+        asm volatile("" ::"v"(st.cur), "v"(st.sp));
+        pc_t3 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_setprio(GBL_QUAD_PRIO_DENSE);
         if (STATS && ql.c != 0u) {   // leaf / instance steps ran in all four lanes: count them once
             cnt.tris = keep_tris;
@@ -396,6 +434,17 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         quad_fence();   // the slab is free for the next query
     }
     __builtin_amdgcn_s_setprio(0);
+#ifdef GBL_PHASE_CLOCK
+    {
+        asm volatile("" ::"v"(res.t), "v"(res.inst));
+        const unsigned long long pc_t4 = __builtin_amdgcn_s_memtime();
+        unsigned long long* q = cnt.pc + (ANY ? 4 : 0);
+        q[0] += pc_t4 - pc_t0;
+        q[1] += pc_t1 - pc_t0;
+        q[2] += (pc_t2 - pc_t1) + (pc_t4 - pc_t3);
+        q[3] += pc_t3 - pc_t2;
+    }
+#endif
 #ifndef GBL_PROBE_OCC
     if (STATS && !ANY && want) {
         int b = steps <= 3 ? 0 : min(6, 30 - __clz(static_cast<int>(steps)));

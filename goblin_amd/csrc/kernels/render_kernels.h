@@ -455,6 +455,9 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     if constexpr (STREAM) svol = stream_vol_scratch(scx, slay);
 
     LaneCounters cnt = {};
+#ifdef GBL_PHASE_CLOCK
+    const unsigned long long pc_k0 = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles) * ra.chunks;
     const int sub_w = ra.window[1] - ra.window[0];
@@ -859,6 +862,12 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     if (STATS) accumulate_stats(ra, cnt, paths_done);
     if (STATS && STREAM && threadIdx.x == 0)
         for (int i = 0; i < 5; ++i) atomicAdd(ra.stats + 25 + i, stream_tm[i]);
+#ifdef GBL_PHASE_CLOCK
+    if (QUAD && !STATS && (threadIdx.x & 63) == 0) {   // measurement build: one lane per wave reports its phase ticks
+        cnt.pc[8] = __builtin_amdgcn_s_memtime() - pc_k0;
+        for (int i = 0; i < 24; ++i) atomicAdd(ra.stats + i, cnt.pc[i]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -868,7 +877,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 // QUAD: the camera ray and the occlusion rays run as wave-wide queries whose last <= 16 rays migrate to quads of lanes
 // (kernels/quadtrace.h); per-sample radiance only (ra.li_defer), LDS = quads' records | ctrl | stacks.
 template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false>
-__global__ __launch_bounds__(GBL_BLOCK) void ao_kernel(DevScene sc, RenderArgs ra) {
+__global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void ao_kernel(DevScene sc, RenderArgs ra) {
     constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;

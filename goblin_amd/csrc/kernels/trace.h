@@ -44,6 +44,14 @@ struct LaneCounters {
     // rays by interior steps: [0] <= 3, [1] 4-7, [2] 8-15, [3] 16-31, [4] 32-63, [5] 64-127, [6] >= 128;
     // hist_steps[b] sums the steps of bin b (closest-hit rays of the megakernel's trace())
     uint32_t hist[7], hist_steps[7];
+#ifdef GBL_PHASE_CLOCK
+    // measurement build (tools/phase_clock.py): shader-clock ticks of this wave per phase of the lean quad kernel --
+    // [0..3] closest-hit query: whole call, one-ray-per-lane loop, migration + hand-back, quad loop; [4..7] the same for the
+    // any-hit query; [8] the kernel; [9] / [10] dense / quad loop iterations; dense loop: [11] / [12] ticks inside interior / other
+    // blocks, [13] / [14] their executions, [15] / [16] lanes inside them; quad loop: [17..19] ticks of interior / leaf / other
+    // iterations, [20..22] their counts, [23] rays (quads) alive summed over iterations
+    unsigned long long pc[24];
+#endif
 };
 
 // first active lane of the current exec mask adds one wave-step
@@ -91,11 +99,18 @@ __device__ __forceinline__ bool tri_test_regs(float4 q0, float4 q1, float4 q2, F
     *b2_out = b2;
     return true;
 }
+// The three loads of a triangle record travel together: left alone the compiler sinks the p0 load below the `divisor == 0`
+// early-out, which makes every triangle test two dependent memory round trips instead of one (the traversal loops wait on
+// memory 43 % of their time, profiles/r03_bunny.json).  The empty asm needs all nine floats, so they are fetched ahead of it.
+__device__ __forceinline__ void tri_fetch_together(float4& q0, float4& q1, float4& q2) {
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z));
+}
 __device__ __forceinline__ bool tri_test(const DevTri* tp, F3 o, F3 d, float mint, float maxt, float* t_out, float* b1_out,
                                          float* b2_out) {
-    const float4 q0 = reinterpret_cast<const float4*>(tp)[0];
-    const float4 q1 = reinterpret_cast<const float4*>(tp)[1];
-    const float4 q2 = reinterpret_cast<const float4*>(tp)[2];
+    float4 q0 = reinterpret_cast<const float4*>(tp)[0];
+    float4 q1 = reinterpret_cast<const float4*>(tp)[1];
+    float4 q2 = reinterpret_cast<const float4*>(tp)[2];
+    tri_fetch_together(q0, q1, q2);
     return tri_test_regs(q0, q1, q2, o, d, mint, maxt, t_out, b1_out, b2_out);
 }
 
@@ -339,7 +354,9 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 // order -- and so does the wavefront's lean extension kernel, while every replay / stream / instrumented build keeps it.
 // `any`: the query kind as a value -- a compile-time constant through trav_other<ANY, ...> below, a per-lane flag in the
 // wave-pool kernel (kernels/wavepool.h), whose lanes trace shadow and extension rays side by side.
-template <bool STATS, bool EXT, class STK, bool TIES>
+// FUSE: a leaf whose pop uncovers the instance's sentinel (and then, possibly, the exit marker) takes those steps at once instead
+// of spending an iteration of the caller's loop on each (needs st.world: the one-ray-per-lane loops only).
+template <bool STATS, bool EXT, class STK, bool TIES, bool FUSE = false>
 __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, const bool ANY,
                                                 bool* occluded, int filter) {
     const int cur = st.cur;
@@ -407,12 +424,20 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         }
     }
     st.cur = static_cast<int>(stk.load(--st.sp));
+    if (FUSE) {
+        if (st.cur == GBL_STACK_SENTINEL) {
+            st.r = st.world;
+            st.inst = -1;
+            st.cur = static_cast<int>(stk.load(--st.sp));
+        }
+        if (st.cur == GBL_STACK_EXIT) return true;
+    }
     return false;
 }
-template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true>
+template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true, bool FUSE = false>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
                                            int filter = GBL_FILTER_NONE) {
-    return trav_other_kind<STATS, EXT, STK, TIES>(sc, st, stk, cnt, ANY, occluded, filter);
+    return trav_other_kind<STATS, EXT, STK, TIES, FUSE>(sc, st, stk, cnt, ANY, occluded, filter);
 }
 
 __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
@@ -439,13 +464,25 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
     // simply takes the step it needs; phasing by majority state (GBL_TRAV_TH) only pays in the
     // wavefront trace kernel, whose waves mix rays of many pixels and depths (measured: 64.6 ms vs
     // 76.3 ms per 68 M-path frame here, 82.4 ms vs 79.6 ms there).
+    // Lean builds, one iteration: the leaf / instance step of the lanes that stand at one, then the interior step of every lane
+    // that stands at an interior node by then -- a lane that leaves a leaf for a node (or enters an instance) takes both in one
+    // iteration (measured against one step of either kind per iteration, the quad kernels' dense phase: bunny -1 %, Cornell
+    // -4 %, grid -3 %).  The EXT builds keep one step per iteration: the longer body cost them 100+ spilled registers.
     uint32_t steps = 0;
     for (;;) {
-        if (trav_at_interior(st)) {
-            trav_interior<STATS, !ANY>(sc, st, stk, cnt);
-            if (STATS) ++steps;
-        } else if (trav_other<ANY, STATS, EXT, STK, TIES>(sc, st, stk, cnt, &occluded, filter)) {
-            break;
+        if constexpr (EXT) {
+            if (trav_at_interior(st)) {
+                trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+                if (STATS) ++steps;
+            } else if (trav_other<ANY, STATS, EXT, STK, TIES>(sc, st, stk, cnt, &occluded, filter)) {
+                break;
+            }
+        } else {
+            if (!trav_at_interior(st) && trav_other<ANY, STATS, EXT, STK, TIES, true>(sc, st, stk, cnt, &occluded, filter)) break;
+            if (trav_at_interior(st)) {
+                trav_interior<STATS, !ANY>(sc, st, stk, cnt);
+                if (STATS) ++steps;
+            }
         }
     }
 #ifndef GBL_PROBE_OCC
