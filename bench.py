@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s of the HIP path tracer on N MI355X GPUs.
 
-    python bench.py                      # 1 GPU: BASELINE.json configs[1], 5 steps, 1 warmup
+    python bench.py                      # 1 GPU: BASELINE configs[1], 5 steps, 1 warmup
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -15,6 +15,15 @@ Workloads (--workload):
   grid   BASELINE configs[3]: grid.json, 15 instances of the 69k-triangle bunny (1.04 M instanced triangles), 1024x1024
          film, 256 spp, max_ray_depth 8 = 270,536,704 paths per step.  The default for N > 1, as north_star words it:
          "image tiles shard across the 8 GPUs of one node with a final RCCL reduce of Film tiles".
+  cornell / ao  BASELINE configs[2] / configs[4].
+At N = 1 the default run also renders ONE full-size step of each of the other three configurations after the headline's
+timed region (`other_configs` in the line), so that every BASELINE configuration has a number the driver saw.
+
+Roofline (`roofline` in the line): SURVEY.md 8(d)'s figure -- algorithmic bytes of the dominant kernel over its measured
+launch time against the 8 TB/s HBM peak -- with the HBM bytes that really moved (`traffic`, PMC) beside it.  The scenes are
+cache resident, so the kernel is not HBM bound; what the counters say does bound it is under `roofline.issue`: VALU
+wave-instructions per second against the MEASURED issue peak of this chip (profiles/valu_issue_peak.json, tools/valu_peak.py)
+and the share of the waves' cycles spent parked on memory.
 
 Multi-GPU work split (goblin_amd/distributed.py), --scaling:
   strong (default for N > 1) rank r traces every N-th 8x8 sample tile of the ONE frame (Film::mergeTile's sum over
@@ -33,26 +42,41 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+SIMDS = 256 * 4
 
 
-def algorithmic_bytes(st):
-    """Algorithmic bytes of one launch of the tracing kernel (with the build's real node size): per ray
-    64 B per BVH node VISITED (one 4-wide node = four 16-B quantised child boxes; st["nodes"] counts child boxes tested,
-    4 per visit) + 48 B per triangle tested + 48 B (32 B ray in, 16 B hit out); per path 4 B per sample dimension
-    consumed + 16 B of radiance written.  The film splat (16 B per touched pixel) belongs to the splat kernel."""
-    rays = st["extension_rays"] + st["shadow_rays"]
-    return 16 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
-
-
-def survey_literal_bytes(st):
-    """SURVEY 8d read literally on node VISITS: 32 B (the reference's CompactBVHNode) per node visited."""
+def survey_8d_bytes(st):
+    """SURVEY.md 8(d), literally: per ray 32 B per BVH node visited (the reference's CompactBVHNode, GoblinBVH.h:8-16) + 48 B
+    per triangle tested + 48 B (32 B ray in, 16 B hit out); per path 4 B per sample dimension consumed + 16 B of radiance
+    written.  st["nodes"] counts child boxes tested, 4 per visit of this build's 4-wide nodes.  (The film splat's 16 B per
+    touched pixel belongs to the splat kernel.)"""
     rays = st["extension_rays"] + st["shadow_rays"]
     return 32 * (st["nodes"] // 4) + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
 
 
-def pmc_for(kernel_tag, workload, schedule):
+def build_bytes(st):
+    """The same with this build's real node: one visit fetches 64 B (four 16-B quantised child boxes)."""
+    rays = st["extension_rays"] + st["shadow_rays"]
+    return 16 * st["nodes"] + 48 * st["tris"] + 48 * rays + 4 * st["dims"] + 16 * st["paths"]
+
+
+def _template_arg(kernel_name, index):
+    """The index-th template argument of a demangled kernel name ('void wf_trace<false, true, ...>(...)' -> 'true' for 1)."""
+    a = kernel_name.find("<")
+    b = kernel_name.find(">", a)
+    args = [x.strip() for x in kernel_name[a + 1:b].split(",")] if a >= 0 and b > a else []
+    return args[index] if index < len(args) else None
+
+
+# the un-instrumented lean kernels a standard run launches, by (integrator, schedule)
+LEAN_KERNELS = {("path", "megakernel"): "void path_trace_kernel<0, false, false, true, false>(DevScene, RenderArgs)",
+                ("ao", "megakernel"): "void ao_kernel<0, false, false, true, false>(DevScene, RenderArgs)"}
+
+
+def pmc_for(workload, schedule, integrator):
     """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_<workload>_<schedule>.json,
-    written by tools/summarize_profile.py) -- only if they were collected from THIS source tree (build stamp)."""
+    written by tools/summarize_profile.py from tools/profile_gpu.sh's passes) -- only if they were collected from THIS source
+    tree (the stamp is recorded on the GPU box at collection time)."""
     from goblin_amd import build
     path = os.path.join(REPO, "profiles", "pmc_%s_%s.json" % (workload, schedule))
     if not os.path.exists(path):
@@ -62,6 +86,8 @@ def pmc_for(kernel_tag, workload, schedule):
     stamp = build.source_stamp()
     if d.get("source_stamp") != stamp:
         return None, "%s was collected from source stamp %s, this tree is %s" % (os.path.basename(path), d.get("source_stamp"), stamp)
+    keys = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES",
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_INSTS_LDS")
     if schedule == "wavefront":
         # a step is hundreds of launches of three kernels: the counters of one step = sum over the un-instrumented wavefront
         # kernels of (counters per launch x launches per render); their kernel time likewise, from the same kernel trace
@@ -73,36 +99,88 @@ def pmc_for(kernel_tag, workload, schedule):
                 continue
             per_render = calls[name] / renders
             kernels.append("%s x %g" % (name.split("(")[0].replace("void ", ""), per_render))
-            for key in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "FETCH_SIZE", "WRITE_SIZE"):
+            for key in keys:
                 if key in c:
                     agg[key] = agg.get(key, 0.0) + c[key] * per_render
             agg["kernel_avg_ms"] = agg.get("kernel_avg_ms", 0.0) + c.get("kernel_avg_ms", 0.0) * per_render
         if agg.get("SQ_INSTS_VALU"):
             return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp), None
         return None, "no wavefront kernels in %s" % os.path.basename(path)
-    # the lean instantiation: the named kernel with every template argument false (the list grows with the experiments) but
-    # the one that selects the quad-per-ray steps (kernels/quadtrace.h), which is what a lean scene runs by default
-    base = kernel_tag.split("<")[0]
-    quad_arg = {"path_trace_kernel": 7, "ao_kernel": 4}.get(base)
-    best = None
-    for name, c in d.get("counters_per_launch", {}).items():
-        if (" " + base + "<") not in (" " + name) or _template_arg(name, 0) != "false":
-            continue
-        if not all(_template_arg(name, i) in ("false", None) for i in range(12) if i != quad_arg):
-            continue
-        if best is None or _template_arg(name, quad_arg) == "true":
-            best = (name, c)
-    if best is not None:
-        return dict(best[1], kernel=best[0], file=os.path.relpath(path, REPO), source_stamp=stamp), None
-    return None, "no kernel matching %r in %s" % (kernel_tag, os.path.basename(path))
+    name = LEAN_KERNELS.get((integrator, schedule))
+    c = d.get("counters_per_launch", {}).get(name)
+    if c:
+        return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp), None
+    return None, "no kernel %r in %s" % (name, os.path.basename(path))
 
 
-def _template_arg(kernel_name, index):
-    """The index-th template argument of a demangled kernel name ('void wf_trace<false, true, ...>(...)' -> 'true' for 1)."""
-    a = kernel_name.find("<")
-    b = kernel_name.find(">", a)
-    args = [x.strip() for x in kernel_name[a + 1:b].split(",")] if a >= 0 and b > a else []
-    return args[index] if index < len(args) else None
+def valu_issue_peak(waves_per_simd):
+    """The measured VALU issue peak (tools/valu_peak.py -> profiles/valu_issue_peak.json): v_fma_f32 and v_add_f32, independent
+    chains, `waves_per_simd` resident waves on every SIMD of every CU."""
+    path = os.path.join(REPO, "profiles", "valu_issue_peak.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    out = {"file": "profiles/valu_issue_peak.json", "waves_per_simd": waves_per_simd}
+    for op, tag in (("v_fma_f32", "fma"), ("v_add_f32", "add")):
+        rows = [r for r in d["ops"].get(op, []) if r["waves_per_simd"] == waves_per_simd]
+        if not rows:
+            return None
+        out[tag + "_cycles_per_instruction_per_simd"] = rows[0]["ticks_per_instruction_per_simd"]
+        out[tag + "_g_wave_instructions_per_s"] = rows[0]["g_wave_instructions_per_s"]
+        out[tag + "_clock_ghz_under_that_load"] = rows[0]["tick_rate_ghz"]
+    return out
+
+
+def roofline_object(counted, kernel_ms, pmc, pmc_note, kernel_label, waves_per_simd=3):
+    """SURVEY 8(d)'s HBM-roofline object for one step's dominant kernel(s), with the issue-side evidence beside it."""
+    b8d, bb = survey_8d_bytes(counted), build_bytes(counted)
+    sec = kernel_ms * 1e-3
+    ach = b8d / sec / 1e9
+    traffic = int((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None
+    r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+         "traffic": traffic,
+         "formula": "SURVEY 8(d): 32 B x node visits + 48 B x triangles tested + 48 B x rays + 4 B x sample dimensions + 16 B x paths, over the "
+                    "kernel's measured launch time",
+         "algorithmic_bytes_per_launch": int(b8d),
+         "with_this_builds_64B_nodes": {"bytes_per_launch": int(bb), "gbps": round(bb / sec / 1e9, 2), "frac": round(bb / sec / 1e9 / HBM_PEAK_GBPS, 4)},
+         "kernel": kernel_label, "kernel_ms_avg": round(kernel_ms, 3),
+         "counters": {k: int(v) for k, v in counted.items() if k not in ("kernel_ms", "reserved")}}
+    if traffic:
+        r["traffic_gbps"] = round(traffic / sec / 1e9, 1)
+        r["traffic_over_algorithmic"] = round(traffic / b8d, 4)
+    if pmc and pmc.get("SQ_INSTS_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
+        clock_hz = pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["kernel_avg_ms"] * 1e-3)
+        ach_i = pmc["SQ_INSTS_VALU"] / sec * 1e-9
+        issue = {"valu_wave_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]), "achieved_g_wave_instructions_per_s": round(ach_i, 1),
+                 "cycles_per_instruction_per_simd": round(SIMDS * clock_hz * sec / pmc["SQ_INSTS_VALU"], 3),
+                 "clock_ghz_pmc": round(clock_hz * 1e-9, 3),
+                 "pmc": {"file": pmc["file"], "source_stamp": pmc["source_stamp"], "kernel": pmc["kernel"], "kernel_avg_ms_rocprof": pmc["kernel_avg_ms"]}}
+        if "TCC_HIT_sum" in pmc:
+            issue["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
+        if pmc.get("SQ_WAVE_CYCLES"):
+            for key, out in (("SQ_WAIT_ANY", "wait_frac_pmc"), ("SQ_WAIT_INST_ANY", "issue_stall_frac_pmc"), ("SQ_ACTIVE_INST_ANY", "active_frac_pmc")):
+                if key in pmc:
+                    issue[out] = round(pmc[key] / pmc["SQ_WAVE_CYCLES"], 4)
+        if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
+            issue["lane_util_pmc"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
+        peak = valu_issue_peak(min(4, waves_per_simd))   # (the microbenchmark covers 1-4 resident waves per SIMD)
+        if peak:
+            # in cycles: what a SIMD with this many waves can issue (measured, independent v_fma_f32) against what the kernel's
+            # instruction stream took per instruction -- at the kernel's own clock, which it keeps (the all-FMA microbenchmark
+            # is power-throttled to a lower one)
+            issue["measured_peak"] = peak
+            issue["frac_of_fma_issue_peak_in_cycles"] = round(peak["fma_cycles_per_instruction_per_simd"] / issue["cycles_per_instruction_per_simd"], 4)
+            issue["frac_of_fma_issue_peak_in_wall_time"] = round(ach_i / peak["fma_g_wave_instructions_per_s"], 4)
+        issue["reading"] = ("the scene is cache resident (traffic is a few per cent of the algorithmic bytes), so HBM does not bound this "
+                            "kernel; its waves sit parked on memory for wait_frac_pmc of their cycles and a SIMD issues one wave64 "
+                            "instruction per cycles_per_instruction_per_simd cycles where the microbenchmark sustains one per "
+                            "fma_cycles_per_instruction_per_simd: latency bound (dependent node / triangle fetches at three waves per "
+                            "SIMD), with lane_util_pmc of the lanes switched on")
+        r["issue"] = issue
+    else:
+        r["pmc_note"] = pmc_note
+    return r
 
 
 def cpu_baseline(workload_overrides, spp_sample, cores):
@@ -190,7 +268,6 @@ def l2_vs_reference(tracer, ref_film, spp_sample):
 def l2_vs_cpu(tracer, workload_overrides, spp_sample, cores, seed):
     """Per-pixel L2 of the normalised film against the CPU oracle on identical samples
     (native sampler, same seed), at the bounded spp."""
-    import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_binding as ob
@@ -213,17 +290,63 @@ def l2_vs_cpu(tracer, workload_overrides, spp_sample, cores, seed):
 
 
 WORKLOADS = {
-    # name: (scene, resolution, spp, depth, what it is)
+    # name: (scene, resolution, spp, depth, what it is[, extra overrides])
     "bunny": ("bunny", (512, 512), 256, 8, "BASELINE configs[1]: bunny.json, glass stand-in bunny (69120 tris) on a plane, spot light"),
     "grid": ("grid", (1024, 1024), 256, 8, "BASELINE configs[3]: grid.json, 15 instances of the bunny BLAS (1.04 M instanced triangles)"),
-    # the other two configurations, for profiles (tools/profile_gpu.sh): run them with --spp to bound the time, the kernels'
-    # per-launch behaviour does not depend on it
     "cornell": ("cornell", (1024, 1024), 1024, 16, "BASELINE configs[2]: cornell.json, Cornell box + glass bunny, area light, divergent BSDF mix"),
     "ao": ("bunny", (2048, 2048), 4096, 8, "BASELINE configs[4]: bunny.json under the AO integrator (1 closest hit + 25 any-hit rays per camera sample)",
            {"method": "ao", "ao_samples": 25}),
 }
-VALU_CYCLES_PER_WAVE_INSTRUCTION = 4   # MI355X_MICROARCH.md: one wave64 f32 VALU instruction holds its SIMD's issue for 4 cycles
-SIMDS = 256 * 4
+
+
+class Workload:
+    """One configuration resident on the device: scene, tracer, film, and the band structure of a frame."""
+
+    def __init__(self, name, device_index, res=None, spp=None, depth=None):
+        from goblin_amd import scene as gs
+        from goblin_amd.renderer import HipPathTracer
+        w = WORKLOADS[name]
+        self.name, self.scene_name, self.text = name, w[0], w[4]
+        self.extra = w[5] if len(w) > 5 else {}
+        self.res = tuple(res) if res else w[1]
+        self.spp = spp or w[2]
+        self.depth = depth or w[3]
+        self.standard = (self.res, self.spp, self.depth) == w[1:4]
+        self.integrator = "ao" if self.extra.get("method") == "ao" else "path"
+        self.overrides = gs.config_overrides(resolution=self.res, spp=self.spp, depth=self.depth, **self.extra)
+        self.scene = gs.load_scene(self.scene_name, self.overrides)
+        self.tracer = HipPathTracer(self.scene, device_index)
+        self.film = self.tracer.new_film()
+        # a call takes fewer than 2^32 camera samples (configs[4] at its 4096 spp has 1.7e10): such a frame is rendered in
+        # bands of 8-pixel tile rows, one call each, all of them inside the timed step
+        x0, x1, y0, y1 = self.tracer.window
+        rows = max(8, ((1 << 31) // max(1, (x1 - x0) * self.scene.spp())) // 8 * 8)
+        self.bands = [(x0, x1, y, min(y1, y + rows)) for y in range(y0, y1, rows)]
+        if len(self.bands) == 1:
+            self.bands = [None]
+
+    def render_frame(self, target=None, setting=None, **kw):
+        out = None
+        for w in self.bands:
+            r = self.tracer.render(film=target or self.film, window=w, setting=setting, **kw)
+            if out is None:
+                out = r
+            elif r["stats"]:
+                for k, v in r["stats"].items():
+                    if k not in ("schedule", "reserved"):   # (what the call ran under: not a counter)
+                        out["stats"][k] += v
+        return out
+
+    def describe(self):
+        wpx = (self.tracer.window[1] - self.tracer.window[0], self.tracer.window[3] - self.tracer.window[2])
+        return "%s -- %dx%d film (%dx%d sampled px), %d spp, %s, gaussian r=2" % (
+            self.text, self.res[0], self.res[1], wpx[0], wpx[1], self.scene.spp(),
+            "%d occlusion rays per camera sample" % self.extra["ao_samples"] if self.integrator == "ao" else "max_ray_depth %d" % self.depth)
+
+    def kernel_label(self, resolved):
+        if resolved == "wavefront":
+            return "wf_trace / wf_shade (all wavefront kernels of a step)"
+        return ("ao_kernel" if self.integrator == "ao" else "path_trace_kernel") + "<native sampler, lean, quad-per-ray queries>"
 
 
 def run_steps(render, zero_film, allreduce, barrier, sync, steps, warmup, world, make_event=None):
@@ -257,6 +380,61 @@ def run_steps(render, zero_film, allreduce, barrier, sync, steps, warmup, world,
     return elapsed, per_step
 
 
+def counters_of(wl, seed, shard, schedule, scale_from_spp=None):
+    """Node / triangle / ray counters of one step (an instrumented launch of the same deterministic work).  A frame whose
+    instrumented launch would take tens of seconds is counted at `scale_from_spp` samples per pixel and scaled: the sampler is
+    stratified per pixel, so the per-path averages of a lower spp are the frame's to well under a per cent."""
+    from goblin_amd import _abi
+    if scale_from_spp and scale_from_spp < wl.scene.spp():
+        s = _abi.gbl_render_setting.from_buffer_copy(wl.scene.desc.setting)
+        s.sample_per_pixel = scale_from_spp
+        x0, x1, y0, y1 = wl.tracer.window
+        st = wl.tracer.render(film=wl.tracer.new_film(), setting=s, seed=seed, shard=shard, stats=True, schedule=schedule)["stats"]
+        k = wl.scene.spp() / float(scale_from_spp)
+        out = {key: (int(round(v * k)) if key not in ("schedule", "reserved", "kernel_ms") else v) for key, v in st.items()}
+        out["_scaled_from_spp"] = scale_from_spp
+        return out
+    return wl.render_frame(seed=seed, shard=shard, stats=True, schedule=schedule)["stats"]
+
+
+def one_config(name, device_index, seed, torch):
+    """One full-size step of another BASELINE configuration (N = 1, after the headline's timed region): device time, rates,
+    the schedule AUTO resolved to, counters and SURVEY 8(d)'s fraction."""
+    from goblin_amd import _abi
+    wl = Workload(name, device_index)
+    # warm-up (allocates the radiance buffer / the wavefront pool): a full step where that is a few seconds, 16 spp for the
+    # AO frame (25 s at its 4096 spp)
+    if wl.integrator == "ao":
+        s = _abi.gbl_render_setting.from_buffer_copy(wl.scene.desc.setting)
+        s.sample_per_pixel = 16
+        wl.tracer.render(film=wl.film, setting=s, seed=seed)
+    else:
+        wl.render_frame(seed=seed)
+    torch.cuda.synchronize()
+    wl.film.zero_()
+    t0 = time.perf_counter()
+    full = wl.render_frame(seed=seed, timed=True)   # (timed: the library also reports the schedule AUTO resolved this call to)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    resolved = {1: "megakernel", 2: "wavefront"}.get(full["stats"]["schedule"], "megakernel")
+    timings = wl.tracer.timings(len(wl.bands))
+    kernel_ms = sum(x[0] for x in timings) if timings else ms
+    counted = counters_of(wl, seed, None, resolved, scale_from_spp=64 if wl.scene.spp() > 256 else None)
+    paths = counted["paths"]
+    rays = counted["extension_rays"] + counted["shadow_rays"]
+    pmc, note = pmc_for(name, resolved, wl.integrator)
+    roof = roofline_object({k: v for k, v in counted.items() if not k.startswith("_")}, kernel_ms, pmc, note, wl.kernel_label(resolved),
+                           waves_per_simd=5 if resolved == "wavefront" else 3)
+    out = {"workload": wl.describe(), "schedule": resolved, "steps": 1, "ms_per_step": round(ms, 2), "kernel_ms": round(kernel_ms, 2),
+           "paths_per_step": int(paths), "value": round(paths / ms * 1e-3, 2), "unit": "Mpaths/s",
+           "rays_per_path": round(rays / max(1, paths), 3), "grays_per_s": round(rays / ms * 1e-6, 3), "roofline": roof}
+    if "_scaled_from_spp" in counted:
+        out["counters_note"] = "counted by an instrumented launch at %d spp and scaled to the frame's %d" % (counted["_scaled_from_spp"], wl.scene.spp())
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,15 +446,13 @@ def main():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / l2 legs")
-    ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel", "wavepool"], default="auto")
+    ap.add_argument("--no-others", action="store_true", help="skip the full-size steps of the other BASELINE configurations")
+    ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel"], default="auto")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from goblin_amd import distributed as gd
-    from goblin_amd import scene as gs
-    from goblin_amd import _abi
-    from goblin_amd.renderer import HipPathTracer
 
     rank, local_rank, world = gd.init()
     if world != args.gpus:
@@ -291,54 +467,28 @@ def main():
     torch.cuda.set_device(device_index)
 
     wl_name = args.workload or ("bunny" if world == 1 else "grid")
-    scene_name, res, spp, depth, wl_text = WORKLOADS[wl_name][:5]
-    wl_extra = WORKLOADS[wl_name][5] if len(WORKLOADS[wl_name]) > 5 else {}
-    res = tuple(args.resolution) if args.resolution else res
-    spp = args.spp or spp
-    depth = args.depth or depth
-    standard = (res, spp, depth) == WORKLOADS[wl_name][1:4]
+    wl = Workload(wl_name, device_index, args.resolution, args.spp, args.depth)
+    tracer, film, scene = wl.tracer, wl.film, wl.scene
     scaling = args.scaling or ("strong" if world > 1 else "weak")
-    overrides = gs.config_overrides(resolution=res, spp=spp, depth=depth, **wl_extra)
-    scene = gs.load_scene(scene_name, overrides)
-    tracer = HipPathTracer(scene, device_index)
-    film = tracer.new_film()
     base_seed = 20261003
     part = gd.shard_for(rank, world, "samples" if scaling == "weak" else "tiles", base_seed)
 
-    # a call takes fewer than 2^32 camera samples (configs[4] at its 4096 spp has 1.7e10): such a frame is rendered in
-    # bands of 8-pixel tile rows, one call each, all of them inside the timed step
-    x0, x1, y0, y1 = tracer.window
-    rows_per_band = max(8, ((1 << 31) // max(1, (x1 - x0) * scene.spp())) // 8 * 8)
-    bands = [(x0, x1, y, min(y1, y + rows_per_band)) for y in range(y0, y1, rows_per_band)]
-    if len(bands) == 1:
-        bands = [None]
-
-    def render_frame(target, **kw):
-        out = None
-        for w in bands:
-            r = tracer.render(film=target, window=w, **kw)
-            if out is None:
-                out = r
-            elif r["stats"]:
-                for k, v in r["stats"].items():
-                    if k not in ("schedule", "reserved"):   # (what the call ran under: not a counter)
-                        out["stats"][k] += v
-        return out
-
     # counters for the roofline (one instrumented launch, outside the timed region;
     # the sampler is counter-based so every timed launch does exactly this work)
-    counted = render_frame(film, seed=part["seed"], shard=part["shard"], stats=True, schedule=args.schedule)["stats"]
+    counted = counters_of(wl, part["seed"], part["shard"], args.schedule,
+                          scale_from_spp=64 if (scene.spp() > 256 and wl.standard) else None)
+    counted_note = counted.pop("_scaled_from_spp", None)
     my_paths = counted["paths"]
 
     one_gpu_ms = None
     if world > 1 and rank == 0 and scaling == "strong":
         # the WHOLE frame on one GPU, outside the timed region: the N-GPU line then carries its own strong-scaling baseline
         whole = tracer.new_film()
-        render_frame(whole, seed=base_seed, schedule=args.schedule)
+        wl.render_frame(whole, seed=base_seed, schedule=args.schedule)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         whole.zero_()
-        render_frame(whole, seed=base_seed, schedule=args.schedule)
+        wl.render_frame(whole, seed=base_seed, schedule=args.schedule)
         torch.cuda.synchronize()
         one_gpu_ms = (time.perf_counter() - t1) * 1e3
         del whole
@@ -347,74 +497,46 @@ def main():
         gd.allreduce_film(torch.zeros(16, device=tracer.device))
         gd.barrier()
     elapsed, per_step = run_steps(
-        render=lambda: render_frame(film, seed=part["seed"], shard=part["shard"], schedule=args.schedule),
+        render=lambda: wl.render_frame(seed=part["seed"], shard=part["shard"], schedule=args.schedule),
         zero_film=film.zero_, allreduce=lambda: gd.allreduce_film(film.accum), barrier=gd.barrier, sync=torch.cuda.synchronize,
         steps=args.steps, warmup=args.warmup, world=world, make_event=lambda: torch.cuda.Event(enable_timing=True))
+    my_elapsed = elapsed
+    call_ms = [a for a, _ in per_step]          # device events around gbl_render (the launch stream)
+    reduce_ms = [b for _, b in per_step]
+    my_trace_ms = sum(call_ms) / len(call_ms)
 
     red_dev = tracer.device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     paths = torch.tensor([float(my_paths)], dtype=torch.float64, device=red_dev)
+    per_rank = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(paths, op=dist.ReduceOp.SUM)
+        # per rank: device time of the trace, of the reduce, paths traced and the schedule the library resolved AUTO to
+        mine = torch.tensor([my_trace_ms, sum(reduce_ms) / len(reduce_ms), float(my_paths), float(counted.get("schedule", 0)), my_elapsed * 1e3 / args.steps],
+                            dtype=torch.float64, device=red_dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [g.cpu().tolist() for g in gathered]
     elapsed = float(t.item())
     job_paths = float(paths.item())   # paths all ranks traced in one step
 
     # what AUTO resolved to: the library reports the schedule a call ran under (gbl_stats.schedule)
-    resolved = args.schedule if args.schedule != "auto" else {1: "megakernel", 2: "wavefront", 3: "wavepool"}.get(counted.get("schedule"), "megakernel")
+    resolved = args.schedule if args.schedule != "auto" else {1: "megakernel", 2: "wavefront"}.get(counted.get("schedule"), "megakernel")
     if rank == 0:
-        call_ms = [a for a, _ in per_step]                                    # device events around gbl_render (the launch stream)
-        reduce_ms = [b for _, b in per_step]
-        timings = tracer.timings(args.steps * len(bands))                      # HIP events inside the library, per kernel class and call
+        timings = tracer.timings(args.steps * len(wl.bands))                      # HIP events inside the library, per kernel class and call
         main_ms = [x[0] for x in timings] or call_ms
         avg_kernel_ms = sum(main_ms) / args.steps if timings else sum(main_ms) / len(main_ms)   # per step (a step is len(bands) calls)
-        alg_bytes = algorithmic_bytes(counted)
-        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        kernel_tag = {"megakernel": "path_trace_kernel<false, ...>", "wavepool": "wp_kernel<false, false, false>",
-                      "wavefront": "wf_trace<false, false, false, false, false>"}[resolved]
-        if wl_extra.get("method") == "ao":
-            kernel_tag = "ao_kernel<false, false, false, false>"
-        pmc, pmc_note = (pmc_for(kernel_tag, wl_name, resolved) if (standard and world == 1) else (None, "non-standard run: no counters quoted"))
+        pmc, pmc_note = (pmc_for(wl_name, resolved, wl.integrator) if (wl.standard and world == 1) else (None, "non-standard run: no counters quoted"))
         rays = counted["extension_rays"] + counted["shadow_rays"]
         value = job_paths * args.steps / elapsed * 1e-6
-        window_px = (tracer.window[1] - tracer.window[0], tracer.window[3] - tracer.window[2])
-        hbm = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-               "frac": round(achieved / HBM_PEAK_GBPS, 4),
-               "algorithmic_bytes_per_launch": int(alg_bytes),
-               "survey_8d_literal": {"bytes_per_launch": int(survey_literal_bytes(counted)),
-                                     "frac": round(survey_literal_bytes(counted) / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-               "note": "algorithmic bytes (64 B per 4-wide node visited, 48 B per triangle, 48 B per ray, 4 B per sample "
-                       "dimension, 16 B per path) over the kernel's measured time: a cache-served figure -- the scene is "
-                       "L2-resident, `traffic` below is what reaches HBM"}
-        roofline = dict(hbm)
-        if pmc and pmc.get("SQ_INSTS_VALU") and pmc.get("GRBM_GUI_ACTIVE"):
-            # the kernel is VALU-issue bound: its instruction stream over what the 1024 SIMDs can issue in the measured time.
-            # Instruction count from the stamped PMC pass of this very build; time and clock measured here / there.
-            clock_hz = pmc["GRBM_GUI_ACTIVE"] / 8.0 / (pmc["kernel_avg_ms"] * 1e-3)
-            peak = SIMDS * clock_hz / VALU_CYCLES_PER_WAVE_INSTRUCTION * 1e-9
-            ach = pmc["SQ_INSTS_VALU"] / (avg_kernel_ms * 1e-3) * 1e-9
-            traffic = int((2 * pmc.get("FETCH_SIZE", 0.0) + pmc.get("WRITE_SIZE", 0.0)) * 1024) if "FETCH_SIZE" in pmc else None
-            roofline = {"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
-                        "frac": round(ach / peak, 4), "traffic": traffic,
-                        "valu_wave_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]),
-                        "valu_busy_pmc": round(pmc["SQ_ACTIVE_INST_VALU"] * 4 / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS), 4) if "SQ_ACTIVE_INST_VALU" in pmc else None,
-                        "clock_ghz_pmc": round(clock_hz * 1e-9, 3),
-                        "l2_hit_rate": round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in pmc else None,
-                        "pmc": {"file": pmc["file"], "source_stamp": pmc["source_stamp"], "kernel": pmc["kernel"],
-                                "kernel_avg_ms_rocprof": pmc["kernel_avg_ms"]},
-                        "hbm": dict(hbm, traffic=traffic, traffic_gbps=round(traffic / (avg_kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
-                        "note": "peak = 1024 SIMDs x clock / 4 cycles per wave64 VALU instruction; frac = the share of the "
-                                "SIMDs' issue slots the kernel's own instruction stream fills -- high means issue bound, and "
-                                "the headroom is in the lanes (see DESIGN.md 4.1: lane utilisation), not in this fraction"}
-        else:
-            roofline["traffic"] = None
-            roofline["pmc_note"] = pmc_note
-        roofline.update({"kernel": kernel_tag if resolved != "wavefront" else "wf_trace / wf_shade (all wavefront kernels of a step)",
-                         "kernel_ms_avg": round(avg_kernel_ms, 3), "call_ms_avg": round(sum(call_ms) / len(call_ms), 3),
-                         "counters": {k: int(v) for k, v in counted.items() if k != "kernel_ms"}})
+        roofline = roofline_object(counted, avg_kernel_ms, pmc, pmc_note, wl.kernel_label(resolved), waves_per_simd=5 if resolved == "wavefront" else 3)
+        roofline["call_ms_avg"] = round(sum(call_ms) / len(call_ms), 3)
+        if counted_note:
+            roofline["counters_note"] = "counted by an instrumented launch at %d spp and scaled to the frame's %d" % (counted_note, scene.spp())
         line = {
-            "metric": "Mpaths/sec at 512x512x256spp (GoblinPathtracer hot path, bunny.json, max_ray_depth 8)" if wl_name == "bunny" and standard
-                      else "Mpaths/sec at %dx%dx%dspp (GoblinPathtracer hot path, %s.json, max_ray_depth %d)" % (res[0], res[1], scene.spp(), scene_name, depth),
+            "metric": "Mpaths/sec at 512x512x256spp (GoblinPathtracer hot path, bunny.json, max_ray_depth 8)" if wl_name == "bunny" and wl.standard
+                      else "Mpaths/sec at %dx%dx%dspp (GoblinPathtracer hot path, %s.json, max_ray_depth %d)" % (wl.res[0], wl.res[1], scene.spp(), wl.scene_name, wl.depth),
             "value": round(value, 3),
             "unit": "Mpaths/s",
             "n_gpus": world,
@@ -427,8 +549,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s -- %dx%d film (%dx%d sampled px), %d spp, max_ray_depth %d, gaussian r=2" % (
-                    wl_text, res[0], res[1], window_px[0], window_px[1], scene.spp(), depth),
+                "workload": wl.describe(),
                 "schedule": resolved,
                 "paths_per_step": int(job_paths),
                 "rays_per_path": round(rays / max(1, my_paths), 3),
@@ -441,14 +562,46 @@ def main():
             "roofline": roofline,
         }
         if world > 1:
+            try:
+                import torch.cuda.nccl as tnccl
+                rccl_version = ".".join(str(v) for v in tnccl.version()) if dist.get_backend() == "nccl" else None
+            except Exception:
+                rccl_version = None
+            tr = [p[0] for p in per_rank]
             line["collective"] = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (CPU rehearsal)"),
+                                  "rccl_version": rccl_version,
                                   "ranks": dist.get_world_size(), "op": "all_reduce(sum) of the film accumulators",
                                   "bytes": int(film.accum.numel() * 4),
-                                  "ms_avg": round(sum(reduce_ms) / len(reduce_ms), 3), "trace_ms_avg": round(sum(call_ms) / len(call_ms), 3)}
+                                  "ms_avg": round(sum(reduce_ms) / len(reduce_ms), 3), "trace_ms_avg": round(sum(call_ms) / len(call_ms), 3),
+                                  "note": "ms_avg is rank 0's device time between the end of its trace and the end of the all-reduce: it "
+                                          "includes waiting for the slowest rank's trace (per_rank below tells the two apart)"}
+            line["per_rank"] = {"trace_ms": [round(x, 3) for x in tr], "trace_ms_min": round(min(tr), 3), "trace_ms_max": round(max(tr), 3),
+                                "trace_imbalance": round(max(tr) / max(1e-9, min(tr)) - 1.0, 4),
+                                "reduce_ms": [round(p[1], 3) for p in per_rank], "paths": [int(p[2]) for p in per_rank],
+                                "schedule": [{1: "megakernel", 2: "wavefront"}.get(int(p[3]), "?") for p in per_rank],
+                                "step_ms": [round(p[4], 3) for p in per_rank]}
             if one_gpu_ms is not None:
                 line["config"]["one_gpu_same_workload"] = {"ms_per_step": round(one_gpu_ms, 3), "mpaths_per_s": round(job_paths / one_gpu_ms * 1e-3, 2),
                                                            "speedup": round(one_gpu_ms / (elapsed / args.steps * 1e3), 3),
                                                            "note": "rank 0 alone, whole frame, outside the timed region"}
+        if world == 1 and wl.standard and resolved == "megakernel":
+            # the same steps with the reference's exact-t tie rule kept in the lean kernel (gbl_render_params.exact_ties): what the
+            # headline would post if it resolved the ~5 ties per 10^7 paths as the replay / stream kernels do
+            try:
+                for _ in range(1):
+                    wl.render_frame(seed=part["seed"], schedule=args.schedule, exact_ties=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_tie = 3
+                for _ in range(n_tie):
+                    film.zero_()
+                    wl.render_frame(seed=part["seed"], schedule=args.schedule, exact_ties=True)
+                torch.cuda.synchronize()
+                tie_ms = (time.perf_counter() - t1) * 1e3 / n_tie
+                line["value_tie_exact"] = {"value": round(my_paths / tie_ms * 1e-3, 3), "unit": "Mpaths/s", "ms_per_step": round(tie_ms, 3), "steps": n_tie,
+                                           "note": "gbl_render_params.exact_ties = 1: the lean kernel with trace.h's TIES rule compiled in"}
+            except Exception as e:
+                print("value_tie_exact leg failed: %s" % e, file=sys.stderr)
         if world == 1 and wl_name == "bunny":
             # the same frame with the reference's own mt19937 sample stream generated on the device (GBL_SAMPLES_STREAM):
             # its Film is the reference binary's; reported beside the headline, never as `value`
@@ -467,13 +620,22 @@ def main():
                 del sfilm
             except Exception as e:
                 print("reference_stream_sampler leg failed: %s" % e, file=sys.stderr)
+        if world == 1 and wl_name == "bunny" and wl.standard and not args.no_others:
+            # every other BASELINE configuration, one full-size step each, outside the headline's timed region
+            line["other_configs"] = {}
+            for other in ("cornell", "grid", "ao"):
+                try:
+                    line["other_configs"][other] = one_config(other, device_index, base_seed, torch)
+                except Exception as e:
+                    line["other_configs"][other] = {"error": str(e)}
+                    print("other_configs[%s] failed: %s" % (other, e), file=sys.stderr)
         if world == 1 and wl_name == "bunny" and not args.no_cpu:
             # every host core this process may run on (the reference defaults to hardware_concurrency, GoblinThreadPool.cpp:5-10)
             cores = max(1, len(os.sched_getaffinity(0)))
             # the CPU leg renders the FULL workload when the box has the cores to do it in ~15-30 s (68 M paths at
             # ~0.3 Mpaths/s per thread), so that its Film can be compared at BASELINE's own size; fewer samples otherwise
-            cpu_spp = spp if cores >= 12 else (64 if cores >= 4 else 16)
-            line["cpu_baseline"] = cpu_baseline(overrides, cpu_spp, cores)
+            cpu_spp = wl.spp if cores >= 12 else (64 if cores >= 4 else 16)
+            line["cpu_baseline"] = cpu_baseline(wl.overrides, cpu_spp, cores)
             if line["cpu_baseline"]:
                 line["cpu_baseline"]["host"] = {"os_cpu_count": os.cpu_count(), "affinity": cores}
             ref_film = line["cpu_baseline"].pop("_film", None) if line["cpu_baseline"] else None
@@ -483,7 +645,7 @@ def main():
                 except Exception as e:
                     print("l2_vs_reference failed: %s" % e, file=sys.stderr)
             try:
-                line["l2_vs_cpu"] = l2_vs_cpu(tracer, overrides, 16, min(cores, 32), base_seed)
+                line["l2_vs_cpu"] = l2_vs_cpu(tracer, wl.overrides, 16, min(cores, 32), base_seed)
             except Exception as e:
                 print("l2_vs_cpu failed: %s" % e, file=sys.stderr)
             if line["cpu_baseline"]:

@@ -127,7 +127,7 @@ class gbl_render_params(C.Structure):
                 ("tile_shard_index", C.c_int32), ("tile_shard_count", C.c_int32),
                 ("sample_mode", C.c_uint32), ("seed", C.c_uint64), ("replay_samples", C.c_void_p),
                 ("li_out", C.c_void_p), ("russian_roulette", C.c_uint32), ("collect_stats", C.c_uint32),
-                ("schedule", C.c_uint32), ("stream", C.c_void_p)]
+                ("schedule", C.c_uint32), ("exact_ties", C.c_uint32), ("stream", C.c_void_p)]
 
 
 class gbl_stats(C.Structure):

@@ -276,7 +276,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     const bool ext = sc.extended != 0;
     const bool masks = sc.has_masks != 0;
     // native sampler, lean build: no tie rule (trace.h)
-    const bool lean_native = !masks && !want_stats && !replay;
+    const bool lean_native = !masks && !want_stats && !replay && p->exact_ties == 0;
     gbl_wf_kernel k_ext = gbl_kernel_wf_trace(false, want_stats, ext || masks || want_stats, masks, !lean_native);
     gbl_wf_kernel k_shd = gbl_kernel_wf_trace(true, want_stats, ext || masks || want_stats, masks, true);
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
@@ -1118,8 +1118,8 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         if (!stream_mode && defer) {
             const size_t lds_quad = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
             gbl_render_kernel k_quad = nullptr;
-            if (p->integrator == GBL_INTEGRATOR_AO && !ext && !want_stats && quad_wanted(false)) k_quad = gbl_kernel_ao_quad(replay);
-            if (p->integrator == GBL_INTEGRATOR_PATH && quad_wanted(ext || want_stats)) k_quad = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
+            if (p->integrator == GBL_INTEGRATOR_AO && !ext && !want_stats && quad_wanted(false)) k_quad = gbl_kernel_ao_quad(replay, p->exact_ties != 0);
+            if (p->integrator == GBL_INTEGRATOR_PATH && quad_wanted(ext || want_stats)) k_quad = gbl_kernel_path_quad(replay, want_stats, ext || want_stats, p->exact_ties != 0);
             if (k_quad && lds_quad <= 160 * 1024) {
                 kernel = k_quad;
                 lds = lds_quad;

@@ -83,8 +83,8 @@ typedef void (*gbl_li_kernel)(DevScene, RenderArgs, float4*);
 gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext);
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext);
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
-gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext);
-gbl_render_kernel gbl_kernel_ao_quad(bool replay);
+gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext, bool exact_ties = false);
+gbl_render_kernel gbl_kernel_ao_quad(bool replay, bool exact_ties = false);
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);

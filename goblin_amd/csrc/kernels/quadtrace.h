@@ -129,15 +129,19 @@ __device__ __forceinline__ void quad_interior(TravState& st, const QuadLane& ql,
 // mint <= t <= maxt and shrinks maxt to t, so the nearest accepted triangle stays and, among equal distances, the one
 // tested last -- is the minimum over the quad with ties going to the higher lane.  (Used where the reference's tie rule is
 // compiled out, GBL `TIES` = false, and for any-hit queries; a NaN distance, which the loop would accept, loses here.)
-template <bool ANY, bool STATS>
+// TIES (closest-hit queries of the builds that follow the reference's tie rule): the rule only ever matters when two accepted
+// distances are EXACTLY equal -- two lanes of the quad, or a lane and the hit the ray already holds in this instance -- or
+// when a distance is NaN (which trav_other's loop accepts).  Those leaves (a handful per 10^7 paths) are left untouched and
+// *redo is set: the caller runs trav_other's own loop on them; every other leaf gives what that loop would.
+template <bool ANY, bool STATS, bool TIES = false>
 __device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded, uint4 w0, uint4 w1, uint4 w2,
-                                          uint32_t popped) {
+                                          uint32_t popped, bool* redo = nullptr) {
     const uint32_t ref = ~static_cast<uint32_t>(st.cur);
     const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
     float t = INFINITY, b1 = 0.0f, b2 = 0.0f;
     bool ok = false;
+    if (STATS && ql.c == 0u) cnt.tris += count;   // (the other lanes' counters are put back after the quad phase)
     if (ql.c < count) {
-        if (STATS) cnt.tris += 1;
         float4 q0 = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), 0.0f);
         float4 q1 = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), 0.0f);
         float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), 0.0f);
@@ -147,6 +151,19 @@ __device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, Lan
     const float tq = ok ? t : INFINITY;
     float m = fminf(tq, quad_dpp_f<GBL_QP_XOR1>(tq));
     m = fminf(m, quad_dpp_f<GBL_QP_XOR2>(m));
+    if (TIES && !ANY) {
+        // a NaN distance passes tri_test_regs' range check as it passes the loop's: mark the lane (fminf drops the NaN)
+        uint32_t odd = (ok && t != t) ? 1u : 0u;
+        odd |= quad_dpp<GBL_QP_XOR1>(odd);
+        odd |= quad_dpp<GBL_QP_XOR2>(odd);
+        uint32_t wm = (ok && tq == m) ? ql.bitc : 0u;
+        wm |= quad_dpp<GBL_QP_XOR1>(wm);
+        wm |= quad_dpp<GBL_QP_XOR2>(wm);
+        if (odd != 0u || (m < INFINITY && ((wm & (wm - 1u)) != 0u || (m == st.hit.t && st.hit.inst == st.inst)))) {
+            *redo = true;
+            return false;
+        }
+    }
     if (m < INFINITY) {   // (the same in the quad's four lanes)
         if (ANY) {
             *occluded = true;
@@ -355,6 +372,9 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
 #endif
         uint32_t keep_tris = cnt.tris, keep_ol = cnt.oth_lane, keep_ow = cnt.oth_wave;
         int sel_inst = -2;   // the instance space the v_perm selectors were made for
+        // one triangle per lane at a leaf (quad_leaf); the instrumented builds' any-hit queries keep trav_other's loop, whose
+        // early exit is what their triangle counter counts
+        constexpr bool QUAD_LEAVES = !(ANY && STATS);
         while (!qdone) {
 #ifdef GBL_PHASE_CLOCK
             cnt.pc[10] += 1;
@@ -377,19 +397,23 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 }
                 quad_interior<!ANY, STATS>(st, ql, cnt, w0, w1, w2, w3, popped);
                 if (STATS) ++qsteps;
-            } else if ((ANY ? !STATS : !TIES) && st.cur < 0 && st.inst >= 0 &&
-                       (!EXT || (~static_cast<uint32_t>(st.cur) >> 2) < GBL_SHAPE_FIRST_DISK)) {
+            } else if (QUAD_LEAVES && st.cur < 0 && st.inst >= 0 && (!EXT || (~static_cast<uint32_t>(st.cur) >> 2) < GBL_SHAPE_FIRST_DISK)) {
                 const uint32_t lref = ~static_cast<uint32_t>(st.cur);
                 const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + (lref >> 2) + min(ql.c, lref & 3u));
                 const uint4 w0 = tp[0], w1 = tp[1], w2 = tp[2];
                 const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
-                qdone = quad_leaf<ANY, STATS>(st, ql, cnt, &qocc, w0, w1, w2, popped);
+                bool redo = false;
+                qdone = quad_leaf<ANY, STATS, TIES>(st, ql, cnt, &qocc, w0, w1, w2, popped, &redo);
+                if (TIES && !ANY && redo) {   // an exact tie in this leaf: the reference's rule, in trav_other's own loop
+                    if (STATS && ql.c == 0u) cnt.tris -= (lref & 3u) + 1u;
+                    qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, qstk, cnt, &qocc, filter);
+                }
             } else if (st.cur == GBL_STACK_SENTINEL || (st.cur < 0 && st.inst < 0)) {
                 quad_transition<STATS, EXT>(sc, st, qstk, qrec, cnt, filter);
-            } else if (!EXT && (ANY ? !STATS : !TIES)) {   // lean builds: all that is left is the exit marker
+            } else if (!EXT && QUAD_LEAVES) {   // lean builds: all that is left is the exit marker
                 qdone = true;
                 (void)qstk;
-            } else {   // the exit marker; analytic shapes; leaves under the reference's tie rule
+            } else {   // the exit marker; analytic shapes; any-hit leaves of the instrumented builds
                 qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES>(sc, st, qstk, cnt, &qocc, filter);
             }
 #ifdef GBL_PHASE_CLOCK

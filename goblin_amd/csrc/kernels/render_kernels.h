@@ -420,11 +420,13 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 #define GBL_SRC_NATIVE 0
 #define GBL_SRC_REPLAY 1
 #define GBL_SRC_STREAM 2
-template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false>
+// EXACT: the native sampler's lean kernels compile the reference's exact-t tie rule out (trace.h TIES: +2 ... 3 % on the BASELINE
+// scenes for the ~5 ties per 10^7 paths it decides); gbl_render_params.exact_ties selects the instantiations that keep it.
+template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
-    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM;
+    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM, TIES = REPLAY || STATS || EXACT;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
@@ -569,14 +571,14 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             bool got = false;
             if constexpr (QUAD) {
                 const bool want = active && sc.num_lights != 0;
-                got = trace_quad<false, STATS, EXT, REPLAY || STATS>(sc, want, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
+                got = trace_quad<false, STATS, EXT, TIES>(sc, want, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
                 if (active && !want) finished = true;
                 if (STATS && want) cnt.ext += 1;
             } else if (active) {
                 if (sc.num_lights == 0) {
                     finished = true;   // PathTracer::Li returns Black without lights (:53-56)
                 } else {
-                    got = trace<false, STATS, EXT, REPLAY || STATS>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
+                    got = trace<false, STATS, EXT, TIES>(sc, ps.o, ps.d, ps.mint, INFINITY, stk, hit, cnt);
                     if (STATS) cnt.ext += 1;
                 }
             }
@@ -804,10 +806,11 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                             ps.Li = f3(ps.Li.x + add.x, ps.Li.y + add.y, ps.Li.z + add.z);
                             finished = true;
                         } else {
-                            // survivors carry 1/q on what depends on the extension ray -- the BSDF-sampled light term and
-                            // the next throughput, both proportional to cosw -- NOT on this vertex's light-sampled term,
-                            // which is collected whether or not the path survives
-                            ps.cosw = ps.cosw * (1.0f / q);
+                            // survivors carry 1/q on what depends on the extension ray -- the BSDF-sampled light term, the
+                            // environment term of an escaping ray and the next throughput, all proportional to f -- NOT on this
+                            // vertex's light-sampled term, which is collected whether or not the path survives
+                            // (restated in oracle/goblin_oracle.cpp russian_roulette: checked sample by sample)
+                            ps.f = ps.f * (1.0f / q);
                         }
                     }
                 } else {
@@ -876,9 +879,9 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 // ---------------------------------------------------------------------------
 // QUAD: the camera ray and the occlusion rays run as wave-wide queries whose last <= 16 rays migrate to quads of lanes
 // (kernels/quadtrace.h); per-sample radiance only (ra.li_defer), LDS = quads' records | ctrl | stacks.
-template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false>
+template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = false>
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void ao_kernel(DevScene sc, RenderArgs ra) {
-    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM;
+    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM, TIES = REPLAY || STATS || EXACT;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     camera_ray<EXT>(sc.camera, image_x, image_y, 0.0f, 0.0f, &o, &d, &cam_mint);
                 }
                 Hit hit;
-                const bool got = trace_quad<false, STATS, EXT, REPLAY || STATS>(sc, valid, o, d, cam_mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
+                const bool got = trace_quad<false, STATS, EXT, TIES>(sc, valid, o, d, cam_mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
                 const bool want = valid && got;
                 Frag fr;
                 fr.p = f3(0, 0, 0);
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             camera_ray<EXT>(sc.camera, image_x, image_y, lens_u1, lens_u2, &o, &d, &cam_mint);
             Hit hit;
             F3 L = f3(0, 0, 0);
-            bool got = trace<false, STATS, EXT, REPLAY || STATS>(sc, o, d, cam_mint, INFINITY, stk, hit, cnt);   // lean native build: no tie rule (trace.h)
+            bool got = trace<false, STATS, EXT, TIES>(sc, o, d, cam_mint, INFINITY, stk, hit, cnt);   // lean native build: no tie rule (trace.h)
             if (STATS) {
                 cnt.ext += 1;
                 cnt.dims += 2;

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             float q = fminf(0.95f, fmaxf(tn.x, fmaxf(tn.y, tn.z)));
             float u = nat_u01(nat_mix(nat_mix(src.pixel_key, 0xBADC0DEu + ps.bounce), src.k));
             if (!(u < q)) rr_killed = true;
-            else rr_inv = 1.0f / q;   // carried by cosw, see the megakernel
+            else rr_inv = 1.0f / q;   // carried by f, see the megakernel
         }
         if (EXT && null_sampled && !is_black(f) && pdf > 0.0f) {
         } else if (!rr_killed && !is_black(f) && pdf > 0.0f) {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             ps.fw = fw;
             ps.bsdf_pdf = pdf;
             ps.cosw = absdot(wi, fr.n);
-            if (ra.russian_roulette && !REPLAY && rr_inv != 1.0f) ps.cosw = ps.cosw * rr_inv;
+            if (ra.russian_roulette && !REPLAY && rr_inv != 1.0f) ps.f = ps.f * rr_inv;
             ps.o = fr.p;
             ps.d = wi;
             ps.mint = fr.eps;

@@ -107,7 +107,7 @@ class HipPathTracer:
         return Film(self.info.xres, self.info.yres, self.device)
 
     def _params(self, setting=None, window=None, seed=0, replay=None, li_out=None, stats=False, rr=False, shard=None,
-                schedule=0, sampler="native"):
+                schedule=0, sampler="native", exact_ties=False):
         s = setting or self.scene.desc.setting
         p = _abi.gbl_render_params()
         p.integrator = s.integrator
@@ -128,18 +128,20 @@ class HipPathTracer:
         p.russian_roulette = 1 if rr else 0
         p.collect_stats = 1 if stats else 0
         p.schedule = {"auto": 0, "megakernel": 1, "wavefront": 2}.get(schedule, schedule)
+        p.exact_ties = 1 if exact_ties else 0
         torch = _torch()
         p.stream = torch.cuda.current_stream(self.device).cuda_stream
         return p
 
     def render(self, film=None, setting=None, window=None, seed=0, replay_samples=None, want_li=False, stats=False,
-               timed=False, rr=False, shard=None, schedule="auto", sampler="native"):
+               timed=False, rr=False, shard=None, schedule="auto", sampler="native", exact_ties=False):
         """Accumulate one pass into ``film`` (created if None).
 
         replay_samples: (n, dims) float32 tensor/array of Sample records for the
         window, pixel-major (GBL_SAMPLES_REPLAY); otherwise the native sampler.
         sampler: "native" (counter-based law) or "stream" (the reference's own mt19937 stream, GBL_SAMPLES_STREAM).
         shard: (index, count) renders only every count-th 8x8 sample tile (multi-GPU).
+        exact_ties: native sampler on lean scenes -- keep the reference's exact-t tie rule (gbl_render_params.exact_ties).
         Returns dict(film=..., li=..., stats=...).
         """
         torch = _torch()
@@ -158,7 +160,7 @@ class HipPathTracer:
             if tuple(replay.shape) != (npaths, dims):
                 raise ValueError("replay_samples must have shape (%d, %d), got %s" % (npaths, dims, tuple(replay.shape)))
         li = torch.zeros((npaths, 4), dtype=torch.float32, device=self.device) if want_li else None
-        p = self._params(s, window, seed, replay, li, stats, rr, shard, schedule, sampler)
+        p = self._params(s, window, seed, replay, li, stats, rr, shard, schedule, sampler, exact_ties)
         st_out = _abi.gbl_stats() if (stats or timed) else None
         st = self.lib.gbl_render(self.handle, C.byref(p), film.accum.data_ptr(), C.byref(st_out) if st_out else None)
         if st != _abi.GBL_OK:

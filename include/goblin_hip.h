@@ -450,6 +450,9 @@ typedef struct gbl_render_params {
                                   GoblinPathtracer.cpp:76)                    */
     uint32_t collect_stats;    /* fill node/triangle counters (slower)        */
     uint32_t schedule;         /* gbl_schedule                                */
+    uint32_t exact_ties;       /* native sampler, lean scenes: resolve two triangles accepted at exactly the same t as the
+                                  reference's own BVH order does (replay / stream / instrumented renders always do); costs
+                                  2-3 % for the ~5 ties per 10^7 paths it decides, so it is off by default               */
     void* stream;              /* hipStream_t, NULL = default stream          */
 } gbl_render_params;
 

@@ -2410,7 +2410,27 @@ struct LiCtx {
     Counters cnt;
     uint64_t dims_used = 0;
     float primary_maxt = INF;   // the camera ray's maxt after Li: Ray::maxt is mutable and the first scene query clips it
+    // Russian roulette, the device's build-side extension (the reference's loop is fixed length, GoblinPathtracer.cpp:76):
+    // restated here only so that the device's kill draws and 1 / q factors can be checked sample by sample
+    // (goblin_amd/csrc/kernels/render_kernels.h, wavefront.h).  Native sampler only: the draw is keyed by the pixel and sample.
+    bool rr = false;
+    uint32_t rr_pixel_key = 0, rr_k = 0;
 };
+inline uint32_t nat_mix(uint32_t a, uint32_t b);
+inline float nat_u01(uint32_t h);
+// From the third bounce on a path survives with probability q = min(0.95, max component of the throughput its sampled
+// direction would carry on); a survivor's bsdf value f carries 1 / q into everything that depends on the extension ray (the
+// BSDF-sampled light term, the environment term of an escaping ray, the next throughput), the vertex's light-sampled term is
+// collected either way.  Returns false when the path is killed.
+inline bool russian_roulette(const LiCtx* c, int bounce, Col throughput, Col* f, float cosw, float bsdf_pdf) {
+    if (!c->rr || bounce < 2) return true;
+    const Col tn = throughput * ((*f) * cosw / bsdf_pdf);
+    const float q = fminf(0.95f, fmaxf(tn.r, fmaxf(tn.g, tn.b)));
+    const float u = nat_u01(nat_mix(nat_mix(c->rr_pixel_key, 0xBADC0DEu + static_cast<uint32_t>(bounce)), c->rr_k));
+    if (!(u < q)) return false;
+    *f = (*f) * (1.0f / q);
+    return true;
+}
 
 // BSDFSample(rng), GoblinMaterial.cpp:26-30 -- three draws whose values never
 // matter in a mask-free scene but which advance the tile's stream.
@@ -2780,6 +2800,10 @@ Col path_li(LiCtx* c, const Ray& primary, const float* rec, const RayDiff* prima
             if (!(sampled & BSDF_SPECULAR)) {
                 light_pdf_v = light_pdf(s, light, p, wi);
                 fw = power_heuristic(1, bsdf_pdf, 1, light_pdf_v);
+            }
+            if (!russian_roulette(c, bounce, throughput, &f, absdot(wi, n), bsdf_pdf)) {   // (extension; off in every parity mode)
+                Li += throughput * Ld / pick_pdf;
+                break;
             }
             Ray r;
             r.o = p; r.d = wi; r.mint = epsilon; r.maxt = INF;
@@ -3592,6 +3616,43 @@ int32_t orc_native_samples(const orc_scene* s, const gbl_render_setting* rs, uin
             uint32_t pixel = static_cast<uint32_t>((y - s->window[2]) * fw + (x - s->window[0]));
             for (int k = 0; k < ns.spp; ++k) ns.fill(q, pixel, x, y, k, out + (rec++) * dims);
         }
+    return 0;
+}
+
+// Li of the native sampler's records for a sub-window, pixel-major, with the device's Russian roulette extension on or off
+// (rr = 0 gives what orc_native_samples + orc_li_replay give).
+int32_t orc_li_native(const orc_scene* s, const gbl_render_setting* rs, uint64_t seed, const int32_t window[4], int32_t rr, float* li_out,
+                      int32_t threads) {
+    PtIndices ix;
+    Quota q = make_quota(*rs, &ix, s);
+    const uint32_t dims = q.dims();
+    NativeSampler ns(seed, rs->sample_per_pixel);
+    const int fw = s->window[1] - s->window[0], ww = window[1] - window[0];
+    const int64_t npix = static_cast<int64_t>(ww) * (window[3] - window[2]);
+    const int nt = std::max(1, threads);
+    std::vector<std::thread> pool;
+    auto work = [&](int tid) {
+        LiCtx c;
+        c.s = s; c.rs = rs; c.q = &q; c.ix = &ix; c.rng = nullptr; c.ref_faithful = 0;
+        c.rr = rr != 0;
+        std::vector<float> rec(dims);
+        for (int64_t pi = tid; pi < npix; pi += nt) {
+            const int x = window[0] + static_cast<int>(pi % ww), y = window[2] + static_cast<int>(pi / ww);
+            const uint32_t pixel = static_cast<uint32_t>((y - s->window[2]) * fw + (x - s->window[0]));
+            c.rr_pixel_key = nat_mix(ns.seed_key, pixel);
+            for (int k = 0; k < ns.spp; ++k) {
+                ns.fill(q, pixel, x, y, k, rec.data());
+                c.rr_k = static_cast<uint32_t>(k);
+                Col L = eval_li(&c, rec.data());
+                if (s->volume.on) L = task_sample(&c, rec.data(), L);
+                float* o = li_out + 4 * (pi * ns.spp + k);
+                o[0] = L.r; o[1] = L.g; o[2] = L.b; o[3] = L.a;
+            }
+        }
+    };
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
     return 0;
 }
 

@@ -64,6 +64,8 @@ def lib():
         L.orc_splat.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_native_samples.argtypes = [C.c_void_p, C.POINTER(_abi.gbl_render_setting), C.c_uint64,
                                          C.POINTER(C.c_int32), C.c_void_p]
+        L.orc_li_native.argtypes = [C.c_void_p, C.POINTER(_abi.gbl_render_setting), C.c_uint64, C.POINTER(C.c_int32), C.c_int32,
+                                    C.c_void_p, C.c_int32]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(_abi.gbl_render_setting), C.c_int32, C.c_int32, C.c_int32,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
                                  C.POINTER(orc_counters)]
@@ -171,6 +173,16 @@ class Oracle:
         out = np.zeros((n, self.dims(s)), np.float32)
         lib().orc_native_samples(self.h, C.byref(s), seed, (C.c_int32 * 4)(*w), _ptr(out))
         return out
+
+    def li_native(self, seed, rr=False, window=None, setting=None, threads=4):
+        """Li of the native sampler's records for a window, pixel-major (the device's li order); rr: with the device's Russian
+        roulette extension restated (same counter-based kill draw, same 1 / q placement)."""
+        s = setting or self.scene.desc.setting
+        w = window or self.window()
+        spp = int(np.ceil(np.sqrt(np.float32(s.sample_per_pixel)))) ** 2
+        li = np.zeros(((w[1] - w[0]) * (w[3] - w[2]) * spp, 4), np.float32)
+        lib().orc_li_native(self.h, C.byref(s), seed, (C.c_int32 * 4)(*w), 1 if rr else 0, _ptr(li), threads)
+        return li
 
     def render(self, setting=None, threads=1, ref_faithful=0, sampler=0, seed=0, want_samples=False):
         """The reference's whole render loop.  Returns dict(film, seconds, counters[, samples, li])."""
