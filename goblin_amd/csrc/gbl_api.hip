@@ -278,7 +278,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     // native sampler, lean build: no tie rule (trace.h)
     const bool lean_native = !masks && !want_stats && !replay && p->exact_ties == 0;
     gbl_wf_kernel k_ext = gbl_kernel_wf_trace(false, want_stats, ext || masks || want_stats, masks, !lean_native);
-    gbl_wf_kernel k_shd = gbl_kernel_wf_trace(true, want_stats, ext || masks || want_stats, masks, true);
+    gbl_wf_kernel k_shd = gbl_kernel_wf_trace(true, want_stats, ext || masks || want_stats, masks, !lean_native);
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a
     // workgroup that has to wait for a free CU would serialise its share), never more waves than regions
     int occ_ext = 0, occ_shd = 0;
@@ -1085,9 +1085,9 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             gbl_status sst = ensure_stream_buffers(ctx, stream_scratch_words(L, tail_words), grid64, npix * ra.spp, &ra);
             if (sst != GBL_OK) return sst;
         } else if (p->integrator == GBL_INTEGRATOR_PATH) {
-            kernel = gbl_kernel_path(replay, want_stats, ext || want_stats);
+            kernel = gbl_kernel_path(replay, want_stats, ext || want_stats, p->exact_ties != 0);
         } else {
-            kernel = gbl_kernel_ao(replay, want_stats, ext || want_stats);
+            kernel = gbl_kernel_ao(replay, want_stats, ext || want_stats, p->exact_ties != 0);
         }
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1114,12 +1114,16 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         }
         // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records take
         // the LDS film tile's place.  Its LDS need differs from the film-tile formula checked above: checked again here, and a
-        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.
+        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.  By default the lean kernels of the native
+        // sampler only: the builds that follow the reference's tie rule and reachability test (replay, exact_ties, instrumented)
+        // run one ray per lane, where ref_reached applies (trace.h); GBL_MK_QUAD=1 forces the quad kernels on them (tests).
         if (!stream_mode && defer) {
             const size_t lds_quad = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            const bool ties_build = replay || want_stats || p->exact_ties != 0;
             gbl_render_kernel k_quad = nullptr;
-            if (p->integrator == GBL_INTEGRATOR_AO && !ext && !want_stats && quad_wanted(false)) k_quad = gbl_kernel_ao_quad(replay, p->exact_ties != 0);
-            if (p->integrator == GBL_INTEGRATOR_PATH && quad_wanted(ext || want_stats)) k_quad = gbl_kernel_path_quad(replay, want_stats, ext || want_stats, p->exact_ties != 0);
+            if (p->integrator == GBL_INTEGRATOR_AO && !ext && !want_stats && quad_wanted(ties_build)) k_quad = gbl_kernel_ao_quad(replay);
+            if (p->integrator == GBL_INTEGRATOR_PATH && quad_wanted(ext || ties_build)) k_quad = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
+            if (p->exact_ties != 0 && !replay && !want_stats) k_quad = nullptr;   // (exact_ties has one-ray-per-lane instantiations only)
             if (k_quad && lds_quad <= 160 * 1024) {
                 kernel = k_quad;
                 lds = lds_quad;

@@ -745,7 +745,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             if constexpr (QUAD) {
                 if (__ballot(need_shadow) != 0ull) {
                     Hit dummy;
-                    quad_occluded = trace_quad<true, STATS, EXT, true>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, stk, quad_slab, quad_stack, dummy, cnt,
+                    quad_occluded = trace_quad<true, STATS, EXT, TIES>(sc, need_shadow, fr.p, shadow_d, fr.eps, shadow_maxt, stk, quad_slab, quad_stack, dummy, cnt,
                                                                      (EXT && sc.has_masks != 0) ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 }
             }
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                 Hit dummy;
                 const bool masks = EXT && sc.has_masks != 0;
                 bool occluded = QUAD ? quad_occluded
-                                   : trace<true, STATS, EXT>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
+                                   : trace<true, STATS, EXT, TIES>(sc, fr.p, shadow_d, fr.eps, shadow_maxt, stk, dummy, cnt,
                                                              masks ? GBL_FILTER_OPAQUE : GBL_FILTER_NONE);
                 if (STATS) cnt.shadow += 1;
                 if (!occluded && masks) {
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                             dir = shade_to_world(fr, uniform_sample_hemisphere(u1, u2));
                         }
                         Hit dummy;
-                        const bool occ = trace_quad<true, STATS, EXT, true>(sc, want, fr.p, dir, fr.eps, INFINITY, stk, quad_slab, quad_stack, dummy, cnt);
+                        const bool occ = trace_quad<true, STATS, EXT, TIES>(sc, want, fr.p, dir, fr.eps, INFINITY, stk, quad_slab, quad_stack, dummy, cnt);
                         if (want && occ) occluded += 1;
                     }
                 }
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     }
                     F3 dir = shade_to_world(fr, uniform_sample_hemisphere(u1, u2));
                     Hit dummy;
-                    if (trace<true, STATS, EXT>(sc, fr.p, dir, fr.eps, INFINITY, stk, dummy, cnt)) occluded += 1;
+                    if (trace<true, STATS, EXT, TIES>(sc, fr.p, dir, fr.eps, INFINITY, stk, dummy, cnt)) occluded += 1;
                     if (STATS) cnt.shadow += 1;
                 }
                 if (STATS) cnt.dims += 2 * ra.ao_n;

@@ -118,6 +118,7 @@ __device__ __forceinline__ bool tri_test(const DevTri* tp, F3 o, F3 d, float min
 struct TravState {
     RaySpace world, r;   // world-space ray and the ray in the current space (world or instance)
     float mint, maxt;
+    float maxt0;         // the query's own maxt (maxt shrinks with every accepted hit); read by the TIES builds only
     int sp, cur, inst;
     Hit hit;
 };
@@ -159,6 +160,7 @@ __device__ __forceinline__ void trav_begin(const DevScene& sc, TravState& st, F3
     st.r = st.world;
     st.mint = mint;
     st.maxt = maxt;
+    st.maxt0 = maxt;
     st.sp = 0;
     stk.store(st.sp++, GBL_STACK_EXIT);
     st.cur = sc.num_instances > 0 ? sc.tlas_root : GBL_STACK_EXIT;
@@ -345,6 +347,23 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
     return !ref_leaf_reached(sc, cur, o, d, mint, t);
 }
 
+// Would the reference's own traversal get to test this triangle at all?  Its box tests are not watertight (static
+// intersect(bbox, ...), GoblinBVH.cpp:156-187: no padding, strict comparisons), while Triangle::intersect accepts with a
+// 1e-7 barycentric slack -- so a ray that grazes the silhouette of an axis-aligned object (the mirror block of the Cornell
+// scene: one sample in 65 536 at 1024 spp) can be accepted by the triangle test yet never reach it in the reference, whose
+// leaf box (the triangle's own bound, one triangle per leaf) or TLAS leaf box (the instance's world bound) the same ray
+// misses by a rounding.  Every ancestor's box contains those two, so they decide.  The TIES builds (replay, stream,
+// exact_ties, instrumented) therefore accept a triangle only if both pass the reference's test, with the query's own maxt.
+__device__ __forceinline__ bool ref_reached(const DevScene& sc, int inst, uint32_t shade, F3 wo, F3 wd, F3 oo, F3 od, float mint, float maxt0) {
+    const DevInstanceBound wb = sc.instance_bounds[inst];
+    if (!ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), wo, wd, mint, maxt0)) return false;
+    const DevTriShade sh = sc.tri_shade[shade];
+    const F3 a = load3(sc.positions + 3 * sh.v[0]), b = load3(sc.positions + 3 * sh.v[1]), c = load3(sc.positions + 3 * sh.v[2]);
+    const F3 lo = f3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
+    const F3 hi = f3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+    return ref_box_reached(lo, hi, oo, od, mint, maxt0);
+}
+
 // EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
 // `filter` (EXT builds): GBL_FILTER_* -- instances whose material is / is not a mask are skipped whole, which is
 // what Model::intersect does with the isOpaque / notOpaque IntersectFilter (GoblinModel.cpp:30-32, 44-46).
@@ -356,9 +375,13 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 // wave-pool kernel (kernels/wavepool.h), whose lanes trace shadow and extension rays side by side.
 // FUSE: a leaf whose pop uncovers the instance's sentinel (and then, possibly, the exit marker) takes those steps at once instead
 // of spending an iteration of the caller's loop on each (needs st.world: the one-ray-per-lane loops only).
-template <bool STATS, bool EXT, class STK, bool TIES, bool FUSE = false>
+// `wrec`: where the WORLD ray's origin and direction wait (6 words) when the caller does not keep st.world (the quads' records,
+// kernels/quadtrace.h); null: st.world.
+// REACH: apply ref_reached (one-ray-per-lane loops of the TIES builds; the quad kernels' queries keep the tie rule only, see
+// kernels/quadtrace.h).
+template <bool STATS, bool EXT, class STK, bool TIES, bool FUSE = false, bool REACH = true>
 __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, const bool ANY,
-                                                bool* occluded, int filter) {
+                                                bool* occluded, int filter, const gbl_lds_u32* wrec = nullptr) {
     const int cur = st.cur;
     if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
     if (cur == GBL_STACK_EXIT) return true;
@@ -386,8 +409,14 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         const float radius = sc.instances[st.inst].radius;
         float t;
         if (STATS) cnt.tris += 1;
-        const bool got = first == GBL_SHAPE_FIRST_SPHERE ? sphere_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t)
-                                                         : disk_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t);
+        bool got = first == GBL_SHAPE_FIRST_SPHERE ? sphere_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t)
+                                                   : disk_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t);
+        if (TIES && REACH && got) {   // the TLAS leaf box in front of the shape (ref_reached)
+            const F3 wo = wrec ? f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])) : st.world.o;
+            const F3 wd = wrec ? f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])) : st.world.d;
+            const DevInstanceBound wb = sc.instance_bounds[st.inst];
+            got = ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), wo, wd, st.mint, st.maxt0);
+        }
         if (got) {
             if (ANY) {
                 *occluded = true;
@@ -406,6 +435,11 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         float t, b1, b2;
         if (STATS) cnt.tris += 1;
         if (tri_test(sc.tris + first + i, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2)) {
+            if (TIES && REACH) {
+                const F3 wo = wrec ? f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])) : st.world.o;
+                const F3 wd = wrec ? f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])) : st.world.d;
+                if (!ref_reached(sc, st.inst, sc.tris[first + i].shade, wo, wd, st.r.o, st.r.d, st.mint, st.maxt0)) continue;
+            }
             if (ANY) {
                 *occluded = true;
                 return true;
@@ -434,10 +468,10 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
     }
     return false;
 }
-template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true, bool FUSE = false>
+template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true, bool FUSE = false, bool REACH = true>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
-                                           int filter = GBL_FILTER_NONE) {
-    return trav_other_kind<STATS, EXT, STK, TIES, FUSE>(sc, st, stk, cnt, ANY, occluded, filter);
+                                           int filter = GBL_FILTER_NONE, const gbl_lds_u32* wrec = nullptr) {
+    return trav_other_kind<STATS, EXT, STK, TIES, FUSE, REACH>(sc, st, stk, cnt, ANY, occluded, filter, wrec);
 }
 
 __device__ __forceinline__ bool trav_at_interior(const TravState& st) {

@@ -729,7 +729,9 @@ def test_full_size_properties_on_the_cornell_config(torch):
     print("lean vs tie-exact wavefront: differing samples", differing, "of", li_wf.shape[0])
     assert differing <= 1e-5 * li_wf.shape[0]
     del li_wf
-    _oracle_blocks(scene, r, exact, seed, ((100, 500), (520, 640), (500, 40)), 8, 8, tol=1e-4)
+    # (block (100, 500) holds the sample this test found: a ray that grazes the mirror block's vertical edge, accepted by the triangle
+    #  test's 1e-7 slack and never reached by the reference's unpadded box tests -- ref_reached, trace.h)
+    _oracle_blocks(scene, r, exact, seed, ((100, 500), (520, 640), (500, 40)), 8, 8)
 
 
 def test_full_size_properties_on_the_grid_config(torch):
