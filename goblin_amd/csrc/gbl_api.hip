@@ -547,7 +547,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
         fprintf(stderr, "probe: traversal stack entries %d (per-level bound %d: TLAS depth %d, BLAS depth %d)\n", packed.stack_entries,
                 3 * (packed.tlas_depth + packed.blas_max_depth) + 2, packed.tlas_depth, packed.blas_max_depth);
     for (uint32_t i = 0; i < desc->num_lights; ++i)
-        if (desc->lights[i].type == GBL_LIGHT_DIRECTIONAL) ctx->has_directional = true;
+        if (desc->lights[i].type == GBL_LIGHT_DIRECTIONAL || desc->lights[i].type == GBL_LIGHT_IBL) ctx->has_directional = true;   // lights sized by the scene bound
     ctx->info.build_ms = ctx->build_ms;
     ctx->info.blas_depth = packed.blas_max_depth;
     ctx->info.tlas_depth = packed.tlas_depth;
@@ -567,8 +567,8 @@ static gbl_status gbl_update_instances_impl(gbl_ctx* ctx, uint32_t first, uint32
         return GBL_ERR_INVALID;
     }
     if (ctx->has_directional) {
-        ctx->error = "gbl_update_instances: a directional light's power depends on the scene bound (GoblinLight.cpp:203-210); "
-                     "re-create the context instead";
+        ctx->error = "gbl_update_instances: a directional or image based light's power (and the image based light's sampling sphere) "
+                     "depends on the scene bound (GoblinLight.cpp:203-210, 590-629); re-create the context instead";
         return GBL_ERR_UNSUPPORTED;
     }
     for (uint32_t i = 0; i < count; ++i)

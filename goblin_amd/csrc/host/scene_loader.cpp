@@ -507,15 +507,30 @@ private:
                 float lo[3], hi[3];
             } h;
             static_assert(sizeof(Header) == 48, ".vol header");
+            // a header whose dimensions overflow, exceed what the device indexes with 32-bit ints, or promise more data than the
+            // file holds is not a grid: the reference's own fallback for an unreadable file (one cell of density 1) takes over
             if (fread(&h, sizeof(h), 1, f) == 1 && h.sig[0] == 'V' && h.sig[1] == 'O' && h.sig[2] == 'L' && (h.nch == 1 || h.nch == 3) && h.nx > 0 &&
                 h.ny > 0 && h.nz > 0 && h.encoding == 1) {
-                const size_t n = static_cast<size_t>(h.nx) * h.ny * h.nz * h.nch;
-                std::vector<float> data(n, 0.0f);
-                const size_t got = fread(data.data(), sizeof(float), n, f);   // (a short file leaves the tail as the reference's
-                (void)got;                                                     //  uninitialised buffer would: zeros here)
-                s_->density.swap(data);
-                nx = h.nx, ny = h.ny, nz = h.nz, nch = h.nch;
-                for (int i = 0; i < 3; ++i) lo[i] = h.lo[i], hi[i] = h.hi[i];
+                const uint64_t n64 = static_cast<uint64_t>(h.nx) * static_cast<uint64_t>(h.ny);
+                const bool fits = n64 < (1ull << 31) && n64 * static_cast<uint64_t>(h.nz) < (1ull << 31) &&
+                                  n64 * static_cast<uint64_t>(h.nz) * static_cast<uint64_t>(h.nch) < (1ull << 31);
+                if (fits) {
+                    const size_t n = static_cast<size_t>(n64) * h.nz * h.nch;
+                    long here = ftell(f);
+                    long end = here;
+                    if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+                        end = ftell(f);
+                        fseek(f, here, SEEK_SET);
+                    }
+                    if (here >= 0 && end >= here && static_cast<uint64_t>(end - here) >= n * sizeof(float)) {
+                        std::vector<float> data(n, 0.0f);
+                        if (fread(data.data(), sizeof(float), n, f) == n) {
+                            s_->density.swap(data);
+                            nx = h.nx, ny = h.ny, nz = h.nz, nch = h.nch;
+                            for (int i = 0; i < 3; ++i) lo[i] = h.lo[i], hi[i] = h.hi[i];
+                        }
+                    }
+                }
             }
             fclose(f);
         }

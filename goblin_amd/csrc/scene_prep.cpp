@@ -1232,6 +1232,19 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
                 *err = "heterogeneous volume: the density grid needs positive dimensions, 1 or 3 channels and its data";
                 return GBL_ERR_INVALID;
             }
+            // the march loops of kernels/medium.h advance t by step_size: zero, negative, NaN or a step below the float spacing
+            // of t never terminates -- a spin on the reference's CPU, an unrecoverable hang on a GPU
+            if (!(g.step_size > 0.0f) || !std::isfinite(g.step_size)) {
+                *err = "heterogeneous volume: step_size must be a positive finite number";
+                return GBL_ERR_INVALID;
+            }
+            // the device indexes the grid with 32-bit ints
+            const uint64_t cells = static_cast<uint64_t>(g.grid[0]) * static_cast<uint64_t>(g.grid[1]);
+            if (cells > (1ull << 31) || cells * static_cast<uint64_t>(g.grid[2]) > (1ull << 31) ||
+                cells * static_cast<uint64_t>(g.grid[2]) * static_cast<uint64_t>(g.grid_channels) >= (1ull << 31)) {
+                *err = "heterogeneous volume: the density grid holds 2^31 values or more";
+                return GBL_ERR_INVALID;
+            }
             v.hetero = 1u;
             v.step = g.step_size;
             v.nx = g.grid[0], v.ny = g.grid[1], v.nz = g.grid[2], v.nch = g.grid_channels;
@@ -1254,6 +1267,21 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
         Trs t = compose(d->volume.to_world.position, d->volume.to_world.orientation, d->volume.to_world.scale);
         store3x4(t.m, v.m);
         store3x4(t.inv, v.inv);
+        if (v.hetero != 0u) {
+            // a march is at most (the region's longest world-space diagonal) / step_size points long: bounded at the 10^6 the
+            // stream sampler's draw budget assumes (gbl_api.hip medium_draws_per_sample) -- a step of 1e-12 is a hang, not a render
+            double diag = 0.0;
+            for (int sgn = 0; sgn < 4; ++sgn) {
+                const double e[3] = {double(v.hi[0] - v.lo[0]), (sgn & 1 ? -1.0 : 1.0) * double(v.hi[1] - v.lo[1]), (sgn & 2 ? -1.0 : 1.0) * double(v.hi[2] - v.lo[2])};
+                double w[3];
+                for (int r = 0; r < 3; ++r) w[r] = v.m[4 * r] * e[0] + v.m[4 * r + 1] * e[1] + v.m[4 * r + 2] * e[2];
+                diag = std::max(diag, std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
+            }
+            if (!(diag / double(v.step) <= 1.0e6)) {
+                *err = "heterogeneous volume: step_size is too small for the region (more than 10^6 steps across it)";
+                return GBL_ERR_INVALID;
+            }
+        }
         const float dx = scene_bound.hi[0] - scene_bound.lo[0], dy = scene_bound.hi[1] - scene_bound.lo[1], dz = scene_bound.hi[2] - scene_bound.lo[2];
         v.bound_radius = std::sqrt(dx * dx + dy * dy + dz * dz);
         out->extended = 1;

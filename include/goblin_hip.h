@@ -522,8 +522,8 @@ gbl_status gbl_get_info(const gbl_ctx* ctx, gbl_info* out);
 
 /* Instance edits: give instances [first, first + count) new transforms and rebuild the TLAS over all instances in
  * place (BLASes untouched; the reference would rebuild its whole scene BVH, GoblinScene.cpp:11-27).  Synchronises
- * the device.  Instances that carry an area light, and scenes with a directional light (whose power depends on
- * the scene bound), are GBL_ERR_UNSUPPORTED: re-create the context for those. */
+ * the device.  Instances that carry an area light, and scenes with a directional or image based light (whose power and
+ * sampling sphere depend on the scene bound), are GBL_ERR_UNSUPPORTED: re-create the context for those. */
 gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world);
 
 /* Self-test hook: the device's sinf / cosf (glibc's algorithm restated, kernels/refmath.h) on n device floats. */

@@ -79,6 +79,24 @@ def test_bad_descriptions_are_rejected_before_touching_the_device():
     assert _abi.hip_lib().gbl_create(C.byref(desc), 0, C.byref(h)) == _abi.GBL_ERR_UNSUPPORTED
 
 
+def test_degenerate_march_steps_are_rejected_not_hung():
+    """A heterogeneous medium is ray marched in steps of step_size (kernels/medium.h): zero, negative, NaN, or a step so small
+    that the region is more than 10^6 steps across would never come back from the device.  pack_scene refuses them."""
+    from goblin_amd import scene as gs
+    scene = gs.load_scene("hetero", gs.config_overrides(resolution=(16, 16), spp=1, depth=2))
+    h = C.c_void_p()
+    for step in (0.0, -0.1, float("nan"), float("inf"), 1e-12):
+        desc = _abi.gbl_scene_desc.from_buffer_copy(scene.desc)
+        desc.volume.step_size = step
+        assert _abi.hip_lib().gbl_create(C.byref(desc), 0, C.byref(h)) == _abi.GBL_ERR_INVALID, step
+        assert b"step_size" in _abi.hip_lib().gbl_last_error(None)
+    desc = _abi.gbl_scene_desc.from_buffer_copy(scene.desc)
+    desc.volume.grid[0] = 1 << 16
+    desc.volume.grid[1] = 1 << 16
+    assert _abi.hip_lib().gbl_create(C.byref(desc), 0, C.byref(h)) == _abi.GBL_ERR_INVALID
+    assert b"2^31" in _abi.hip_lib().gbl_last_error(None)
+
+
 def test_product_never_touches_the_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/."""
     pkg = os.path.join(REPO, "goblin_amd")

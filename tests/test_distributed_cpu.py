@@ -142,3 +142,32 @@ def test_tile_shards_partition_the_window():
     assert gd.shard_for(3, 8, "tiles", 7) == {"shard": (3, 8), "seed": 7}
     assert gd.shard_for(3, 8, "samples", 7) == {"shard": None, "seed": 10}
     assert gd.shard_for(0, 1, "tiles", 7) == {"shard": None, "seed": 7}
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tile_split_of_the_multi_gpu_config_is_balanced(world):
+    """bench.py --gpus N renders BASELINE configs[3] (grid.json, 1024x1024 film: a 1028x1028 sample window, 129x129 tiles of
+    8x8, the last row / column 4 wide) under the interleaved tile split: every rank owns within +-2 % of the pixels (hence of
+    the camera paths), every tile belongs to exactly one rank, and the tiles of a rank are spread over the whole image
+    (Film::mergeTile's workers take whichever tile comes next, GoblinRenderer.cpp:99-126: no spatial partition there either)."""
+    scene = gs.load_scene("grid", gs.config_overrides(resolution=(1024, 1024), spp=256, depth=8))
+    import ctypes as C
+    from goblin_amd import _abi
+    w = (C.c_int32 * 4)()
+    _abi.host_lib().gbl_host_sample_window(C.byref(scene.desc.film), w)
+    window = tuple(w)
+    assert window == (-2, 1026, -2, 1026)
+    owned = np.zeros((1028, 1028), np.int32)
+    counts = []
+    for rank in range(world):
+        px = 0
+        rows = set()
+        for (x0, x1, y0, y1) in gd.tiles_of(window, rank, world):
+            owned[y0 + 2:y1 + 2, x0 + 2:x1 + 2] += 1
+            px += (x1 - x0) * (y1 - y0)
+            rows.add(y0)
+        counts.append(px)
+        assert len(rows) == 129          # a rank's tiles touch every tile row
+    assert (owned == 1).all()
+    assert sum(counts) == 1028 * 1028 and sum(counts) * scene.spp() == scene.num_paths()
+    assert max(counts) <= 1.02 * min(counts), counts

@@ -622,6 +622,11 @@ def test_instance_edits_rebuild_the_tlas_in_place(torch, schedule, bvh):
     with pytest.raises(_abi.GoblinError) as e:
         cornell.update_instances(cornell.scene.desc.num_instances, [moves[0]])
     assert e.value.status == _abi.GBL_ERR_INVALID
+    # an image based light's power, pick pdf and sampling sphere come from the scene bound, like a directional light's power
+    ibl = HipPathTracer(gs.load_scene("ibl", gs.config_overrides(resolution=(16, 16), spp=1, depth=2)), 0)
+    with pytest.raises(_abi.GoblinError) as e:
+        ibl.update_instances(0, [moves[0]])
+    assert e.value.status == _abi.GBL_ERR_UNSUPPORTED
 
 
 def test_full_size_properties_on_the_headline_config(torch):

@@ -427,7 +427,15 @@ def test_heterogeneous_volume_and_vol_grid(tmp_path):
     assert v.step_size == pytest.approx(0.1) and v.sample_num == 5 and v.g == pytest.approx(0.2)
     np.testing.assert_array_equal(np.ctypeslib.as_array(v.density, shape=(72,)), data.ravel())
     assert list(v.to_world.position) == [1, 2, 3]
-    for bad in (str(tmp_path / "missing.vol"), str(tmp_path / "half.vol")):
+    # hostile or truncated headers are not grids either (on the GPU they would be out-of-bounds reads): dimensions whose product
+    # wraps size_t, a product beyond what 32-bit indices address, a file shorter than its header promises
+    with open(tmp_path / "wrap.vol", "wb") as f:
+        f.write(b"VOL\x03" + struct.pack("<5i", 1, 1 << 30, 1 << 30, 16, 1) + struct.pack("<6f", -1, -2, -3, 1.5, 2.5, 3.5) + bytes(64))
+    with open(tmp_path / "huge.vol", "wb") as f:
+        f.write(b"VOL\x03" + struct.pack("<5i", 1, 2048, 2048, 1024, 1) + struct.pack("<6f", -1, -2, -3, 1.5, 2.5, 3.5) + bytes(64))
+    with open(tmp_path / "short.vol", "wb") as f:
+        f.write(b"VOL\x03" + struct.pack("<5i", 1, 2, 3, 4, 3) + struct.pack("<6f", -1, -2, -3, 1.5, 2.5, 3.5) + data.tobytes()[:100])
+    for bad in (str(tmp_path / "missing.vol"), str(tmp_path / "half.vol"), str(tmp_path / "wrap.vol"), str(tmp_path / "huge.vol"), str(tmp_path / "short.vol")):
         s = gs.load_scene_text(json.dumps(minimal(volume=dict(vol, density_grid=bad, step_size=0.25, sample_num=2))), MODELS)
         v = s.desc.volume
         assert list(v.grid) == [1, 1, 1] and v.grid_channels == 1 and v.density[0] == 1.0
