@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
 GBL_ABI_VERSION = 13
-GBL_AUTO_WAVEFRONT_TRIS, GBL_AUTO_WAVEFRONT_PATHS = 400000, 150000000   # gbl_schedule AUTO thresholds (goblin_hip.h)
+GBL_AUTO_WAVEFRONT_RAYS_PER_PATH, GBL_AUTO_WAVEFRONT_PATHS = 6.0, 1 << 22   # gbl_schedule AUTO thresholds (goblin_hip.h)
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM, GBL_ERR_INTERNAL = range(7)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
                 4: "GBL_ERR_DEVICE", 5: "GBL_ERR_OOM", 6: "GBL_ERR_INTERNAL"}

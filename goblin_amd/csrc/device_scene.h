@@ -52,7 +52,7 @@ struct DevTri {
     float p0[3];
     uint32_t shade;   // index into tri_shade / original triangle id within the scene
     float e1[3];
-    float pad0;
+    uint32_t flags;   // DevTriShade::flags again (bit 0: vertex normals, bit 1: uvs): a plain mesh's hit needs no tri_shade fetch
     float e2[3];
     float pad1;
 };

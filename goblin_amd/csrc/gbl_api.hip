@@ -456,7 +456,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
             int depth = 0;
             st = gbl_build_blas_device(ctx, d_pos + 3 * static_cast<size_t>(gm.vertex_offset), d_idx + 3 * static_cast<size_t>(gm.tri_offset), gm.tri_count,
                                    &packed.mesh_lo[3 * m], &packed.mesh_hi[3 * m], const_cast<DevNode*>(sc.nodes), node_base,
-                                   const_cast<DevTri*>(sc.tris), tri_base, gm.tri_offset, &mesh_root[m], &used, &depth);
+                                   const_cast<DevTri*>(sc.tris), tri_base, gm.tri_offset, (gm.has_normal ? 1u : 0u) | (gm.has_uv ? 2u : 0u), &mesh_root[m], &used, &depth);
             if (st != GBL_OK) return bail(st);
             node_base += static_cast<int32_t>(used);
             tri_base += gm.tri_count;
@@ -610,6 +610,7 @@ static gbl_status gbl_update_instances_impl(gbl_ctx* ctx, uint32_t first, uint32
     ctx->info.tlas_depth = depth;
     ctx->info.tlas_nodes = tlas.size();
     ctx->h_instances.swap(edited);
+    ctx->auto_rays_per_path.clear();   // the edited scene's paths may be longer or shorter: AUTO measures again
     return GBL_OK;
 }
 gbl_status gbl_update_instances(gbl_ctx* ctx, uint32_t first, uint32_t count, const gbl_trs* to_world) {
@@ -694,6 +695,39 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
     if (p->schedule > GBL_SCHEDULE_WAVEFRONT) {
         ctx->error = "unknown schedule " + std::to_string(p->schedule);
         return GBL_ERR_INVALID;
+    }
+    // GBL_SCHEDULE_AUTO for the path tracer goes by how long the scene's paths are (see the schedule paragraph below): measured
+    // once per context and max_ray_depth by a pilot -- one instrumented sample per pixel over every 4th tile, native sampler,
+    // into a scratch film -- before anything of this call is queued.
+    float pilot_rays_per_path = 0.0f;
+    if (p->schedule == GBL_SCHEDULE_AUTO && p->integrator == GBL_INTEGRATOR_PATH && p->sample_mode != GBL_SAMPLES_STREAM && sc.has_masks == 0) {
+        auto it = ctx->auto_rays_per_path.find(p->max_ray_depth);
+        if (it == ctx->auto_rays_per_path.end()) {
+            float* scratch = nullptr;
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&scratch), static_cast<size_t>(ctx->info.xres) * ctx->info.yres * 4 * sizeof(float)));
+            gbl_render_params pilot;
+            memset(&pilot, 0, sizeof(pilot));
+            pilot.integrator = GBL_INTEGRATOR_PATH;
+            pilot.sample_per_pixel = 1;
+            pilot.max_ray_depth = p->max_ray_depth;
+            pilot.ao_sample_num = p->ao_sample_num;
+            pilot.bssrdf_sample_num = p->bssrdf_sample_num;
+            pilot.tile_shard_index = 0;
+            pilot.tile_shard_count = 4;
+            pilot.sample_mode = GBL_SAMPLES_NATIVE;
+            pilot.seed = 0x9011057ull;
+            pilot.collect_stats = 1;
+            pilot.schedule = GBL_SCHEDULE_MEGAKERNEL;
+            pilot.stream = p->stream;
+            gbl_stats ps;
+            const gbl_status pst = gbl_render_impl(ctx, &pilot, scratch, &ps);
+            (void)hipFree(scratch);
+            if (pst != GBL_OK) return pst;
+            const float rpp = ps.paths ? static_cast<float>(static_cast<double>(ps.extension_rays + ps.shadow_rays) / static_cast<double>(ps.paths)) : 0.0f;
+            it = ctx->auto_rays_per_path.emplace(p->max_ray_depth, rpp).first;
+        }
+        pilot_rays_per_path = it->second;
     }
     ra.integrator = static_cast<int32_t>(p->integrator);
     ra.spp = round_to_square(p->sample_per_pixel, &ra.root);
@@ -842,47 +876,23 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         }
         ra.tile_seeds = ctx->stream_seeds;
     }
-    // schedule.  AUTO follows the measurements in DESIGN.md 4: the persistent megakernel wins while its workgroups fit three to
-    // a CU and the scene is small (bunny.json at any depth: 12.8 / 14.9 / 16.1 ms against the wavefront's 19.7 / 23.3 / 25.2 at
-    // depth 8 / 12 / 16, 512^2 x 64 spp), the wavefront formulation once traversal dominates and its compaction pays for the
-    // path pool traffic -- many instanced triangles (config 4, 15 bunnies: 297 ms against 385 ms) -- or once the megakernel's
-    // full-depth LDS stacks leave room for two workgroups per CU only (the Cornell box at every depth: 3.5 s against 6.5 s at
-    // depth 16).  (Until the quad-per-ray queries AUTO also went by max_ray_depth >= 12; the megakernel has since gained
-    // 11 ... 14 % and wins bunny.json at depth 16 by 56 %.)  AO always runs the megakernel; mask scenes do under AUTO (the
-    // wavefront kernels handle masks -- same radiance -- but run the filtered MIS query and the attenuation walks inline in the
-    // trace kernel: 48.6 ms against 16.1 ms on masked.json).
+    // schedule.  The persistent megakernel keeps the path state in registers and regenerates paths in place; the wavefront
+    // formulation moves it through a 2^23-slot pool in HBM (~400 B per slot and iteration) to trace at five waves per SIMD with
+    // compacted queues.  Which pays is a matter of how much of a path is incoherent traversal: measured (tools/auto_check.py,
+    // 512^2 x 64 spp, wavefront / megakernel time) 1.6 on bunny.json at any depth (3.4 ... 3.5 rays per path), 1.15 ... 1.19 on the
+    // 15-bunny grid (3.5 ... 3.8), 1.04 / 0.98 / 0.96 / 0.92 / 0.91 on the Cornell box at max_ray_depth 4 / 6 / 8 / 12 / 16 (4.9 / 6.6 /
+    // 7.9 / 9.6 / 10.7 rays per path: a closed box, its paths never leave), 1.35 ... 1.73 on the feature scenes (2.9 ... 4.0); at full
+    // size 291 against 280 ms on BASELINE configs[3] and 3.39 against 4.62 s on configs[2], where the pool is refilled 130
+    // times.  AUTO = wavefront when the pilot above sees GBL_AUTO_WAVEFRONT_RAYS_PER_PATH rays per path or more and the call
+    // (this rank's tiles x spp) holds at least GBL_AUTO_WAVEFRONT_PATHS camera samples to fill the pool with; megakernel
+    // otherwise, for mask scenes (the wavefront kernels run the filtered MIS query and the attenuation walks inline: 35.3
+    // against 20.2 ms on masked.json), for AO, Whitted and the stream sampler.  (Until round 3 AUTO went by instanced triangles
+    // and by whether the megakernel's LDS stacks would leave three workgroups per CU; the megakernel has since gained 6 ... 9 %
+    // and wins the grid at every size.)
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
-    // The deep-tree rule: would the lean megakernel fit three workgroups per CU if its LDS stacks held the PER-LEVEL bound,
-    // 3 * (TLAS + BLAS depth) + 2 entries per lane (47 for bunny.json: yes; 50 for the Cornell box, 53 for the grid: no)?
-    // When this rule was measured that bound sized the stacks, and a third fewer waves cost the megakernel 28 % (bunny with
-    // 2-triangle leaves: 66 against 51 ms, the wavefront 56).  The stacks now hold the exact need of the built trees
-    // (scene_prep.cpp scene_stack_entries; see DESIGN.md 3 for those three scenes' figures), which put the Cornell box back at three
-    // workgroups (101.6 -> 78.6 ms at depth 16) -- and still behind the wavefront's 66.7 ms: its paths are long and never
-    // leave the box.  The rule therefore stays on the per-level bound, as a proxy for scenes of many objects whose paths keep
-    // traversing; tools/auto_check.py re-measures the nine cases it was calibrated on.
-    bool mk_lds_cliff = false;
-    if (wf_capable && !stream_mode && p->schedule == GBL_SCHEDULE_AUTO && sc.extended == 0) {
-        const bool quad = quad_wanted(false);
-        gbl_render_kernel k = quad ? gbl_kernel_path_quad(replay, false, false) : gbl_kernel_path(replay, false, false);
-        const size_t level_bound = static_cast<size_t>(3 * (ctx->info.tlas_depth + ctx->info.blas_depth) + 2);
-        const size_t l = (quad ? (gbl_quad_lds_words() + 4) * sizeof(uint32_t) : sizeof(float) * (4 * tp * tp + 256) + 4 * sizeof(uint32_t)) +
-                         level_bound * GBL_BLOCK * sizeof(uint32_t);
-        if (l > 160 * 1024) {
-            mk_lds_cliff = true;
-        } else {
-            if (l > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l)));
-            int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k), GBL_BLOCK, l) == hipSuccess) mk_lds_cliff = occ < GBL_PT_WAVES;
-            else mk_lds_cliff = l * 3 > 160 * 1024;
-        }
-    }
-    // A scene of many instanced triangles goes by the size of the call: the wavefront's hundreds of launches per frame and its
-    // 2^23-slot pool want work to amortise over -- the 15-bunny grid at 1024^2 x 256 spp (270 M paths): 297 against 301 ms for the
-    // megakernel; one rank's share of that frame under 2 / 4 / 8-way tile sharding (135 / 68 / 34 M paths): 154.2 / 84.6 / 44.2
-    // against 153.2 / 79.7 / 40.3 ms (tools/shard_check.py) -- so the strong-scaling ranks of section 8 run the megakernel.
     const uint64_t call_paths = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * static_cast<uint64_t>(ra.window[3] - ra.window[2]) * ra.spp /
                                 static_cast<uint64_t>(ra.shard_count);
-    const bool auto_wavefront = ctx->info.instanced_triangles >= GBL_AUTO_WAVEFRONT_TRIS ? call_paths >= GBL_AUTO_WAVEFRONT_PATHS : mk_lds_cliff;
+    const bool auto_wavefront = pilot_rays_per_path >= GBL_AUTO_WAVEFRONT_RAYS_PER_PATH && call_paths >= GBL_AUTO_WAVEFRONT_PATHS;
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && auto_wavefront));
     if (p->schedule == GBL_SCHEDULE_WAVEFRONT && !wavefront) {

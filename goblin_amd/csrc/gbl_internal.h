@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct gbl_ctx {
     uint64_t vol_entries = 0;
     float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
     uint64_t sss_entries = 0;
+    std::map<int, float> auto_rays_per_path;   // GBL_SCHEDULE_AUTO's pilot: rays per camera path by max_ray_depth (gbl_render)
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;
@@ -102,5 +104,5 @@ gbl_render_kernel gbl_kernel_vol(bool replay, bool stats);
 void gbl_launch_vol_combine(float4* li, const float4* vol, uint64_t n, hipStream_t stream);
 void gbl_launch_film_resolve(const float* accum, float* rgb, int n, hipStream_t stream);
 gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,
-                                 DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base,
+                                 DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base, uint32_t tri_flags,
                                  int32_t* root_out, uint32_t* nodes_out, int* depth_out);

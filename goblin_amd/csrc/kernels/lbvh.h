@@ -222,7 +222,7 @@ __global__ void lbvh_collapse(LbvhTree t, const LbvhFrontier* in, uint32_t n_in,
     nodes[f.slot] = nd;
 }
 
-__global__ void lbvh_tris(const float* pos, const uint32_t* idx, const unsigned long long* keys, uint32_t n, uint32_t shade_base, DevTri* out) {
+__global__ void lbvh_tris(const float* pos, const uint32_t* idx, const unsigned long long* keys, uint32_t n, uint32_t shade_base, uint32_t flags, DevTri* out) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t t = static_cast<uint32_t>(keys[k] & 0xffffffffull);
@@ -236,6 +236,7 @@ __global__ void lbvh_tris(const float* pos, const uint32_t* idx, const unsigned 
         d.e2[a] = p2[a] - p0[a];
     }
     d.shade = shade_base + t;
-    d.pad0 = d.pad1 = 0.0f;
+    d.flags = flags;
+    d.pad1 = 0.0f;
     out[k] = d;
 }

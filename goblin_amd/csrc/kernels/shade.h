@@ -179,19 +179,23 @@ __device__ __forceinline__ void make_fragment(const DevScene& sc, const Hit& h, 
     const float4 q1 = reinterpret_cast<const float4*>(tp)[1];
     const float4 q2 = reinterpret_cast<const float4*>(tp)[2];
     F3 e1 = f3(q1.x, q1.y, q1.z), e2 = f3(q2.x, q2.y, q2.z);
-    const DevTriShade sh = sc.tri_shade[__float_as_uint(q0.w)];
+    // (the record's own copy of the mesh's flags: a mesh without vertex normals and uvs -- face normal, default uvs -- needs
+    //  nothing from tri_shade, one dependent fetch less at every hit)
+    const uint32_t tri_flags = __float_as_uint(q1.w);
+    DevTriShade sh = {};
+    if (tri_flags != 0u) sh = sc.tri_shade[__float_as_uint(q0.w)];
     float b1 = h.b1, b2 = h.b2;
     float b0 = 1.0f - b1 - b2;
     F3 pos = ro + h.t * rd;
     F3 nrm;
-    if (sh.flags & 1u) {
+    if (tri_flags & 1u) {
         F3 n0 = load3(sc.normals + 3 * sh.v[0]), n1 = load3(sc.normals + 3 * sh.v[1]), n2 = load3(sc.normals + 3 * sh.v[2]);
         nrm = normalize(b0 * n0 + b1 * n1 + b2 * n2);
     } else {
         nrm = normalize(cross(e1, e2));
     }
     F3 dpdu;
-    if (sh.flags & 2u) {
+    if (tri_flags & 2u) {
         const float* uv = sc.uvs;
         float u0 = uv[2 * sh.v[0]], v0 = uv[2 * sh.v[0] + 1];
         float u1 = uv[2 * sh.v[1]], v1 = uv[2 * sh.v[1] + 1];

@@ -67,7 +67,7 @@ struct LbvhScratch {
 }  // namespace
 
 gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,
-                             DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base,
+                             DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base, uint32_t tri_flags,
                              int32_t* root_out, uint32_t* nodes_out, int* depth_out) {
     LbvhScratch sc;
     unsigned long long *keys = nullptr, *keys_sorted = nullptr;
@@ -98,7 +98,7 @@ gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_
         return GBL_ERR_OOM;
     }
     HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, keys_sorted, static_cast<int>(n), 0, 62));
-    hipLaunchKernelGGL(lbvh_tris, grid, block, 0, 0, d_pos, d_idx, keys_sorted, n, shade_base, d_tris + tri_base);
+    hipLaunchKernelGGL(lbvh_tris, grid, block, 0, 0, d_pos, d_idx, keys_sorted, n, shade_base, tri_flags, d_tris + tri_base);
     *nodes_out = 0;
     *depth_out = 0;
     if (n <= GBL_MAX_LEAF_TRIS) {   // the whole mesh is one leaf

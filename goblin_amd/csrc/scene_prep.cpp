@@ -778,6 +778,7 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
                 t.e2[k] = p2[k] - p0[k];
             }
             t.shade = gm.tri_offset + p.id;
+            t.flags = (gm.has_normal ? 1u : 0u) | (gm.has_uv ? 2u : 0u);
             out->tris.push_back(t);
         }
         auto leaf_ref = [&](uint32_t first, uint32_t count) {

@@ -413,11 +413,12 @@ typedef enum gbl_sample_mode {
 /* How the device schedules the same arithmetic (identical per-sample radiance):
  *  WAVEFRONT   path pool in HBM, compacted ray queues, extend / shade / shadow kernels
  *  MEGAKERNEL  one persistent kernel, path state in registers, in-wave regeneration */
-/* AUTO: instanced triangles >= TRIS and at least PATHS camera samples in the call (this rank's tiles x spp), or fewer
- * triangles under trees so deep that the megakernel's workgroups would fit two to a CU at three stack entries per level
- * -> WAVEFRONT, else MEGAKERNEL (gbl_stats.schedule reports what a call ran under) */
-#define GBL_AUTO_WAVEFRONT_TRIS 400000
-#define GBL_AUTO_WAVEFRONT_PATHS 150000000ull
+/* AUTO (path tracer): WAVEFRONT when the scene's paths are long -- at least RAYS_PER_PATH scene queries per camera path, measured
+ * once per context and max_ray_depth by a one-sample pilot inside the first such gbl_render call (which therefore synchronises)
+ * -- and the call (this rank's tiles x spp) holds at least PATHS camera samples; MEGAKERNEL otherwise and for mask scenes, AO,
+ * Whitted and GBL_SAMPLES_STREAM (gbl_stats.schedule reports what a call ran under) */
+#define GBL_AUTO_WAVEFRONT_RAYS_PER_PATH 6.0f
+#define GBL_AUTO_WAVEFRONT_PATHS (1ull << 22)
 typedef enum gbl_schedule {
     GBL_SCHEDULE_AUTO = 0,
     GBL_SCHEDULE_MEGAKERNEL = 1,

@@ -371,16 +371,21 @@ def test_headline_scene_radiance_is_bit_identical(torch, schedule):
     assert same_n.mean() >= 0.99999
 
 
-def test_auto_schedule_at_config3_depth_is_the_wavefront(golden, torch):
-    """BASELINE configs[2]'s shape (Cornell box, max_ray_depth 16): AUTO resolves to the wavefront schedule -- the box's
-    top-level tree is a level deeper than bunny.json's and the megakernel's LDS stacks would fit two workgroups per CU;
-    bunny.json itself stays on the megakernel at that depth (16.1 against 25.2 ms at 512^2 x 64 spp).  Every schedule gives
-    the same per-sample radiance on the reference's records."""
+def test_auto_schedule_goes_by_path_length(golden, torch):
+    """GBL_SCHEDULE_AUTO (include/goblin_hip.h): a one-sample pilot inside the first AUTO render measures the scene's rays per
+    camera path; the wavefront schedule runs when that is >= 6 (the Cornell box from max_ray_depth 6 on: a closed box) and the
+    call holds >= 2^22 camera samples to fill its pool with, the megakernel otherwise (bunny.json and the instanced grid at any
+    depth: 3.4 ... 3.8 rays per path; small calls).  Every schedule gives the same per-sample radiance on the reference's records."""
     from goblin_amd.renderer import HipPathTracer
     meta, data = golden("cornell_pt_d16")
     assert meta["overrides"]["render_setting"]["max_ray_depth"] == 16 and meta["dims"] == 4 + 7 * 16 + 32
-    assert HipPathTracer(gs.load_scene(meta["scene"], meta["overrides"]), 0).render(seed=5, stats=True)["stats"]["schedule"] == 2
-    assert HipPathTracer(gs.load_scene("bunny", gs.config_overrides(resolution=(64, 64), spp=4, depth=16)), 0).render(seed=5, stats=True)["stats"]["schedule"] == 1
+    sched = lambda name, **kw: HipPathTracer(gs.load_scene(name, gs.config_overrides(**kw)), 0).render(seed=5, timed=True)["stats"]["schedule"]
+    assert sched("cornell", resolution=(256, 256), spp=64, depth=16) == 2     # 260^2 x 64 = 4.3 M samples of long paths
+    assert sched("cornell", resolution=(256, 256), spp=64, depth=4) == 1      # ... of short ones (4.9 rays per path)
+    assert sched("cornell", resolution=(64, 64), spp=16, depth=16) == 1       # too few to fill the pool
+    assert sched("bunny", resolution=(256, 256), spp=64, depth=16) == 1
+    assert sched("grid", resolution=(256, 256), spp=64, depth=8) == 1
+    assert sched("masked", resolution=(256, 256), spp=64, depth=16) == 1      # mask scenes stay on the megakernel
     scene = gs.load_scene(meta["scene"], meta["overrides"])
     r = HipPathTracer(scene, 0)
     seed = 5
@@ -461,26 +466,6 @@ def test_exact_stack_entries_hold_every_ray(torch):
             for s in (["megakernel", "wavefront"] if "method" not in kw else ["auto"]):
                 got = r.render(seed=21, want_li=True, schedule=s)["li"].cpu().numpy()
                 np.testing.assert_array_equal(got.view(np.uint32), np.load("%s/%d_%s.npy" % (tmp, i, s)).view(np.uint32))
-
-
-def test_auto_schedule_avoids_the_megakernels_lds_cliff(torch, monkeypatch):
-    """GBL_SCHEDULE_AUTO's deep-tree rule goes by three stack entries per tree level: bunny.json at depth 8 runs the
-    megakernel (47 entries by that count: three workgroups per CU would just fit); the same scene built with 2-triangle leaves
-    (GBL_MAX_LEAF=2: one BLAS level more, 50) would leave room for two, so AUTO takes the wavefront schedule there (56
-    against 66 ms at full size when the rule was calibrated; the stacks themselves now hold the trees' exact need, DESIGN.md
-    3).  gbl_stats reports what ran; the radiance is the same either way."""
-    from goblin_amd.renderer import HipPathTracer
-    ov = gs.config_overrides(resolution=(96, 96), spp=16, depth=8)
-    monkeypatch.delenv("GBL_MAX_LEAF", raising=False)
-    r = HipPathTracer(gs.load_scene("bunny", ov), 0)
-    a = r.render(seed=5, want_li=True, stats=True)
-    assert a["stats"]["schedule"] == 1 and 3 * (r.info.blas_depth + r.info.tlas_depth) + 2 <= 48
-    monkeypatch.setenv("GBL_MAX_LEAF", "2")
-    r2 = HipPathTracer(gs.load_scene("bunny", ov), 0)
-    b = r2.render(seed=5, want_li=True, stats=True)
-    assert 3 * (r2.info.blas_depth + r2.info.tlas_depth) + 2 > 48 and b["stats"]["schedule"] == 2
-    assert r2.render(seed=5, stats=True, schedule="megakernel")["stats"]["schedule"] == 1
-    np.testing.assert_array_equal(a["li"].cpu().numpy().view(np.uint32), b["li"].cpu().numpy().view(np.uint32))
 
 
 def test_wavefront_without_stream_overlap_keeps_its_stack_backing_in_bounds(torch, monkeypatch):
@@ -741,25 +726,26 @@ def test_full_size_properties_on_the_cornell_config(torch):
 
 def test_full_size_properties_on_the_grid_config(torch):
     """BASELINE configs[3] at full size (15 instanced bunnies = 1.04 M instanced triangles, 1024x1024 film, 256 spp, depth 8:
-    270 536 704 paths): AUTO resolves to the wavefront for the whole frame and to the megakernel for one rank's share of an
-    8-way tile split; schedules bit-identical; 8 tile shards sum to the film; three blocks equal the oracle."""
+    270 536 704 paths): AUTO resolves to the megakernel (3.8 rays per path; 280 against the wavefront's 291 ms), for the whole frame
+    and for one rank's share of an 8-way tile split; schedules bit-identical; 8 tile shards sum to the film; three blocks equal
+    the oracle."""
     from goblin_amd.renderer import HipPathTracer
     scene = gs.load_scene("grid", gs.config_overrides(resolution=(1024, 1024), spp=256, depth=8))
     assert scene.num_paths() == 1028 * 1028 * 256
     r = HipPathTracer(scene, 0)
     seed = 20261003
     auto = r.render(seed=seed, want_li=True, timed=True)
-    assert auto["stats"]["schedule"] == 2
+    assert auto["stats"]["schedule"] == 1
     li = auto["li"]
     assert torch.isfinite(li).all()
-    mk = r.render(seed=seed, want_li=True, schedule="megakernel")
-    assert torch.equal(mk["li"], li)
-    del mk
+    wf = r.render(seed=seed, want_li=True, schedule="wavefront")
+    assert torch.equal(wf["li"], li)
+    del wf
     film = r.new_film()
     paths = []
     for rank in range(8):
         out = r.render(film=film, seed=seed, shard=(rank, 8), timed=True)
-        assert out["stats"]["schedule"] == 1          # a rank's share is below AUTO's 150 M-sample mark
+        assert out["stats"]["schedule"] == 1
         paths.append(out["stats"]["paths"])
     assert sum(paths) == scene.num_paths() and max(paths) <= 1.02 * min(paths)
     np.testing.assert_allclose(film.numpy(), auto["film"].numpy(), rtol=1e-4, atol=1e-4)
