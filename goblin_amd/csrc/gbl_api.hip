@@ -143,12 +143,11 @@ uint64_t li_budget_bytes(gbl_ctx* ctx) {
     return ctx->li_budget;
 }
 
-// Quad-per-ray steps of the megakernel (kernels/quadtrace.h): on unless GBL_MK_QUAD=0 for the lean kernels (-9 ... -11 % on
-// the BASELINE scenes), off unless GBL_MK_QUAD=1 for the EXT ones (two waves per SIMD, mostly small scenes: +1 ... +14 %)
-static bool quad_wanted(bool ext) {
+// Quad-per-ray queries (kernels/quadtrace.h): what the lean kernels of the native sampler run (-9 ... -14 % on the BASELINE scenes);
+// GBL_MK_QUAD=0 selects their one-ray-per-lane builds instead (bit-identity tests, A/B measurements).
+static bool quad_wanted() {
     const char* e = getenv("GBL_MK_QUAD");
-    if (e == nullptr || e[0] == '\0') return !ext;
-    return e[0] != '0';
+    return e == nullptr || e[0] != '0';
 }
 
 // Random numbers one camera sample's transmittance + Lv may draw (GBL_SAMPLES_STREAM sizes a pixel's tail with it): 9 per light
@@ -927,7 +926,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             ctx->vol_entries = entries;
         }
         ra.vol = ctx->vol_buf;
-        gbl_render_kernel k_vol = gbl_kernel_vol(replay, want_stats);
+        gbl_render_kernel k_vol = gbl_kernel_vol(replay);
         const size_t lds_vol = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
         if (lds_vol > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_vol), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -964,7 +963,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         for (int k = 0; k < 3; ++k)
             if (!wev[k]) HIP_TRY(ctx, hipEventCreate(&wev[k]));
         HIP_TRY(ctx, hipEventRecord(wev[0], stream));
-        gbl_li_kernel k_wh = stream_mode ? gbl_kernel_whitted_stream(want_stats) : gbl_kernel_whitted(replay, want_stats);
+        gbl_li_kernel k_wh = stream_mode ? gbl_kernel_whitted_stream() : gbl_kernel_whitted(replay);
         size_t lds_wh = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
         if (stream_mode) {
             const size_t want = std::max<size_t>(lds_wh, 40 * 1024);
@@ -1026,18 +1025,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             memset(stats, 0, sizeof(*stats));
             stats->kernel_ms = ms;
             stats->schedule = GBL_SCHEDULE_MEGAKERNEL;
-            stats->paths = npix * ra.spp;
-            if (want_stats) {
-                unsigned long long h[32];
-                HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));
-                stats->paths = h[0];
-                stats->extension_rays = h[1];
-                stats->shadow_rays = h[2];
-                stats->nodes = h[3];
-                stats->tris = h[4];
-                stats->splats = h[5];
-                stats->dims = h[6];
-            }
+            stats->paths = npix * ra.spp;   // (the Whitted kernel is not instrumented: no ray counters)
         }
         return GBL_OK;
     }
@@ -1060,7 +1048,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             ctx->sss_entries = entries;
         }
         ra.sss = reinterpret_cast<const float*>(ctx->sss_buf);
-        gbl_li_kernel k_sss = gbl_kernel_sss(replay, want_stats);
+        gbl_li_kernel k_sss = gbl_kernel_sss(replay);
         const size_t lds_sss = static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
         if (lds_sss > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sss), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1081,7 +1069,7 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         const bool ext = sc.extended != 0;   // see render_wavefront
         void (*kernel)(DevScene, RenderArgs) = nullptr;
         if (stream_mode) {
-            kernel = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_stream(want_stats, ext || want_stats)
+            kernel = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_stream(ext || want_stats)
                                                         : gbl_kernel_path_stream(want_stats, ext || want_stats);
             const StreamLayout L = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2,
                                                  p->integrator == GBL_INTEGRATOR_AO ? ra.ao_n : 0);
@@ -1124,16 +1112,12 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         }
         // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records take
         // the LDS film tile's place.  Its LDS need differs from the film-tile formula checked above: checked again here, and a
-        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.  By default the lean kernels of the native
-        // sampler only: the builds that follow the reference's tie rule and reachability test (replay, exact_ties, instrumented)
-        // run one ray per lane, where ref_reached applies (trace.h); GBL_MK_QUAD=1 forces the quad kernels on them (tests).
-        if (!stream_mode && defer) {
+        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.  The lean kernels of the native sampler only:
+        // the EXT builds are slower under it, and the builds that follow the reference's tie rule and reachability test (replay,
+        // exact_ties, instrumented) run one ray per lane, where ref_reached applies (trace.h).
+        if (!stream_mode && defer && !ext && !replay && !want_stats && p->exact_ties == 0 && quad_wanted()) {
             const size_t lds_quad = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            const bool ties_build = replay || want_stats || p->exact_ties != 0;
-            gbl_render_kernel k_quad = nullptr;
-            if (p->integrator == GBL_INTEGRATOR_AO && !ext && !want_stats && quad_wanted(ties_build)) k_quad = gbl_kernel_ao_quad(replay);
-            if (p->integrator == GBL_INTEGRATOR_PATH && quad_wanted(ext || ties_build)) k_quad = gbl_kernel_path_quad(replay, want_stats, ext || want_stats);
-            if (p->exact_ties != 0 && !replay && !want_stats) k_quad = nullptr;   // (exact_ties has one-ray-per-lane instantiations only)
+            gbl_render_kernel k_quad = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_quad() : (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_quad() : nullptr);
             if (k_quad && lds_quad <= 160 * 1024) {
                 kernel = k_quad;
                 lds = lds_quad;

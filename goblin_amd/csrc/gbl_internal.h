@@ -85,22 +85,22 @@ typedef void (*gbl_li_kernel)(DevScene, RenderArgs, float4*);
 gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext, bool exact_ties = false);
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext, bool exact_ties = false);
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
-gbl_render_kernel gbl_kernel_path_quad(bool replay, bool stats, bool ext);
-gbl_render_kernel gbl_kernel_ao_quad(bool replay);
+gbl_render_kernel gbl_kernel_path_quad(void);
+gbl_render_kernel gbl_kernel_ao_quad(void);
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);
-gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext);
+gbl_render_kernel gbl_kernel_ao_stream(bool ext);
 // kernels_wavefront.hip (kernels/wavefront.h)
 gbl_wf_kernel gbl_kernel_wf_trace(bool any, bool stats, bool ext, bool masks, bool ties);
 gbl_wf_kernel gbl_kernel_wf_shade(bool replay, bool stats, bool ext);
 gbl_wf_kernel gbl_kernel_wf_splat(bool replay, bool stats);
 // kernels_whitted.hip (kernels/whitted.h)
-gbl_li_kernel gbl_kernel_whitted(bool replay, bool stats);
-gbl_li_kernel gbl_kernel_whitted_stream(bool stats);
+gbl_li_kernel gbl_kernel_whitted(bool replay);
+gbl_li_kernel gbl_kernel_whitted_stream(void);
 // kernels_aux.hip: first-hit passes (kernels/subsurface.h, kernels/volume.h), film resolve, device BLAS build, self tests
-gbl_li_kernel gbl_kernel_sss(bool replay, bool stats);
-gbl_render_kernel gbl_kernel_vol(bool replay, bool stats);
+gbl_li_kernel gbl_kernel_sss(bool replay);
+gbl_render_kernel gbl_kernel_vol(bool replay);
 void gbl_launch_vol_combine(float4* li, const float4* vol, uint64_t n, hipStream_t stream);
 void gbl_launch_film_resolve(const float* accum, float* rgb, int n, hipStream_t stream);
 gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,

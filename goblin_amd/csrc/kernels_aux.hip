@@ -10,15 +10,10 @@
 
 #include <cstring>
 
-gbl_li_kernel gbl_kernel_sss(bool replay, bool stats) {
-    if (replay) return stats ? sss_kernel<true, true> : sss_kernel<true, false>;
-    return stats ? sss_kernel<false, true> : sss_kernel<false, false>;
-}
+// (the first-hit passes are not instrumented: gbl_stats counts the integrator kernels' queries)
+gbl_li_kernel gbl_kernel_sss(bool replay) { return replay ? sss_kernel<true, false> : sss_kernel<false, false>; }
 
-gbl_render_kernel gbl_kernel_vol(bool replay, bool stats) {
-    if (replay) return stats ? vol_kernel<true, true> : vol_kernel<true, false>;
-    return stats ? vol_kernel<false, true> : vol_kernel<false, false>;
-}
+gbl_render_kernel gbl_kernel_vol(bool replay) { return replay ? vol_kernel<true, false> : vol_kernel<false, false>; }
 
 // li[i] = 1 * (tr[i] * li[i] + Lv[i]) over the call's camera samples: the caller's li_out, after the splat has read it
 __global__ void vol_combine_kernel(float4* li, const float4* vol, uint64_t n) {

@@ -8,7 +8,6 @@ gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext) {
     return ext ? path_trace_kernel<GBL_SRC_STREAM, false, true> : path_trace_kernel<GBL_SRC_STREAM, false, false>;
 }
 
-gbl_render_kernel gbl_kernel_ao_stream(bool stats, bool ext) {
-    if (stats) return ao_kernel<GBL_SRC_STREAM, true, true>;
+gbl_render_kernel gbl_kernel_ao_stream(bool ext) {   // (not instrumented)
     return ext ? ao_kernel<GBL_SRC_STREAM, false, true> : ao_kernel<GBL_SRC_STREAM, false, false>;
 }

@@ -394,48 +394,29 @@ def test_auto_schedule_goes_by_path_length(golden, torch):
         np.testing.assert_array_equal(li["auto"].view(np.uint32), li[s].view(np.uint32))
 
 
-def test_quad_per_ray_megakernel_is_bit_identical(golden, torch, monkeypatch):
+def test_quad_per_ray_megakernel_is_bit_identical(torch, monkeypatch):
     """kernels/quadtrace.h: once at most 16 rays of a wave are unfinished each migrates to a quad of lanes (one child box per
-    lane, the sorting network on DPP, one triangle per lane at a leaf) -- the default of the lean megakernel and AO kernel,
-    GBL_MK_QUAD=1 forces it on the EXT builds too, GBL_MK_QUAD=0 is the one-ray-per-lane loop.  A ray's sequence of node
-    visits is the same either way: per-sample radiance bit for bit, native and replayed samples, path tracer and AO."""
+    lane, the sorting network on DPP, one triangle per lane at a leaf) -- what the lean megakernel and AO kernel of the native
+    sampler run; GBL_MK_QUAD=0 selects their one-ray-per-lane builds.  A ray's sequence of node visits is the same either way:
+    per-sample radiance bit for bit, path tracer and AO, and both equal the oracle on the same counter-based samples (exact-t
+    ties aside, which neither lean build resolves: none at these sizes)."""
     from goblin_amd.renderer import HipPathTracer
     cases = [("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=8)),
              ("cornell", gs.config_overrides(resolution=(48, 48), spp=16, depth=12)),
              ("grid", gs.config_overrides(resolution=(64, 64), spp=4, depth=5)),
-             ("masked", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
-             ("shapes", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
-             ("imagetex", gs.config_overrides(resolution=(48, 48), spp=9, depth=5)),
-             ("volume", gs.config_overrides(resolution=(32, 32), spp=4, depth=4)),
              ("bunny", gs.config_overrides(resolution=(96, 96), spp=4, method="ao", ao_samples=9)),
              ("grid", gs.config_overrides(resolution=(64, 64), spp=4, method="ao", ao_samples=9))]
     for name, ov in cases:
         scene = gs.load_scene(name, ov)
         monkeypatch.setenv("GBL_MK_QUAD", "0")
         ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        monkeypatch.setenv("GBL_MK_QUAD", "1")
+        monkeypatch.delenv("GBL_MK_QUAD")
         got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
         np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
         np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
-    # replayed reference samples (the tie-rule builds): the quads run trav_other's own leaf loop there
-    for fixture in ("bunny_pt", "cornell_pt", "grid_pt", "bunny_ao"):
-        meta, data = golden(fixture)
-        scene = gs.load_scene(meta["scene"], meta["overrides"])
-        samples = data["samples"]
-        r = HipPathTracer(scene, 0)
-        pixels = samples.shape[0] // meta["spp"]
-        while True:
-            try:
-                win = fake_window(r.window, pixels)
-                break
-            except ValueError:
-                pixels -= 1
-        samples = samples[:pixels * meta["spp"]]
-        li = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("GBL_MK_QUAD", mode)
-            li[mode] = r.render(window=win, replay_samples=samples, want_li=True, schedule="megakernel")["li"].cpu().numpy()
-        np.testing.assert_array_equal(li["0"].view(np.uint32), li["1"].view(np.uint32))
+        o = ob.Oracle(scene)
+        li_ref, _ = o.li_replay(o.native_samples(13), threads=4)
+        assert helpers.li_mismatch_fraction(got["li"].cpu().numpy(), li_ref) == 0.0
 
 
 def test_exact_stack_entries_hold_every_ray(torch):

@@ -17,7 +17,7 @@ for name, ov in CASES:
     film = tr.new_film()
     row = {"scene": name}
     for mode in ("0", "1"):
-        os.environ["GBL_MK_QUAD"] = mode
+        os.environ["GBL_MK_QUAD"] = mode   # "0": one ray per lane; anything else: the default quad queries
         best = 1e30
         for i in range(4):
             film.zero_()
