@@ -191,7 +191,37 @@ __device__ __forceinline__ void stream_strat2(const StreamLayout& L, uint32_t n,
     *y = uy * strata + yo * sub;
 }
 
+// Which pattern a shuffled column belongs to: column 0 is the lens sample, columns 1 .. F1 the 1D slots, the rest the 2D slots.
+struct StreamCol {
+    uint32_t two_d;   // 0: 1D slot, 1: 2D slot
+    uint32_t slot;    // running 1D / 2D slot number (the record's float offset follows from it)
+    uint32_t n, j;    // the pattern's slot count and this slot's number inside it
+};
+__device__ __forceinline__ StreamCol stream_column(const StreamLayout& L, uint32_t col) {   // col >= 1
+    StreamCol c;
+    uint32_t s = col - 1u;
+    c.two_d = s >= L.F1 ? 1u : 0u;
+    if (c.two_d) s -= L.F1;
+    c.slot = s;
+    c.n = 1u;
+    c.j = 0u;
+    const uint32_t nr = c.two_d ? L.nr2 : L.nr1;
+    for (uint32_t r = 0; r < nr; ++r) {
+        const uint32_t cnt = c.two_d ? L.r2c[r] : L.r1c[r], n = c.two_d ? L.r2n[r] : L.r1n[r];
+        if (s < cnt * n) {
+            c.n = n;
+            c.j = s % n;
+            break;
+        }
+        s -= cnt * n;
+    }
+    return c;
+}
+
 // Sampler::requestSamples for the pixel (cx, cy): fills c.recs.  Called by the whole workgroup.
+// The shuffles run one lane per column on 16-bit positions in LDS (the idle traversal stacks' region), a round of columns at a
+// time, and every round's columns go straight from there into the records: the permutations never travel through global
+// memory (66 KB written and read back per pixel at configs[1] until round 3) and configs[1]'s 65 columns are one round.
 // tm (instrumented builds): wall_clock64 ticks spent emitting / permuting / assembling, accumulated by thread 0
 __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const StreamLayout& L, int cx, int cy,
                                                       unsigned long long* tm = nullptr) {
@@ -203,73 +233,80 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         tm[0] += t1 - t0;
         t0 = t1;
     }
-    // ---- shuffle<T>(buffer, S, dim, rng): for n in [0, S): swap(element n, element rng.randomUInt() % S)
-    // (GoblinSampler.h:149-157), tracked as the position permutation of each column
-    const uint32_t B = min(64u, c.lperm_words / S);
+    unsigned short* lp = reinterpret_cast<unsigned short*>(c.lperm);
+    const uint32_t B = min(static_cast<uint32_t>(GBL_BLOCK), (2u * c.lperm_words) / S);   // columns per round
+    // image samples: not shuffled (sample k sits in sub-cell k, GoblinSampler.cpp:130-131)
+    for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
+        float* rec = c.recs + static_cast<size_t>(k) * L.dims;
+        float x, y;
+        stream_strat2(L, 1u, 0u, k, stream_u01(c.raw[2 * k]), stream_u01(c.raw[2 * k + 1]), &x, &y);
+        rec[0] = cx + x;
+        rec[1] = cy + y;
+    }
     for (uint32_t c0 = 0; c0 < L.ncols; c0 += B) {
+        // ---- shuffle<T>(buffer, S, dim, rng): for n in [0, S): swap(element n, element rng.randomUInt() % S)
+        // (GoblinSampler.h:149-157), tracked as the position permutation of each column
         const uint32_t b = threadIdx.x, col = c0 + b;
-        if (b < B && col < L.ncols) {
-            for (uint32_t k = 0; k < S; ++k) c.lperm[k * B + b] = k;
+        const uint32_t nb = min(B, L.ncols - c0);
+        if (b < nb) {
+            for (uint32_t k = 0; k < S; ++k) lp[k * B + b] = static_cast<unsigned short>(k);
             const uint32_t* u = c.raw + L.NF + col * S;
             for (uint32_t n0 = 0; n0 < S; n0 += 8) {
                 uint32_t o[8];
                 for (uint32_t i = 0; i < 8; ++i) o[i] = n0 + i < S ? u[n0 + i] % S : 0u;
                 for (uint32_t i = 0; i < 8 && n0 + i < S; ++i) {
                     const uint32_t ia = (n0 + i) * B + b, ib = o[i] * B + b;
-                    const uint32_t va = c.lperm[ia], vb = c.lperm[ib];
-                    c.lperm[ia] = vb;
-                    c.lperm[ib] = va;
+                    const unsigned short va = lp[ia], vb = lp[ib];
+                    lp[ia] = vb;
+                    lp[ib] = va;
                 }
             }
-            for (uint32_t k = 0; k < S; ++k) c.perm[col * S + k] = c.lperm[k * B + b];
+        }
+        __syncthreads();
+        if (tm) {
+            const unsigned long long t1 = wall_clock64();
+            tm[1] += t1 - t0;
+            t0 = t1;
+        }
+        // ---- records: sample k takes, in every column of the round, the element its position's permutation points at
+        for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
+            float* rec = c.recs + static_cast<size_t>(k) * L.dims;
+            for (uint32_t bb = 0; bb < nb; ++bb) {
+                const uint32_t cc = c0 + bb;
+                const uint32_t p = lp[k * B + bb];
+                if (cc == 0u) {   // the lens sample
+                    float x, y;
+                    stream_strat2(L, 1u, 0u, p, stream_u01(c.raw[2 * S + 2 * p]), stream_u01(c.raw[2 * S + 2 * p + 1]), &x, &y);
+                    rec[2] = x;
+                    rec[3] = y;
+                    continue;
+                }
+                const StreamCol sc = stream_column(L, cc);
+                if (sc.two_d == 0u) {
+                    const float strata = 1.0f / static_cast<float>(sc.n);
+                    const float sub = strata / static_cast<int>(S);
+                    const float off = static_cast<int>(p) + stream_u01(c.raw[4 * S + sc.slot * S + p]);
+                    rec[4 + sc.slot] = sc.j * strata + off * sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
+                } else {
+                    const uint32_t e = 4 * S + L.F1 * S + 2 * (sc.slot * S + p);
+                    float x, y;
+                    stream_strat2(L, sc.n, sc.j, p, stream_u01(c.raw[e]), stream_u01(c.raw[e + 1]), &x, &y);
+                    rec[4 + L.F1 + 2 * sc.slot] = x;
+                    rec[4 + L.F1 + 2 * sc.slot + 1] = y;
+                }
+            }
+        }
+        __syncthreads();   // the round's positions have been read before the next round overwrites them
+        if (tm) {
+            const unsigned long long t1 = wall_clock64();
+            tm[2] += t1 - t0;
+            t0 = t1;
         }
     }
-    __syncthreads();
-    if (tm) {
-        const unsigned long long t1 = wall_clock64();
-        tm[1] += t1 - t0;
-        t0 = t1;
-    }
-    // ---- records: sample k takes, in every column, the element its position's permutation points at
+    // ---- per-sample shuffles inside each pattern (:185-196); a one-slot pattern swaps its slot with itself
     const uint32_t* uper = c.raw + L.NF + L.ncols * S;   // in-pattern shuffle draws, F1 + F2 per sample
     for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
         float* rec = c.recs + static_cast<size_t>(k) * L.dims;
-        {
-            float x, y;
-            stream_strat2(L, 1u, 0u, k, stream_u01(c.raw[2 * k]), stream_u01(c.raw[2 * k + 1]), &x, &y);
-            rec[0] = cx + x;
-            rec[1] = cy + y;
-            const uint32_t p = c.perm[k];
-            stream_strat2(L, 1u, 0u, p, stream_u01(c.raw[2 * S + 2 * p]), stream_u01(c.raw[2 * S + 2 * p + 1]), &x, &y);
-            rec[2] = x;
-            rec[3] = y;
-        }
-        uint32_t col1 = 0;   // running 1D slot
-        for (uint32_t r = 0; r < L.nr1; ++r) {
-            const uint32_t n = L.r1n[r];
-            const float strata = 1.0f / static_cast<float>(n);
-            const float sub = strata / static_cast<int>(S);
-            for (uint32_t i = 0; i < L.r1c[r]; ++i)
-                for (uint32_t j = 0; j < n; ++j, ++col1) {
-                    const uint32_t p = c.perm[(1u + col1) * S + k];
-                    const float off = static_cast<int>(p) + stream_u01(c.raw[4 * S + col1 * S + p]);
-                    rec[4 + col1] = j * strata + off * sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
-                }
-        }
-        uint32_t col2 = 0;   // running 2D slot
-        for (uint32_t r = 0; r < L.nr2; ++r) {
-            const uint32_t n = L.r2n[r];
-            for (uint32_t i = 0; i < L.r2c[r]; ++i)
-                for (uint32_t j = 0; j < n; ++j, ++col2) {
-                    const uint32_t p = c.perm[(1u + L.F1 + col2) * S + k];
-                    const uint32_t e = 4 * S + L.F1 * S + 2 * (col2 * S + p);
-                    float x, y;
-                    stream_strat2(L, n, j, p, stream_u01(c.raw[e]), stream_u01(c.raw[e + 1]), &x, &y);
-                    rec[4 + L.F1 + 2 * col2] = x;
-                    rec[4 + L.F1 + 2 * col2 + 1] = y;
-                }
-        }
-        // per-sample shuffles inside each pattern (:185-196); a one-slot pattern swaps its slot with itself
         const uint32_t* us = uper + static_cast<size_t>(k) * (L.F1 + L.F2);
         uint32_t off1 = 0;
         for (uint32_t r = 0; r < L.nr1; ++r) {
