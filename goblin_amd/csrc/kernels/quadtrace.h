@@ -308,6 +308,8 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                     trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                     if (STATS) ++steps;
                 }
+                // (a second leaf / instance step behind the interior one -- three steps per iteration -- was measured: 44.7 against
+                //  42.0 ms on configs[1], 74.6 against 69.0 on the Cornell box)
             }
 #endif
         }
