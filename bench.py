@@ -73,7 +73,7 @@ LEAN_KERNELS = {("path", "megakernel"): "void path_trace_kernel<0, false, false,
                 ("ao", "megakernel"): "void ao_kernel<0, false, false, true, false>(DevScene, RenderArgs)"}
 
 
-def pmc_for(workload, schedule, integrator):
+def pmc_for(workload, schedule, integrator, frame_spp=None):
     """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_<workload>_<schedule>.json,
     written by tools/summarize_profile.py from tools/profile_gpu.sh's passes) -- only if they were collected from THIS source
     tree (the stamp is recorded on the GPU box at collection time)."""
@@ -86,6 +86,11 @@ def pmc_for(workload, schedule, integrator):
     stamp = build.source_stamp()
     if d.get("source_stamp") != stamp:
         return None, "%s was collected from source stamp %s, this tree is %s" % (os.path.basename(path), d.get("source_stamp"), stamp)
+    # a frame profiled at fewer samples per pixel (the Cornell and AO frames take seconds per pass at full size): the same
+    # kernels over the same window, so the extensive counters and the kernel time scale with the samples; the ratios do not
+    factor = 1.0
+    if d.get("spp_profiled") and frame_spp and d["spp_profiled"] != frame_spp:
+        factor = frame_spp / float(d["spp_profiled"])
     keys = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES",
             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_INSTS_LDS")
     if schedule == "wavefront":
@@ -104,12 +109,16 @@ def pmc_for(workload, schedule, integrator):
                     agg[key] = agg.get(key, 0.0) + c[key] * per_render
             agg["kernel_avg_ms"] = agg.get("kernel_avg_ms", 0.0) + c.get("kernel_avg_ms", 0.0) * per_render
         if agg.get("SQ_INSTS_VALU"):
-            return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp), None
+            agg = {k: v * factor for k, v in agg.items()}
+            return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp,
+                        scaled_from_spp=d.get("spp_profiled") if factor != 1.0 else None), None
         return None, "no wavefront kernels in %s" % os.path.basename(path)
     name = LEAN_KERNELS.get((integrator, schedule))
     c = d.get("counters_per_launch", {}).get(name)
     if c:
-        return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp), None
+        c = {k: (v * factor if isinstance(v, (int, float)) and k in keys + ("kernel_avg_ms",) else v) for k, v in c.items()}
+        return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp,
+                    scaled_from_spp=d.get("spp_profiled") if factor != 1.0 else None), None
     return None, "no kernel %r in %s" % (name, os.path.basename(path))
 
 
@@ -155,7 +164,8 @@ def roofline_object(counted, kernel_ms, pmc, pmc_note, kernel_label, waves_per_s
         issue = {"valu_wave_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]), "achieved_g_wave_instructions_per_s": round(ach_i, 1),
                  "cycles_per_instruction_per_simd": round(SIMDS * clock_hz * sec / pmc["SQ_INSTS_VALU"], 3),
                  "clock_ghz_pmc": round(clock_hz * 1e-9, 3),
-                 "pmc": {"file": pmc["file"], "source_stamp": pmc["source_stamp"], "kernel": pmc["kernel"], "kernel_avg_ms_rocprof": pmc["kernel_avg_ms"]}}
+                 "pmc": {"file": pmc["file"], "source_stamp": pmc["source_stamp"], "kernel": pmc["kernel"], "kernel_avg_ms_rocprof": pmc["kernel_avg_ms"],
+                         "scaled_from_spp": pmc.get("scaled_from_spp")}}
         if "TCC_HIT_sum" in pmc:
             issue["l2_hit_rate"] = round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4)
         if pmc.get("SQ_WAVE_CYCLES"):
@@ -422,7 +432,7 @@ def one_config(name, device_index, seed, torch):
     counted = counters_of(wl, seed, None, resolved, scale_from_spp=64 if wl.scene.spp() > 256 else None)
     paths = counted["paths"]
     rays = counted["extension_rays"] + counted["shadow_rays"]
-    pmc, note = pmc_for(name, resolved, wl.integrator)
+    pmc, note = pmc_for(name, resolved, wl.integrator, wl.scene.spp())
     roof = roofline_object({k: v for k, v in counted.items() if not k.startswith("_")}, kernel_ms, pmc, note, wl.kernel_label(resolved),
                            waves_per_simd=5 if resolved == "wavefront" else 3)
     out = {"workload": wl.describe(), "schedule": resolved, "steps": 1, "ms_per_step": round(ms, 2), "kernel_ms": round(kernel_ms, 2),
@@ -527,7 +537,7 @@ def main():
         timings = tracer.timings(args.steps * len(wl.bands))                      # HIP events inside the library, per kernel class and call
         main_ms = [x[0] for x in timings] or call_ms
         avg_kernel_ms = sum(main_ms) / args.steps if timings else sum(main_ms) / len(main_ms)   # per step (a step is len(bands) calls)
-        pmc, pmc_note = (pmc_for(wl_name, resolved, wl.integrator) if (wl.standard and world == 1) else (None, "non-standard run: no counters quoted"))
+        pmc, pmc_note = (pmc_for(wl_name, resolved, wl.integrator, scene.spp()) if (wl.standard and world == 1) else (None, "non-standard run: no counters quoted"))
         rays = counted["extension_rays"] + counted["shadow_rays"]
         value = job_paths * args.steps / elapsed * 1e-6
         roofline = roofline_object(counted, avg_kernel_ms, pmc, pmc_note, wl.kernel_label(resolved), waves_per_simd=5 if resolved == "wavefront" else 3)

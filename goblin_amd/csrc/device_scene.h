@@ -90,6 +90,12 @@ struct DevInstance {
 struct DevInstanceBound {
     float lo[3], hi[3];
 };
+// Triangle::getObjectBound (the three vertices' bound): the reference BLAS's leaf box, one triangle per leaf.  Indexed like
+// tri_shade (DevTri::shade); read by the TIES builds only (ref_reached / ref_leaf_reached, kernels/trace.h).
+struct DevTriBound {
+    float lo[3], hi[3];
+    float pad[2];
+};
 // IntersectFilter of a scene query (GoblinPathtracer.cpp:5-11): none, isOpaque (skip masks), notOpaque (masks only)
 #define GBL_FILTER_NONE 0
 #define GBL_FILTER_OPAQUE 1
@@ -207,6 +213,7 @@ struct DevScene {
     const DevNode* nodes;
     const DevTri* tris;
     const DevTriShade* tri_shade;
+    const DevTriBound* tri_bounds;
     const DevTriOrder* tri_order;   // per original triangle id (DevTri::shade); null: ties fall to the device's own order
     const float* positions;         // 3 per vertex, as given: the reference's leaf boxes in a tie (trace.h tie_goes_to)
     const float* normals;    // 3 per vertex

@@ -476,6 +476,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     }
     ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if ((st = upload(ctx, packed.tri_shade, &sc.tri_shade)) != GBL_OK) return bail(st);
+    if ((st = upload(ctx, packed.tri_bounds, &sc.tri_bounds)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.tri_order, &sc.tri_order)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.instance_bounds, &sc.instance_bounds)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.positions, &sc.positions)) != GBL_OK) return bail(st);
@@ -1112,12 +1113,11 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         }
         // kernels/quadtrace.h: sparse interior steps run four lanes per ray; per-sample radiance only, the quads' records take
         // the LDS film tile's place.  Its LDS need differs from the film-tile formula checked above: checked again here, and a
-        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.  The lean kernels of the native sampler only:
-        // the EXT builds are slower under it, and the builds that follow the reference's tie rule and reachability test (replay,
-        // exact_ties, instrumented) run one ray per lane, where ref_reached applies (trace.h).
-        if (!stream_mode && defer && !ext && !replay && !want_stats && p->exact_ties == 0 && quad_wanted()) {
+        // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.  The lean kernels of the native sampler only
+        // (with or without exact_ties): the EXT builds are slower under it, replay and instrumented renders are not timed.
+        if (!stream_mode && defer && !ext && !replay && !want_stats && quad_wanted()) {
             const size_t lds_quad = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            gbl_render_kernel k_quad = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_quad() : (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_quad() : nullptr);
+            gbl_render_kernel k_quad = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_quad(p->exact_ties != 0) : (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_quad(p->exact_ties != 0) : nullptr);
             if (k_quad && lds_quad <= 160 * 1024) {
                 kernel = k_quad;
                 lds = lds_quad;

@@ -85,8 +85,8 @@ typedef void (*gbl_li_kernel)(DevScene, RenderArgs, float4*);
 gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext, bool exact_ties = false);
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext, bool exact_ties = false);
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
-gbl_render_kernel gbl_kernel_path_quad(void);
-gbl_render_kernel gbl_kernel_ao_quad(void);
+gbl_render_kernel gbl_kernel_path_quad(bool exact_ties);
+gbl_render_kernel gbl_kernel_ao_quad(bool exact_ties);
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);

@@ -19,21 +19,21 @@
 // faster -- two LDS round trips per run on a chain that is latency bound once the VALU work shrinks.)  LDS operations of
 // one wave execute in order, so the slab and the foreign stack columns need no barrier, only compiler fences.
 //
-// TIES builds (replay / instrumented) keep the reference's exact-t tie rule here -- a leaf whose triangles tie, with one another
-// or with the hit the ray holds, falls back to trav_other's own loop -- but NOT its reachability test (ref_reached, trace.h): the
-// library runs those builds one ray per lane by default (gbl_api.hip), where it applies; GBL_MK_QUAD=1 forces them through
-// here for the bit-identity tests.  (With ref_reached compiled into this file's loops one replayed sample of bunny.json at
-// 160^2 x 16 spp came out on the other side of an exact tie -- at -O3 only, not at -O1, not with a printf beside it, not in
-// trace()'s loop: not understood, so the test stays where it is verified.)
+// TIES builds (`exact_ties` under the native sampler) keep the reference's exact-t tie rule and its reachability test
+// (ref_reached, trace.h) here: a leaf whose triangles tie, with one another or with the hit the ray holds, falls back to
+// trav_other's own loop; a triangle the quad's lane accepts is checked against the reference's box tests before it counts.  The
+// query's own maxt (TravState::maxt0), which that test needs, travels in the record like the rest of the ray.  (For a round it did
+// not -- a quad's lanes read whatever their own registers held, uninitialised ones in lanes without a ray -- and one replayed
+// sample of bunny.json flipped at -O3 only; the test was kept out of this file until that was found.)
 #pragma once
 #include "trace.h"
 
 #ifndef GBL_QUAD_MAX
 #define GBL_QUAD_MAX 16           // rays that migrate: 64 lanes / 4
 #endif
-// record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8)
+// record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8) | maxt0
 // result (written by the quad's first lane when the ray is done): words 0-5 = hit.inst hit.tri hit.b1 hit.b2 hit.t occluded, 12 = steps
-#define GBL_QUAD_REC_WORDS 21
+#define GBL_QUAD_REC_WORDS 22
 #define GBL_QUAD_LDS_WORDS ((GBL_BLOCK / 64) * 16 * GBL_QUAD_REC_WORDS)
 
 template <int CTRL>
@@ -141,8 +141,8 @@ __device__ __forceinline__ void quad_interior(TravState& st, const QuadLane& ql,
 // when a distance is NaN (which trav_other's loop accepts).  Those leaves (a handful per 10^7 paths) are left untouched and
 // *redo is set: the caller runs trav_other's own loop on them; every other leaf gives what that loop would.
 template <bool ANY, bool STATS, bool TIES = false>
-__device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded, uint4 w0, uint4 w1, uint4 w2,
-                                          uint32_t popped, bool* redo = nullptr) {
+__device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded, uint4 w0, uint4 w1,
+                                          uint4 w2, uint32_t popped, const gbl_lds_u32* wrec, bool* redo = nullptr) {
     const uint32_t ref = ~static_cast<uint32_t>(st.cur);
     const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
     float t = INFINITY, b1 = 0.0f, b2 = 0.0f;
@@ -154,6 +154,9 @@ __device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, Lan
         float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), 0.0f);
         tri_fetch_together(q0, q1, q2);   // one memory round trip (trace.h)
         ok = tri_test_regs(q0, q1, q2, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2);
+        if (TIES && ok)   // would the reference's traversal get to this triangle (trace.h)?  w0.w = DevTri::shade
+            ok = ref_reached(sc, st.inst, w0.w, f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])),
+                             f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])), st.r.o, st.r.d, st.mint, st.maxt0);
     }
     const float tq = ok ? t : INFINITY;
     float m = fminf(tq, quad_dpp_f<GBL_QP_XOR1>(tq));
@@ -244,7 +247,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         st.sp = 0;
         st.cur = GBL_STACK_EXIT;
         st.inst = -1;
-        st.mint = st.maxt = 0.0f;
+        st.mint = st.maxt = st.maxt0 = 0.0f;
         st.hit.t = INFINITY;
         st.hit.inst = -1;
         st.hit.tri = 0;
@@ -284,7 +287,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 }
                 if (!at_int) {
                     const unsigned long long b0 = __builtin_amdgcn_s_memtime();
-                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES, false, false>(sc, st, stk, cnt, &occluded, filter);
+                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, stk, cnt, &occluded, filter);
                     asm volatile("" ::"v"(st.cur), "v"(st.sp));
                     cnt.pc[12] += __builtin_amdgcn_s_memtime() - b0;
                     cnt.pc[14] += 1;
@@ -300,10 +303,10 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                     trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                     if (STATS) ++steps;
                 } else {
-                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES, false, false>(sc, st, stk, cnt, &occluded, filter);
+                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, stk, cnt, &occluded, filter);
                 }
             } else {
-                if (!trav_at_interior(st)) done = trav_other<ANY, STATS, EXT, LdsStack, TIES, true, false>(sc, st, stk, cnt, &occluded, filter);
+                if (!trav_at_interior(st)) done = trav_other<ANY, STATS, EXT, LdsStack, TIES, true>(sc, st, stk, cnt, &occluded, filter);
                 if (!done && trav_at_interior(st)) {
                     trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                     if (STATS) ++steps;
@@ -340,6 +343,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             rec[16] = static_cast<uint32_t>(st.hit.inst); rec[17] = st.hit.tri;
             rec[18] = __float_as_uint(st.hit.b1); rec[19] = __float_as_uint(st.hit.b2);
             rec[20] = static_cast<uint32_t>(st.sp) | (lane << 8);
+            if (TIES) rec[21] = __float_as_uint(st.maxt0);
         }
         quad_fence();
         const bool qlive = q < nl;
@@ -361,6 +365,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             st.inst = static_cast<int>(qrec[15]);
             st.mint = __uint_as_float(qrec[12]);
             st.maxt = __uint_as_float(qrec[13]);
+            if (TIES) st.maxt0 = __uint_as_float(qrec[21]);
             st.cur = static_cast<int>(qrec[14]);
             st.hit.inst = static_cast<int>(qrec[16]);
             st.hit.tri = qrec[17];
@@ -412,10 +417,10 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 const uint4 w0 = tp[0], w1 = tp[1], w2 = tp[2];
                 const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
                 bool redo = false;
-                qdone = quad_leaf<ANY, STATS, TIES>(st, ql, cnt, &qocc, w0, w1, w2, popped, &redo);
+                qdone = quad_leaf<ANY, STATS, TIES>(sc, st, ql, cnt, &qocc, w0, w1, w2, popped, qrec + 6, &redo);
                 if (TIES && !ANY && redo) {   // an exact tie in this leaf: the reference's rule, in trav_other's own loop
                     if (STATS && ql.c == 0u) cnt.tris -= (lref & 3u) + 1u;
-                    qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES, false, false>(sc, st, qstk, cnt, &qocc, filter);
+                    qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, qstk, cnt, &qocc, filter, qrec + 6);
                 }
             } else if (st.cur == GBL_STACK_SENTINEL || (st.cur < 0 && st.inst < 0)) {
                 quad_transition<STATS, EXT>(sc, st, qstk, qrec, cnt, filter);
@@ -423,7 +428,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 qdone = true;
                 (void)qstk;
             } else {   // the exit marker; analytic shapes; any-hit leaves of the instrumented builds
-                qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES, false, false>(sc, st, qstk, cnt, &qocc, filter);
+                qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, qstk, cnt, &qocc, filter, qrec + 6);
             }
 #ifdef GBL_PHASE_CLOCK
             {   // wave-level: the iteration's time goes to the kind of the wave's first live quad

@@ -193,6 +193,14 @@ __device__ __forceinline__ void flush_tile(const DevFilm& film, float* tile, int
 
 // Grab the next path index of this work item for every idle lane of the wave:
 // one LDS atomic per wave, prefix popcount for the lane's offset.
+// (Round 3 measured a barrier-free alternative for the quad kernels -- two work items in flight per workgroup as 64-bit
+//  {item, next path} LDS words, refilled under a per-slot lock while the other slot keeps feeding the waves, no drain and no
+//  barrier between items: Cornell 512^2 x 64 spp 69.1 -> 63.4 ms, the grid unchanged, configs[1] 42.1 -> 44.6 ms.  Items that
+//  start together keep the four waves of a workgroup on neighbouring pixels of one tile, which the short paths of configs[1]
+//  are worth more than their drains; the long-path scenes that gain run the wavefront schedule anyway.  Not kept.
+//  Nor were per-CU item lists: blocks b, b + 256, b + 512 of the persistent grid share a CU (tools/placement.py reads HW_REG_HW_ID),
+//  so a list per blockIdx % 256 puts a CU's twelve waves on the same tiles -- no gain on the Cornell box, the grid or AO, and
+//  configs[1] 42.8 -> 60.5 ms from the static split's imbalance (bunny tiles against background tiles).)
 __device__ __forceinline__ int wave_fetch(bool want, uint32_t* next_path) {
     unsigned long long mask = __ballot(want);
     if (mask == 0ull) return -1;

@@ -305,14 +305,6 @@ __device__ __forceinline__ bool disk_test(float radius, F3 o, F3 d, float mint, 
 // ray enters exactly AT the hit point (the hit is a corner or an edge of the triangle's bound) is skipped and the
 // earlier triangle stays.
 // static intersect(bbox, ray, invDir, dirIsNeg), GoblinBVH.cpp:156-187: the reference's node test
-__device__ __forceinline__ bool ref_box_reached(F3 lo, F3 hi, F3 o, F3 d, float mint, float maxt);
-__device__ __forceinline__ bool ref_leaf_reached(const DevScene& sc, uint32_t tri, F3 o, F3 d, float mint, float maxt) {
-    const DevTriShade sh = sc.tri_shade[sc.tris[tri].shade];
-    const F3 a = load3(sc.positions + 3 * sh.v[0]), b = load3(sc.positions + 3 * sh.v[1]), c = load3(sc.positions + 3 * sh.v[2]);
-    const F3 lo = f3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
-    const F3 hi = f3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
-    return ref_box_reached(lo, hi, o, d, mint, maxt);
-}
 __device__ __forceinline__ bool ref_box_reached(F3 lo, F3 hi, F3 o, F3 d, float mint, float maxt) {
     const F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float tmin = ((d.x < 0.0f ? hi.x : lo.x) - o.x) * inv.x;
@@ -329,22 +321,38 @@ __device__ __forceinline__ bool ref_box_reached(F3 lo, F3 hi, F3 o, F3 d, float 
     if (tzmax < tmax) tmax = tzmax;
     return tmin < maxt && tmax > mint;
 }
-// true: `cand` replaces the current hit `cur` (both accepted at t)
-__device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, uint32_t cand, F3 o, F3 d, float mint, float t) {
-    const DevTriOrder a = sc.tri_order[sc.tris[cur].shade], b = sc.tri_order[sc.tris[cand].shade];
+__device__ __forceinline__ bool ref_leaf_reached(const DevScene& sc, uint32_t tri, F3 o, F3 d, float mint, float maxt) {
+    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + sc.tris[tri].shade);
+    const float4 b0 = bp[0], b1 = bp[1];
+    return ref_box_reached(f3(b0.x, b0.y, b0.z), f3(b0.w, b1.x, b1.y), o, d, mint, maxt);
+}
+// true: `cand` replaces the current hit `cur` (both accepted at t).
+// A function of its own, not inlined (plain pointers and floats: no DevScene to materialise for the call).  Inlined into the quad
+// queries' leaf loop (quadtrace.h) the same code decided 114 of 6.8e7 Cornell samples the other way at -O3 -- not with a printf
+// beside it, not in trace()'s loop, not out of line -- which cost a round of keeping the tie rule out of the quads; a cold call
+// site is also the better place for it: a handful of ties per 10^7 paths.
+static __device__ __attribute__((noinline)) bool tie_goes_to_impl(const DevTri* tris, const DevTriOrder* tri_order, const DevTriBound* tri_bounds, uint32_t cur,
+                                                           uint32_t cand, float ox, float oy, float oz, float dx, float dy, float dz, float mint, float t) {
+    const uint32_t sa = tris[cur].shade, sb = tris[cand].shade;
+    const DevTriOrder a = tri_order[sa], b = tri_order[sb];
     const uint32_t da = a.depth_rank & 0xffu, db = b.depth_rank & 0xffu;
     const uint32_t common = min(da, db);
     const uint32_t x = (a.path ^ b.path) & (common >= 32u ? 0xffffffffu : ((1u << common) - 1u));
     if (x == 0u) return (b.depth_rank >> 8) > (a.depth_rank >> 8);   // one leaf: its triangles are tested in order
     const uint32_t l = static_cast<uint32_t>(__ffs(static_cast<int>(x))) - 1u;
     const uint32_t axis = l < 16u ? (a.axes_lo >> (2u * l)) & 3u : (a.axes_hi >> (2u * (l - 16u))) & 3u;
-    const float dc = axis == 0u ? d.x : (axis == 1u ? d.y : d.z);
+    const float dc = axis == 0u ? dx : (axis == 1u ? dy : dz);
     const bool near_is_second = dc < 0.0f;                 // dirIsNeg[axis]: the second child is entered first
     const bool cand_in_second = ((b.path >> l) & 1u) != 0u;
     const bool cand_is_later = cand_in_second != near_is_second;   // the far child is visited later
     // the later one wins if its leaf is reached with maxt == t; its single-triangle leaf's box is the triangle's bound
-    if (cand_is_later) return ref_leaf_reached(sc, cand, o, d, mint, t);
-    return !ref_leaf_reached(sc, cur, o, d, mint, t);
+    const float4* bp = reinterpret_cast<const float4*>(tri_bounds + (cand_is_later ? sb : sa));
+    const float4 b0 = bp[0], b1 = bp[1];
+    const bool reached = ref_box_reached(f3(b0.x, b0.y, b0.z), f3(b0.w, b1.x, b1.y), f3(ox, oy, oz), f3(dx, dy, dz), mint, t);
+    return cand_is_later ? reached : !reached;
+}
+__device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, uint32_t cand, F3 o, F3 d, float mint, float t) {
+    return tie_goes_to_impl(sc.tris, sc.tri_order, sc.tri_bounds, cur, cand, o.x, o.y, o.z, d.x, d.y, d.z, mint, t);
 }
 
 // Would the reference's own traversal get to test this triangle at all?  Its box tests are not watertight (static
@@ -357,10 +365,9 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 __device__ __forceinline__ bool ref_reached(const DevScene& sc, int inst, uint32_t shade, F3 wo, F3 wd, F3 oo, F3 od, float mint, float maxt0) {
     const DevInstanceBound wb = sc.instance_bounds[inst];
     if (!ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), wo, wd, mint, maxt0)) return false;
-    const DevTriShade sh = sc.tri_shade[shade];
-    const F3 a = load3(sc.positions + 3 * sh.v[0]), b = load3(sc.positions + 3 * sh.v[1]), c = load3(sc.positions + 3 * sh.v[2]);
-    const F3 lo = f3(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
-    const F3 hi = f3(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + shade);
+    const float4 b0 = bp[0], b1 = bp[1];
+    const F3 lo = f3(b0.x, b0.y, b0.z), hi = f3(b0.w, b1.x, b1.y);
     return ref_box_reached(lo, hi, oo, od, mint, maxt0);
 }
 
@@ -377,9 +384,7 @@ __device__ __forceinline__ bool ref_reached(const DevScene& sc, int inst, uint32
 // of spending an iteration of the caller's loop on each (needs st.world: the one-ray-per-lane loops only).
 // `wrec`: where the WORLD ray's origin and direction wait (6 words) when the caller does not keep st.world (the quads' records,
 // kernels/quadtrace.h); null: st.world.
-// REACH: apply ref_reached (one-ray-per-lane loops of the TIES builds; the quad kernels' queries keep the tie rule only, see
-// kernels/quadtrace.h).
-template <bool STATS, bool EXT, class STK, bool TIES, bool FUSE = false, bool REACH = true>
+template <bool STATS, bool EXT, class STK, bool TIES, bool FUSE = false>
 __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, const bool ANY,
                                                 bool* occluded, int filter, const gbl_lds_u32* wrec = nullptr) {
     const int cur = st.cur;
@@ -411,7 +416,7 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         if (STATS) cnt.tris += 1;
         bool got = first == GBL_SHAPE_FIRST_SPHERE ? sphere_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t)
                                                    : disk_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t);
-        if (TIES && REACH && got) {   // the TLAS leaf box in front of the shape (ref_reached)
+        if (TIES && got) {   // the TLAS leaf box in front of the shape (ref_reached)
             const F3 wo = wrec ? f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])) : st.world.o;
             const F3 wd = wrec ? f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])) : st.world.d;
             const DevInstanceBound wb = sc.instance_bounds[st.inst];
@@ -435,7 +440,7 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         float t, b1, b2;
         if (STATS) cnt.tris += 1;
         if (tri_test(sc.tris + first + i, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2)) {
-            if (TIES && REACH) {
+            if (TIES) {
                 const F3 wo = wrec ? f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])) : st.world.o;
                 const F3 wd = wrec ? f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])) : st.world.d;
                 if (!ref_reached(sc, st.inst, sc.tris[first + i].shade, wo, wd, st.r.o, st.r.d, st.mint, st.maxt0)) continue;
@@ -468,10 +473,10 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
     }
     return false;
 }
-template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true, bool FUSE = false, bool REACH = true>
+template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true, bool FUSE = false>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
                                            int filter = GBL_FILTER_NONE, const gbl_lds_u32* wrec = nullptr) {
-    return trav_other_kind<STATS, EXT, STK, TIES, FUSE, REACH>(sc, st, stk, cnt, ANY, occluded, filter, wrec);
+    return trav_other_kind<STATS, EXT, STK, TIES, FUSE>(sc, st, stk, cnt, ANY, occluded, filter, wrec);
 }
 
 __device__ __forceinline__ bool trav_at_interior(const TravState& st) {

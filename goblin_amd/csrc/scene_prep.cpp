@@ -719,6 +719,24 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
                         gm.tri_count, out->tri_order.data() + gm.tri_offset);
     }
 
+    // ---- every triangle's own bound (the reference BLAS's leaf boxes, DevTriBound)
+    out->tri_bounds.assign(d->num_triangles, DevTriBound());
+    for (uint32_t mi = 0; mi < d->num_meshes; ++mi) {
+        const gbl_mesh& gm = d->meshes[mi];
+        if (gm.shape != GBL_SHAPE_MESH) continue;
+        const float* P = d->positions + 3 * static_cast<size_t>(gm.vertex_offset);
+        const uint32_t* I = d->indices + 3 * static_cast<size_t>(gm.tri_offset);
+        for (uint32_t t = 0; t < gm.tri_count; ++t) {
+            DevTriBound& b = out->tri_bounds[gm.tri_offset + t];
+            memset(&b, 0, sizeof(b));
+            const float *a = P + 3 * I[3 * t], *bb = P + 3 * I[3 * t + 1], *c = P + 3 * I[3 * t + 2];
+            for (int k = 0; k < 3; ++k) {
+                b.lo[k] = std::min(std::min(a[k], bb[k]), c[k]);
+                b.hi[k] = std::max(std::max(a[k], bb[k]), c[k]);
+            }
+        }
+    }
+
     // ---- one BLAS per mesh
     const int kBlasCap = 40;
     std::vector<int32_t> mesh_root(d->num_meshes);

@@ -10,6 +10,7 @@ struct PackedScene {
     std::vector<DevNode> nodes;
     std::vector<DevTri> tris;
     std::vector<DevTriShade> tri_shade;
+    std::vector<DevTriBound> tri_bounds;
     std::vector<DevInstanceBound> instance_bounds;
     std::vector<DevTriOrder> tri_order;
     std::vector<float> positions;         // 3 per vertex

@@ -397,26 +397,30 @@ def test_auto_schedule_goes_by_path_length(golden, torch):
 def test_quad_per_ray_megakernel_is_bit_identical(torch, monkeypatch):
     """kernels/quadtrace.h: once at most 16 rays of a wave are unfinished each migrates to a quad of lanes (one child box per
     lane, the sorting network on DPP, one triangle per lane at a leaf) -- what the lean megakernel and AO kernel of the native
-    sampler run; GBL_MK_QUAD=0 selects their one-ray-per-lane builds.  A ray's sequence of node visits is the same either way:
-    per-sample radiance bit for bit, path tracer and AO, and both equal the oracle on the same counter-based samples (exact-t
-    ties aside, which neither lean build resolves: none at these sizes)."""
+    sampler run, with and without `exact_ties`; GBL_MK_QUAD=0 selects their one-ray-per-lane builds.  A ray's sequence of node
+    visits is the same either way: per-sample radiance bit for bit, path tracer and AO, and both equal the oracle on the same
+    counter-based samples (the plain lean build: exact-t ties aside, of which there are none at these sizes; the exact_ties
+    build follows the reference's tie rule and reachability test inside the quads too -- the query's own maxt travels in the
+    quad's record, whose absence once flipped a sample of the 160x160 case)."""
     from goblin_amd.renderer import HipPathTracer
     cases = [("bunny", gs.config_overrides(resolution=(96, 96), spp=16, depth=8)),
+             ("bunny", gs.config_overrides(resolution=(160, 160), spp=16, depth=8)),
              ("cornell", gs.config_overrides(resolution=(48, 48), spp=16, depth=12)),
              ("grid", gs.config_overrides(resolution=(64, 64), spp=4, depth=5)),
              ("bunny", gs.config_overrides(resolution=(96, 96), spp=4, method="ao", ao_samples=9)),
              ("grid", gs.config_overrides(resolution=(64, 64), spp=4, method="ao", ao_samples=9))]
     for name, ov in cases:
         scene = gs.load_scene(name, ov)
-        monkeypatch.setenv("GBL_MK_QUAD", "0")
-        ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        monkeypatch.delenv("GBL_MK_QUAD")
-        got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel")
-        np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
-        np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
         o = ob.Oracle(scene)
         li_ref, _ = o.li_replay(o.native_samples(13), threads=4)
-        assert helpers.li_mismatch_fraction(got["li"].cpu().numpy(), li_ref) == 0.0
+        for exact in (False, True):
+            monkeypatch.setenv("GBL_MK_QUAD", "0")
+            ref = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel", exact_ties=exact)
+            monkeypatch.delenv("GBL_MK_QUAD")
+            got = HipPathTracer(scene, 0).render(seed=13, want_li=True, schedule="megakernel", exact_ties=exact)
+            np.testing.assert_array_equal(got["li"].cpu().numpy().view(np.uint32), ref["li"].cpu().numpy().view(np.uint32))
+            np.testing.assert_allclose(got["film"].numpy(), ref["film"].numpy(), rtol=1e-5, atol=1e-6)
+            assert helpers.li_mismatch_fraction(got["li"].cpu().numpy(), li_ref) == 0.0
 
 
 def test_exact_stack_entries_hold_every_ray(torch):
@@ -700,6 +704,10 @@ def test_full_size_properties_on_the_cornell_config(torch):
     print("lean vs tie-exact wavefront: differing samples", differing, "of", li_wf.shape[0])
     assert differing <= 1e-5 * li_wf.shape[0]
     del li_wf
+    # ... under both schedules (the megakernel's exact build applies both rules inside its quad queries, quadtrace.h)
+    mk_exact = r.render(seed=seed, want_li=True, schedule="megakernel", exact_ties=True)["li"]
+    assert torch.equal(mk_exact, exact)
+    del mk_exact
     # (block (100, 500) holds the sample this test found: a ray that grazes the mirror block's vertical edge, accepted by the triangle
     #  test's 1e-7 slack and never reached by the reference's unpadded box tests -- ref_reached, trace.h)
     _oracle_blocks(scene, r, exact, seed, ((100, 500), (520, 640), (500, 40)), 8, 8)

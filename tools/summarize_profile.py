@@ -36,7 +36,11 @@ if stamp is None:
 if stamp != build.source_stamp():
     print("warning: counters were collected from source stamp %s, this tree is %s -- the summary keeps the COLLECTED stamp, bench.py will not quote it" %
           (stamp, build.source_stamp()), file=sys.stderr)
+import re
+m_spp = re.search(r"--spp (\d+)", cmd)
 summary = {"name": name, "source_stamp": stamp,
+           # (a frame profiled at fewer samples per pixel than its BASELINE size: bench.py scales the extensive counters)
+           "spp_profiled": int(m_spp.group(1)) if m_spp else None,
            "command": "tools/profile_gpu.sh %s %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group)" % (tag, cmd),
            "workload": what,
            "kernel_avg_ms": {r["Name"]: round(float(r["AverageNs"]) * 1e-6, 4) for r in rows if float(r["Percentage"]) > 0.05},
