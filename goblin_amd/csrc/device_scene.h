@@ -23,7 +23,7 @@
 #define GBL_EXT_WAVES 2         // waves per SIMD the EXT instantiations of the persistent kernels are compiled for (256 registers)
 #endif
 #define GBL_MAX_FILTER_HALO 6   // LDS film tile is (8 + 2*halo)^2 pixels
-#define GBL_STREAM_LDS_WORDS 640   // GBL_SAMPLES_STREAM: 624 mt19937 state words + cursor, padded (kernels/stream.h)
+#define GBL_STREAM_LDS_WORDS 1248   // GBL_SAMPLES_STREAM: two blocks of 624 mt19937 state words (kernels/stream.h)
 #define GBL_WHITTED_MAX_DEPTH 12   // frames of the Whitted kernel's explicit recursion (kernels/whitted.h)
 
 // child reference: >= 0 interior node index; < 0 leaf: ~ref = (first << 2) | (count - 1)

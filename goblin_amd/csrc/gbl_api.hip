@@ -1115,9 +1115,14 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         // the LDS film tile's place.  Its LDS need differs from the film-tile formula checked above: checked again here, and a
         // scene whose stacks only fit the one-ray-per-lane kernel keeps that one.  The lean kernels of the native sampler only
         // (with or without exact_ties): the EXT builds are slower under it, replay and instrumented renders are not timed.
-        if (!stream_mode && defer && !ext && !replay && !want_stats && quad_wanted()) {
-            const size_t lds_quad = (gbl_quad_lds_words() + 4) * sizeof(uint32_t) + static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            gbl_render_kernel k_quad = p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_quad(p->exact_ties != 0) : (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_quad(p->exact_ties != 0) : nullptr);
+        if (defer && !ext && (stream_mode || !replay) && !want_stats && quad_wanted()) {
+            // (stream mode: the shuffles' LDS region, at least the stacks', and the generator's state come on top)
+            const size_t stack_bytes = stream_mode ? static_cast<size_t>(ra.stream_lperm_words) * sizeof(uint32_t)
+                                                   : static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
+            const size_t lds_quad = (gbl_quad_lds_words() + 4 + (stream_mode ? GBL_STREAM_LDS_WORDS : 0)) * sizeof(uint32_t) + stack_bytes;
+            gbl_render_kernel k_quad = stream_mode ? (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_stream_quad() : nullptr)
+                                       : p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_quad(p->exact_ties != 0)
+                                       : (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_quad(p->exact_ties != 0) : nullptr);
             if (k_quad && lds_quad <= 160 * 1024) {
                 kernel = k_quad;
                 lds = lds_quad;
@@ -1143,9 +1148,14 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(tev[1], stream));
         if (phase_clock) {
-            unsigned long long h[24];
+            unsigned long long h[32];
             HIP_TRY(ctx, hipStreamSynchronize(stream));
             HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));
+            if (h[25] + h[26] + h[27] + h[28] + h[29]) {   // -DGBL_STREAM_TM: the stream sampler's phases in an un-instrumented build
+                const double tot = static_cast<double>(h[25] + h[26] + h[27] + h[28] + h[29]);
+                fprintf(stderr, "stream phases (share of the workgroups' time): emit %.1f%% permute %.1f%% assemble %.1f%% paths %.1f%% skip %.1f%%\n",
+                        100 * h[25] / tot, 100 * h[26] / tot, 100 * h[27] / tot, 100 * h[28] / tot, 100 * h[29] / tot);
+            }
             if (h[8]) {
                 const double k = static_cast<double>(h[8]);
                 fprintf(stderr, "phase clock (share of the waves' ticks): closest-hit query %.1f%% = dense %.1f%% + migrate %.1f%% + quad %.1f%% | any-hit query %.1f%% = dense "

@@ -86,6 +86,7 @@ gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext, bool exact_
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext, bool exact_ties = false);
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
 gbl_render_kernel gbl_kernel_path_quad(bool exact_ties);
+gbl_render_kernel gbl_kernel_path_stream_quad(void);
 gbl_render_kernel gbl_kernel_ao_quad(bool exact_ties);
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)

@@ -289,7 +289,7 @@ __device__ inline StreamVol stream_vol_scratch(const StreamCtx& scx, const Strea
     return v;
 }
 template <bool STATS, class STK>
-__device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, const StreamCtx& scx, const StreamLayout& slay, const StreamVol& sv,
+__device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, StreamCtx& scx, const StreamLayout& slay, const StreamVol& sv,
                                     uint32_t* ctrl, float4* li, const STK& stk, LaneCounters& cnt) {
     __syncthreads();
     if (sc.volume.hetero != 0u) {
@@ -332,9 +332,7 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
             const uint32_t skip = ctrl[1], total = ctrl[2], k1 = ctrl[3];
             __syncthreads();
             stream_emit(scx, nullptr, skip);
-            for (uint32_t t = threadIdx.x; t < GBL_MT_N; t += GBL_BLOCK) save[t] = scx.mt[t];
-            if (threadIdx.x == 0) save[GBL_MT_N] = *scx.pos;
-            __syncthreads();
+            mt_save(scx, save);
             stream_emit(scx, sv.raw, total);
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -360,9 +358,7 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
             __syncthreads();
             const uint32_t consumed = ctrl[2];
             __syncthreads();
-            for (uint32_t t = threadIdx.x; t < GBL_MT_N; t += GBL_BLOCK) scx.mt[t] = save[t];
-            if (threadIdx.x == 0) *scx.pos = save[GBL_MT_N];
-            __syncthreads();
+            mt_restore(scx, save);
             stream_emit(scx, nullptr, consumed);
             k0 = k1;
         }
@@ -430,6 +426,11 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, co
 #define GBL_SRC_STREAM 2
 // EXACT: the native sampler's lean kernels compile the reference's exact-t tie rule out (trace.h TIES: +2 ... 3 % on the BASELINE
 // scenes for the ~5 ties per 10^7 paths it decides); gbl_render_params.exact_ties selects the instantiations that keep it.
+#ifdef GBL_STREAM_TM   // measurement builds: the stream sampler's phase clock in every instantiation (tools/stream_probe.py)
+#define GBL_STREAM_TM_ON true
+#else
+#define GBL_STREAM_TM_ON false
+#endif
 template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     float* ftab = tile + 4 * tp * tp;
     uint32_t* ctrl = QUAD ? reinterpret_cast<uint32_t*>(smem) + GBL_QUAD_LDS_WORDS : reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
-    static_assert(!(QUAD && STREAM), "quad-per-ray steps are built for the native / replay samplers");
+    static_assert(!(QUAD && (EXT || STATS)), "quad-per-ray steps are built for the lean kernels");
     // QUAD: LDS = 16 records per wave | ctrl | stacks
     gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
     gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
@@ -454,15 +455,15 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     if constexpr (STREAM) {
         slay = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
         scx.mt = ctrl + 4;
-        scx.pos = ctrl + 4 + GBL_MT_N;
         scx.lperm = stack;
         scx.lperm_words = ra.stream_lperm_words;
         scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
-        scx.perm = scx.raw + slay.NF + slay.NU;
-        scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+        scx.cols = reinterpret_cast<DevStreamCol*>(scx.raw + slay.NF + slay.NU);
+        scx.recs = reinterpret_cast<float*>(scx.cols + slay.ncols);
     }
     StreamVol svol = {};   // STREAM with a participating medium (stream_medium_phase)
     if constexpr (STREAM) svol = stream_vol_scratch(scx, slay);
+    if constexpr (STREAM) stream_columns(scx, slay);
 
     LaneCounters cnt = {};
 #ifdef GBL_PHASE_CLOCK
@@ -504,11 +505,11 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             it.py0 = tile_item.py0 + sub / tile_item.tw;
             it.tw = it.th = 1;
             it.paths = ra.spp;
-            stream_generate_pixel(scx, slay, it.px0, it.py0, STATS ? stream_tm : nullptr);
+            stream_generate_pixel(scx, slay, it.px0, it.py0, (STATS || GBL_STREAM_TM_ON) ? stream_tm : nullptr);
             if (threadIdx.x == 0) ctrl[1] = ctrl[2] = 0u;
             stream_draws = 0;
             __syncthreads();
-            if (STATS) stream_t0 = wall_clock64();
+            if (STATS || GBL_STREAM_TM_ON) stream_t0 = wall_clock64();
         }
 
         PathState ps;
@@ -858,20 +859,20 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
             __syncthreads();
             const uint32_t drawn = ctrl[2];
             __syncthreads();
-            if (STATS) {
+            if (STATS || GBL_STREAM_TM_ON) {
                 const unsigned long long t1 = wall_clock64();
                 stream_tm[3] += t1 - stream_t0;
                 stream_t0 = t1;
             }
             stream_emit(scx, nullptr, drawn);
-            if (STATS) stream_tm[4] += wall_clock64() - stream_t0;
+            if (STATS || GBL_STREAM_TM_ON) stream_tm[4] += wall_clock64() - stream_t0;
         }
         }   // sub
         __syncthreads();
         if (!ra.li_defer) flush_tile(sc.film, tile, tx0, ty0, tp, ra.film);
     }
     if (STATS) accumulate_stats(ra, cnt, paths_done);
-    if (STATS && STREAM && threadIdx.x == 0)
+    if ((STATS || GBL_STREAM_TM_ON) && STREAM && threadIdx.x == 0)
         for (int i = 0; i < 5; ++i) atomicAdd(ra.stats + 25 + i, stream_tm[i]);
 #ifdef GBL_PHASE_CLOCK
     if (QUAD && !STATS && (threadIdx.x & 63) == 0) {   // measurement build: one lane per wave reports its phase ticks
@@ -907,15 +908,15 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     if constexpr (STREAM) {   // see path_trace_kernel; AORenderer::Li draws nothing from the tile's generator itself
         slay = stream_layout(ra.spp, ra.root, 0, 0, 0, ra.ao_n);
         scx.mt = ctrl + 4;
-        scx.pos = ctrl + 4 + GBL_MT_N;
         scx.lperm = stack;
         scx.lperm_words = ra.stream_lperm_words;
         scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
-        scx.perm = scx.raw + slay.NF + slay.NU;
-        scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+        scx.cols = reinterpret_cast<DevStreamCol*>(scx.raw + slay.NF + slay.NU);
+        scx.recs = reinterpret_cast<float*>(scx.cols + slay.ncols);
     }
     StreamVol svol = {};   // STREAM with a participating medium (stream_medium_phase)
     if constexpr (STREAM) svol = stream_vol_scratch(scx, slay);
+    if constexpr (STREAM) stream_columns(scx, slay);
 
     LaneCounters cnt = {};
     uint32_t paths_done = 0;

@@ -38,11 +38,12 @@ struct StreamLayout {
     uint32_t NF, NU;                // float / uint draws per pixel
     uint32_t ncols;                 // shuffled columns: lens, then every 1D slot, then every 2D slot
     uint32_t dims;
+    uint32_t patterns;              // 1D + 2D patterns requested (of any slot count)
 };
 __host__ __device__ inline void stream_layout_finish(StreamLayout& L) {
-    L.F1 = L.F2 = 0u;
-    for (uint32_t i = 0; i < L.nr1; ++i) L.F1 += L.r1c[i] * L.r1n[i];
-    for (uint32_t i = 0; i < L.nr2; ++i) L.F2 += L.r2c[i] * L.r2n[i];
+    L.F1 = L.F2 = L.patterns = 0u;
+    for (uint32_t i = 0; i < L.nr1; ++i) L.F1 += L.r1c[i] * L.r1n[i], L.patterns += L.r1n[i] != 0u ? L.r1c[i] : 0u;
+    for (uint32_t i = 0; i < L.nr2; ++i) L.F2 += L.r2c[i] * L.r2n[i], L.patterns += L.r2n[i] != 0u ? L.r2c[i] : 0u;
     L.NF = L.S * (4u + L.F1 + 2u * L.F2);
     L.NU = L.S * (1u + 2u * L.F1 + 2u * L.F2);
     L.ncols = 1u + L.F1 + L.F2;
@@ -89,26 +90,41 @@ __host__ __device__ inline bool stream_layout_whitted(StreamLayout& L, int spp, 
     stream_layout_finish(L);
     return true;
 }
-// words of global scratch one workgroup needs: raw draws, column permutations, records
+// What a shuffled column needs when its elements are placed into the records, made once per workgroup (stream_columns): looking
+// the column up in the layout's runs per pixel walked StreamLayout's arrays in scratch memory, 40 % of the assembly phase.
+struct DevStreamCol {
+    uint32_t two_d;   // 0: 1D slot, 1: 2D slot (column 0, the lens sample, is a one-slot 2D pattern)
+    uint32_t raw;     // where the column's floats start among the pixel's raw draws
+    uint32_t rec;     // the slot's float offset in a record
+    float a, b;       // the stratum's corner: j * strata | ux * strata, uy * strata (stratifiedUniform1D / 2D, GoblinSampler.cpp:276-307)
+    float sub;        // the sub-cell's width
+    uint32_t pad[2];
+};
+// words of global scratch one workgroup needs: raw draws, the column table, records
 // tail_per_sample: most outputs one sample can take after its record (the integrator's discarded draws + the medium's)
 __host__ __device__ inline uint64_t stream_scratch_words(const StreamLayout& L, uint32_t tail_per_sample = 0) {
-    return static_cast<uint64_t>(L.NF) + L.NU + static_cast<uint64_t>(L.ncols) * L.S + static_cast<uint64_t>(L.S) * L.dims +
+    return static_cast<uint64_t>(L.NF) + L.NU + static_cast<uint64_t>(L.ncols) * (sizeof(DevStreamCol) / 4) + static_cast<uint64_t>(L.S) * L.dims +
            static_cast<uint64_t>(L.S) * (3u + tail_per_sample);
 }
 
 #ifdef __HIPCC__
 struct StreamCtx {
-    uint32_t* mt;       // LDS: GBL_MT_N state words
-    uint32_t* pos;      // LDS: next unread word of the state block (GBL_MT_N = exhausted)
+    uint32_t* mt;       // LDS: two blocks of GBL_MT_N state words
+    uint32_t pos;       // next unread word of the current block (GBL_MT_N = exhausted) ...
+    uint32_t which;     // ... and which block that is: the same in every thread of the workgroup, so the cursor needs no LDS word
+                        // and advancing it no barrier
     uint32_t* lperm;    // LDS scratch for the shuffles (the traversal stacks' region, idle while samples are generated)
     uint32_t lperm_words;
     uint32_t* raw;      // global, this workgroup's: the pixel's NF + NU raw draws
-    uint32_t* perm;     // global: ncols x S positions
+    DevStreamCol* cols; // global: ncols column descriptors (stream_columns)
     float* recs;        // global: S x dims floats
 };
 
-// std::mt19937(seed): the Knuth initialiser, serial over the state
-__device__ __forceinline__ void mt_seed(const StreamCtx& c, uint32_t seed) {
+// std::mt19937(seed): the Knuth initialiser, serial over the state.  The state lives twice in LDS (c.mt = two blocks of
+// GBL_MT_N words): a refresh writes the other block, so no word is overwritten while it is still being read -- a phase needs
+// one barrier, not two, and reading outputs from the current block needs none.
+__device__ __forceinline__ void mt_seed(StreamCtx& c, uint32_t seed) {
+    __syncthreads();   // (nobody still reads the blocks)
     if (threadIdx.x == 0) {
         uint32_t x = seed;
         c.mt[0] = x;
@@ -116,38 +132,14 @@ __device__ __forceinline__ void mt_seed(const StreamCtx& c, uint32_t seed) {
             x = 1812433253u * (x ^ (x >> 30)) + i;
             c.mt[i] = x;
         }
-        *c.pos = GBL_MT_N;
     }
+    c.pos = GBL_MT_N;
+    c.which = 0u;
     __syncthreads();
 }
 __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t far) {
     uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-// One state refresh.  Word i of the new block needs old words i, i+1 and word i+M of whichever block is current
-// there: [0, N-M) reads old words only, [N-M, 2(N-M)) the first range's new words, and so on -- three barrier
-// phases of <= 227 independent words and the wrap-around word.
-__device__ __forceinline__ void mt_twist(const StreamCtx& c) {
-    const uint32_t t = threadIdx.x;
-    constexpr uint32_t R = GBL_MT_N - GBL_MT_M;   // 227
-    uint32_t v = 0;
-    if (t < R) v = mt_mix(c.mt[t], c.mt[t + 1], c.mt[t + GBL_MT_M]);
-    __syncthreads();
-    if (t < R) c.mt[t] = v;
-    __syncthreads();
-    if (t < R) v = mt_mix(c.mt[R + t], c.mt[R + t + 1], c.mt[t]);
-    __syncthreads();
-    if (t < R) c.mt[R + t] = v;
-    __syncthreads();
-    if (t < GBL_MT_N - 1 - 2 * R) v = mt_mix(c.mt[2 * R + t], c.mt[2 * R + t + 1], c.mt[R + t]);
-    __syncthreads();
-    if (t < GBL_MT_N - 1 - 2 * R) c.mt[2 * R + t] = v;
-    __syncthreads();
-    if (t == 0) {
-        c.mt[GBL_MT_N - 1] = mt_mix(c.mt[GBL_MT_N - 1], c.mt[0], c.mt[GBL_MT_M - 1]);
-        *c.pos = 0;
-    }
-    __syncthreads();
 }
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= y >> 11;
@@ -156,20 +148,58 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= y >> 18;
     return y;
 }
+// A workgroup barrier for phases that only exchange LDS words: __syncthreads() also waits for every global store in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// the generator's state to / from global memory (GBL_MT_N + 1 words; the medium phase rewinds the stream).  Whole workgroup.
+__device__ __forceinline__ void mt_save(const StreamCtx& c, uint32_t* dst) {
+    const uint32_t* cur = c.mt + c.which * GBL_MT_N;
+    for (uint32_t t = threadIdx.x; t < GBL_MT_N; t += blockDim.x) dst[t] = cur[t];
+    if (threadIdx.x == 0) dst[GBL_MT_N] = c.pos;
+    __syncthreads();
+}
+__device__ __forceinline__ void mt_restore(StreamCtx& c, const uint32_t* src) {
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < GBL_MT_N; t += blockDim.x) c.mt[t] = src[t];
+    c.pos = src[GBL_MT_N];
+    c.which = 0u;
+    __syncthreads();
+}
+// One state refresh into the other block.  Word i of the new block needs old words i, i + 1 and word i + M of whichever block
+// is current there: [0, N-M) reads old words only, [N-M, 2(N-M)) the first range's new words, the rest the second's -- three
+// phases of <= 227 independent words, the wrap-around word in the third.  (Tempering and storing the outputs inside these phases
+// was measured: the refresh's share of an instrumented frame 45 -> 79 ms.)
+__device__ __forceinline__ void mt_twist(StreamCtx& c) {
+    constexpr uint32_t R = GBL_MT_N - GBL_MT_M;   // 227
+    const uint32_t t = threadIdx.x;
+    const uint32_t* old = c.mt + c.which * GBL_MT_N;
+    uint32_t* nw = c.mt + (c.which ^ 1u) * GBL_MT_N;
+    if (t < R) nw[t] = mt_mix(old[t], old[t + 1], old[t + GBL_MT_M]);
+    lds_barrier();
+    if (t < R) nw[R + t] = mt_mix(old[R + t], old[R + t + 1], nw[t]);
+    lds_barrier();
+    if (t < GBL_MT_N - 1 - 2 * R) nw[2 * R + t] = mt_mix(old[2 * R + t], old[2 * R + t + 1], nw[R + t]);
+    else if (t == GBL_BLOCK - 1) nw[GBL_MT_N - 1] = mt_mix(old[GBL_MT_N - 1], nw[0], nw[GBL_MT_M - 1]);
+    lds_barrier();
+    c.pos = 0u;
+    c.which ^= 1u;
+}
 // the next `count` outputs of the tile's generator, written to dst (null: skipped).  Called by the whole workgroup.
-__device__ __forceinline__ void stream_emit(const StreamCtx& c, uint32_t* dst, uint32_t count) {
+// (The block a refresh writes was last read three barriers earlier -- by the refresh before it -- so the outputs are read
+//  without one.)
+__device__ __forceinline__ void stream_emit(StreamCtx& c, uint32_t* dst, uint32_t count) {
     uint32_t done = 0;
     while (done < count) {
-        if (*c.pos == GBL_MT_N) mt_twist(c);
-        const uint32_t p = *c.pos;
-        const uint32_t n = min(GBL_MT_N - p, count - done);
+        if (c.pos == GBL_MT_N) mt_twist(c);
+        const uint32_t* cur = c.mt + c.which * GBL_MT_N;
+        const uint32_t n = min(GBL_MT_N - c.pos, count - done);
         if (dst)
-            for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) dst[done + t] = mt_temper(c.mt[p + t]);
-        __syncthreads();
-        if (threadIdx.x == 0) *c.pos = p + n;
-        __syncthreads();
+            for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) dst[done + t] = mt_temper(cur[c.pos + t]);
+        c.pos += n;
         done += n;
     }
+    if (dst) __syncthreads();   // what was stored is visible to the workgroup from here on
 }
 
 // RNGImp::randomFloat: uniform_real_distribution<float>(0, 1) over one 32-bit draw -- generate_canonical<float, 24>
@@ -218,16 +248,62 @@ __device__ __forceinline__ StreamCol stream_column(const StreamLayout& L, uint32
     return c;
 }
 
+// The workgroup's column table, once per launch.  Called by the whole workgroup.
+__device__ __forceinline__ void stream_columns(const StreamCtx& c, const StreamLayout& L) {
+    const uint32_t S = L.S;
+    for (uint32_t col = threadIdx.x; col < L.ncols; col += blockDim.x) {
+        DevStreamCol d;
+        d.pad[0] = d.pad[1] = 0u;
+        if (col == 0u) {   // the lens sample: stream_strat2(L, 1, 0, ...)
+            d.two_d = 1u;
+            d.raw = 2 * S;
+            d.rec = 2u;
+            d.a = d.b = 0.0f;   // r = 1, strata = 1: ux * strata = uy * strata = 0
+            d.sub = 1.0f / static_cast<int>(L.root);
+        } else {
+            const StreamCol sc = stream_column(L, col);
+            d.two_d = sc.two_d;
+            if (sc.two_d == 0u) {
+                const float strata = 1.0f / static_cast<float>(sc.n);
+                d.raw = 4 * S + sc.slot * S;
+                d.rec = 4u + sc.slot;
+                d.a = sc.j * strata;
+                d.b = 0.0f;
+                d.sub = strata / static_cast<int>(S);
+            } else {
+                const int r = static_cast<int>(sqrtf(static_cast<float>(sc.n)));
+                const float strata = 1.0f / r;
+                const int ux = static_cast<int>(sc.j) % r, uy = static_cast<int>(sc.j) / r;
+                d.raw = 4 * S + L.F1 * S + 2 * sc.slot * S;
+                d.rec = 4u + L.F1 + 2 * sc.slot;
+                d.a = ux * strata;
+                d.b = uy * strata;
+                d.sub = strata / static_cast<int>(L.root);
+            }
+        }
+        c.cols[col] = d;
+    }
+    __syncthreads();
+}
+
 // Sampler::requestSamples for the pixel (cx, cy): fills c.recs.  Called by the whole workgroup.
 // The shuffles run one lane per column on 16-bit positions in LDS (the idle traversal stacks' region), a round of columns at a
 // time, and every round's columns go straight from there into the records: the permutations never travel through global
 // memory (66 KB written and read back per pixel at configs[1] until round 3) and configs[1]'s 65 columns are one round.
 // tm (instrumented builds): wall_clock64 ticks spent emitting / permuting / assembling, accumulated by thread 0
-__device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const StreamLayout& L, int cx, int cy,
+__device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const StreamLayout& L, int cx, int cy,
                                                       unsigned long long* tm = nullptr) {
     const uint32_t S = L.S;
     unsigned long long t0 = tm ? wall_clock64() : 0ull;
-    stream_emit(c, c.raw, L.NF + L.NU);
+    // A tile's pixels are strictly sequential and this is the part only this workgroup can do: its few busy lanes go ahead of the
+    // other workgroups' traversal loops on the CU.
+    __builtin_amdgcn_s_setprio(3);
+    // the in-pattern shuffles' draws (the last S (F1 + F2) uints) only matter to patterns of more than one slot: a one-slot
+    // pattern swaps its slot with itself.  Without such patterns (the path tracer's quota without a BSSRDF block) they are passed over.
+    const uint32_t n_shuffled = L.NF + L.ncols * S;
+    const bool in_pattern = L.F1 + L.F2 != L.patterns;
+    stream_emit(c, c.raw, in_pattern ? L.NF + L.NU : n_shuffled);
+    if (!in_pattern) stream_emit(c, nullptr, L.NF + L.NU - n_shuffled);
     if (tm) {
         const unsigned long long t1 = wall_clock64();
         tm[0] += t1 - t0;
@@ -251,11 +327,20 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         if (b < nb) {
             for (uint32_t k = 0; k < S; ++k) lp[k * B + b] = static_cast<unsigned short>(k);
             const uint32_t* u = c.raw + L.NF + col * S;
-            for (uint32_t n0 = 0; n0 < S; n0 += 8) {
-                uint32_t o[8];
-                for (uint32_t i = 0; i < 8; ++i) o[i] = n0 + i < S ? u[n0 + i] % S : 0u;
-                for (uint32_t i = 0; i < 8 && n0 + i < S; ++i) {
-                    const uint32_t ia = (n0 + i) * B + b, ib = o[i] * B + b;
+            const uint32_t pow2 = (S & (S - 1u)) == 0u ? S - 1u : 0u;   // x % S without the division where S is a power of two
+            uint32_t o[16], nx[16];
+#pragma unroll
+            for (uint32_t i = 0; i < 16; ++i) nx[i] = i < S ? u[i] : 0u;
+            for (uint32_t n0 = 0; n0 < S; n0 += 16) {
+#pragma unroll
+                for (uint32_t i = 0; i < 16; ++i) o[i] = nx[i];
+#pragma unroll
+                for (uint32_t i = 0; i < 16; ++i) nx[i] = n0 + 16 + i < S ? u[n0 + 16 + i] : 0u;   // (the next sixteen draws travel while these are applied)
+#pragma unroll
+                for (uint32_t i = 0; i < 16; ++i) {
+                    if (n0 + i >= S) break;
+                    const uint32_t other = pow2 ? (o[i] & pow2) : o[i] % S;
+                    const uint32_t ia = (n0 + i) * B + b, ib = other * B + b;
                     const unsigned short va = lp[ia], vb = lp[ib];
                     lp[ia] = vb;
                     lp[ib] = va;
@@ -269,30 +354,39 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
             t0 = t1;
         }
         // ---- records: sample k takes, in every column of the round, the element its position's permutation points at
+        // (eight columns at a time: their draws are fetched together, then placed)
+        const uint32_t root_pow2 = (L.root & (L.root - 1u)) == 0u ? L.root - 1u : 0u, root_shift = 31u - static_cast<uint32_t>(__clz(static_cast<int>(L.root)));
         for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
             float* rec = c.recs + static_cast<size_t>(k) * L.dims;
-            for (uint32_t bb = 0; bb < nb; ++bb) {
-                const uint32_t cc = c0 + bb;
-                const uint32_t p = lp[k * B + bb];
-                if (cc == 0u) {   // the lens sample
-                    float x, y;
-                    stream_strat2(L, 1u, 0u, p, stream_u01(c.raw[2 * S + 2 * p]), stream_u01(c.raw[2 * S + 2 * p + 1]), &x, &y);
-                    rec[2] = x;
-                    rec[3] = y;
-                    continue;
+            for (uint32_t b0 = 0; b0 < nb; b0 += 8) {
+                uint32_t pp[8];
+                DevStreamCol dc[8];
+                float f0[8], f1[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    const uint32_t bb = min(b0 + i, nb - 1u);
+                    pp[i] = lp[k * B + bb];
+                    dc[i] = c.cols[c0 + bb];
                 }
-                const StreamCol sc = stream_column(L, cc);
-                if (sc.two_d == 0u) {
-                    const float strata = 1.0f / static_cast<float>(sc.n);
-                    const float sub = strata / static_cast<int>(S);
-                    const float off = static_cast<int>(p) + stream_u01(c.raw[4 * S + sc.slot * S + p]);
-                    rec[4 + sc.slot] = sc.j * strata + off * sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
-                } else {
-                    const uint32_t e = 4 * S + L.F1 * S + 2 * (sc.slot * S + p);
-                    float x, y;
-                    stream_strat2(L, sc.n, sc.j, p, stream_u01(c.raw[e]), stream_u01(c.raw[e + 1]), &x, &y);
-                    rec[4 + L.F1 + 2 * sc.slot] = x;
-                    rec[4 + L.F1 + 2 * sc.slot + 1] = y;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    const uint32_t e = dc[i].raw + (dc[i].two_d ? 2 * pp[i] : pp[i]);
+                    f0[i] = stream_u01(c.raw[e]);
+                    f1[i] = dc[i].two_d ? stream_u01(c.raw[e + 1]) : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    const uint32_t p = pp[i];
+                    if (b0 + i >= nb) {
+                    } else if (dc[i].two_d == 0u) {
+                        const float off = static_cast<int>(p) + f0[i];
+                        rec[dc[i].rec] = dc[i].a + off * dc[i].sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
+                    } else {   // stratifiedUniform2D, :288-307: sub-cell p of the root x root grid
+                        const int px = static_cast<int>(root_pow2 ? (p & root_pow2) : p % L.root), py = static_cast<int>(root_pow2 ? (p >> root_shift) : p / L.root);
+                        const float xo = px + f0[i], yo = py + f1[i];
+                        rec[dc[i].rec] = dc[i].a + xo * dc[i].sub;
+                        rec[dc[i].rec + 1] = dc[i].b + yo * dc[i].sub;
+                    }
                 }
             }
         }
@@ -305,7 +399,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
     }
     // ---- per-sample shuffles inside each pattern (:185-196); a one-slot pattern swaps its slot with itself
     const uint32_t* uper = c.raw + L.NF + L.ncols * S;   // in-pattern shuffle draws, F1 + F2 per sample
-    for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
+    for (uint32_t k = threadIdx.x; in_pattern && k < S; k += blockDim.x) {
         float* rec = c.recs + static_cast<size_t>(k) * L.dims;
         const uint32_t* us = uper + static_cast<size_t>(k) * (L.F1 + L.F2);
         uint32_t off1 = 0;
@@ -342,6 +436,7 @@ __device__ __forceinline__ void stream_generate_pixel(const StreamCtx& c, const 
         }
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     if (tm) tm[2] += wall_clock64() - t0;
 }
 #endif

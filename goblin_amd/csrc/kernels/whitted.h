@@ -334,13 +334,15 @@ __global__ __launch_bounds__(GBL_BLOCK) void whitted_stream_kernel(DevScene sc, 
     stream_layout_whitted(slay, ra.spp, ra.root, ra.bssrdf_n, ra.bssrdf_n2, sc.num_lights, [&](int i) { return sc.lights[i].wh_n; });
     StreamCtx scx;
     scx.mt = ctrl + 4;
-    scx.pos = ctrl + 4 + GBL_MT_N;
+    scx.pos = GBL_MT_N;
+    scx.which = 0u;
     scx.lperm = stack;
     scx.lperm_words = ra.stream_lperm_words;
     scx.raw = ra.stream_scratch + static_cast<size_t>(blockIdx.x) * ra.stream_stride;
-    scx.perm = scx.raw + slay.NF + slay.NU;
-    scx.recs = reinterpret_cast<float*>(scx.perm + static_cast<size_t>(slay.ncols) * slay.S);
+    scx.cols = reinterpret_cast<DevStreamCol*>(scx.raw + slay.NF + slay.NU);
+    scx.recs = reinterpret_cast<float*>(scx.cols + slay.ncols);
     const StreamVol svol = stream_vol_scratch(scx, slay);   // with a participating medium (stream_medium_phase)
+    stream_columns(scx, slay);
     LaneCounters cnt = {};
     uint32_t paths_done = 0;
     const uint32_t n_items = static_cast<uint32_t>(ra.local_tiles);

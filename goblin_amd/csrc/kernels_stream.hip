@@ -8,6 +8,10 @@ gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext) {
     return ext ? path_trace_kernel<GBL_SRC_STREAM, false, true> : path_trace_kernel<GBL_SRC_STREAM, false, false>;
 }
 
+// the lean stream kernel with quad-per-ray queries (kernels/quadtrace.h): a pixel's 256 paths are not refilled as they end, so its
+// waves spend most of their queries with a few live rays
+gbl_render_kernel gbl_kernel_path_stream_quad(void) { return path_trace_kernel<GBL_SRC_STREAM, false, false, true>; }
+
 gbl_render_kernel gbl_kernel_ao_stream(bool ext) {   // (not instrumented)
     return ext ? ao_kernel<GBL_SRC_STREAM, false, true> : ao_kernel<GBL_SRC_STREAM, false, false>;
 }
