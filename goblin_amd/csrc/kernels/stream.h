@@ -295,9 +295,8 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
                                                       unsigned long long* tm = nullptr) {
     const uint32_t S = L.S;
     unsigned long long t0 = tm ? wall_clock64() : 0ull;
-    // A tile's pixels are strictly sequential and this is the part only this workgroup can do: its few busy lanes go ahead of the
-    // other workgroups' traversal loops on the CU.
-    __builtin_amdgcn_s_setprio(3);
+    // (raising the wave priority for this phase, the part only this workgroup can do, over the other workgroups' traversal loops:
+    //  no change, 179.8 against 179.0 ms)
     // the in-pattern shuffles' draws (the last S (F1 + F2) uints) only matter to patterns of more than one slot: a one-slot
     // pattern swaps its slot with itself.  Without such patterns (the path tracer's quota without a BSSRDF block) they are passed over.
     const uint32_t n_shuffled = L.NF + L.ncols * S;
@@ -436,7 +435,6 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
         }
     }
     __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
     if (tm) tm[2] += wall_clock64() - t0;
 }
 #endif
