@@ -91,7 +91,7 @@ struct DevInstanceBound {
     float lo[3], hi[3];
 };
 // Triangle::getObjectBound (the three vertices' bound): the reference BLAS's leaf box, one triangle per leaf.  Indexed like
-// tri_shade (DevTri::shade); read by the TIES builds only (ref_reached / ref_leaf_reached, kernels/trace.h).
+// `tris` (a hit's triangle number finds it in one load); read by the TIES builds only (ref_reached / trace_needs_redo, kernels/trace.h).
 struct DevTriBound {
     float lo[3], hi[3];
     float pad[2];

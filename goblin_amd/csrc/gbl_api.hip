@@ -476,7 +476,18 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     }
     ctx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pack0).count();
     if ((st = upload(ctx, packed.tri_shade, &sc.tri_shade)) != GBL_OK) return bail(st);
-    if ((st = upload(ctx, packed.tri_bounds, &sc.tri_bounds)) != GBL_OK) return bail(st);
+    if (!device_bvh) {
+        if ((st = upload(ctx, packed.tri_bounds_leaf, &sc.tri_bounds)) != GBL_OK) return bail(st);
+    } else {
+        const DevTriBound* by_id = nullptr;
+        if ((st = upload(ctx, packed.tri_bounds, &by_id)) != GBL_OK) return bail(st);
+        if ((st = upload_raw(ctx, static_cast<const DevTriBound*>(nullptr), 0, packed.tris.size(), &sc.tri_bounds)) != GBL_OK) return bail(st);
+        gbl_launch_tri_bounds_gather(sc.tris, by_id, const_cast<DevTriBound*>(sc.tri_bounds), static_cast<uint32_t>(packed.tris.size()));
+        if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+            ctx->error = std::string("triangle bound gather: ") + hipGetErrorString(le);
+            return bail(GBL_ERR_DEVICE);
+        }
+    }
     if ((st = upload(ctx, packed.tri_order, &sc.tri_order)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.instance_bounds, &sc.instance_bounds)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.positions, &sc.positions)) != GBL_OK) return bail(st);

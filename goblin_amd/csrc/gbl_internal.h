@@ -103,6 +103,7 @@ gbl_li_kernel gbl_kernel_whitted_stream(void);
 gbl_li_kernel gbl_kernel_sss(bool replay);
 gbl_render_kernel gbl_kernel_vol(bool replay);
 void gbl_launch_vol_combine(float4* li, const float4* vol, uint64_t n, hipStream_t stream);
+void gbl_launch_tri_bounds_gather(const DevTri* tris, const DevTriBound* by_id, DevTriBound* out, uint32_t n);
 void gbl_launch_film_resolve(const float* accum, float* rgb, int n, hipStream_t stream);
 gbl_status gbl_build_blas_device(gbl_ctx* ctx, const float* d_pos, const uint32_t* d_idx, uint32_t n, const float* lo, const float* hi,
                                  DevNode* d_nodes, int32_t node_base, DevTri* d_tris, uint32_t tri_base, uint32_t shade_base, uint32_t tri_flags,

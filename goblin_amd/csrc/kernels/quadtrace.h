@@ -19,21 +19,19 @@
 // faster -- two LDS round trips per run on a chain that is latency bound once the VALU work shrinks.)  LDS operations of
 // one wave execute in order, so the slab and the foreign stack columns need no barrier, only compiler fences.
 //
-// TIES builds (`exact_ties` under the native sampler) keep the reference's exact-t tie rule and its reachability test
-// (ref_reached, trace.h) here: a leaf whose triangles tie, with one another or with the hit the ray holds, falls back to
-// trav_other's own loop; a triangle the quad's lane accepts is checked against the reference's box tests before it counts.  The
-// query's own maxt (TravState::maxt0), which that test needs, travels in the record like the rest of the ray.  (For a round it did
-// not -- a quad's lanes read whatever their own registers held, uninitialised ones in lanes without a ray -- and one replayed
-// sample of bunny.json flipped at -O3 only; the test was kept out of this file until that was found.)
+// TIES builds (`exact_ties` under the native sampler, the stream sampler) follow the reference's exact-t tie rule and its
+// reachability test the way trace() does (trace.h, GBL_TIE_DETECT): the loops here only notice a triangle accepted at exactly the
+// distance of the hit the ray holds -- the flag travels back in the record -- and trace_quad() checks every ray's final hit once,
+// all lanes together, tracing the rare ray that tied or whose hit the reference would not have reached again in the exact loop.
 #pragma once
 #include "trace.h"
 
 #ifndef GBL_QUAD_MAX
 #define GBL_QUAD_MAX 16           // rays that migrate: 64 lanes / 4
 #endif
-// record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8) | maxt0
-// result (written by the quad's first lane when the ray is done): words 0-5 = hit.inst hit.tri hit.b1 hit.b2 hit.t occluded, 12 = steps
-#define GBL_QUAD_REC_WORDS 22
+// record: r.o r.d world.o world.d | mint maxt cur inst | hit.inst hit.tri hit.b1 hit.b2 | sp + (lane << 8)
+// result (written by the quad's first lane when the ray is done): words 0-5 = hit.inst hit.tri hit.b1 hit.b2 hit.t occluded + 2 tied, 12 = steps
+#define GBL_QUAD_REC_WORDS 21
 #define GBL_QUAD_LDS_WORDS ((GBL_BLOCK / 64) * 16 * GBL_QUAD_REC_WORDS)
 
 template <int CTRL>
@@ -136,13 +134,12 @@ __device__ __forceinline__ void quad_interior(TravState& st, const QuadLane& ql,
 // mint <= t <= maxt and shrinks maxt to t, so the nearest accepted triangle stays and, among equal distances, the one
 // tested last -- is the minimum over the quad with ties going to the higher lane.  (Used where the reference's tie rule is
 // compiled out, GBL `TIES` = false, and for any-hit queries; a NaN distance, which the loop would accept, loses here.)
-// TIES (closest-hit queries of the builds that follow the reference's tie rule): the rule only ever matters when two accepted
-// distances are EXACTLY equal -- two lanes of the quad, or a lane and the hit the ray already holds in this instance -- or
-// when a distance is NaN (which trav_other's loop accepts).  Those leaves (a handful per 10^7 paths) are left untouched and
-// *redo is set: the caller runs trav_other's own loop on them; every other leaf gives what that loop would.
+// TIES (the builds that follow the reference's tie rule): two accepted distances EXACTLY equal -- two lanes of the quad, or a lane
+// and the hit the ray already holds in this instance -- or a NaN distance (which trav_other's loop accepts) set st.tied for the
+// end-of-query check (trace.h GBL_TIE_DETECT); an any-hit query leaves its occluder in st.hit.
 template <bool ANY, bool STATS, bool TIES = false>
-__device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded, uint4 w0, uint4 w1,
-                                          uint4 w2, uint32_t popped, const gbl_lds_u32* wrec, bool* redo = nullptr) {
+__device__ __forceinline__ bool quad_leaf(TravState& st, const QuadLane& ql, LaneCounters& cnt, bool* occluded, uint4 w0, uint4 w1, uint4 w2,
+                                          uint32_t popped) {
     const uint32_t ref = ~static_cast<uint32_t>(st.cur);
     const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
     float t = INFINITY, b1 = 0.0f, b2 = 0.0f;
@@ -154,9 +151,6 @@ __device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, con
         float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), 0.0f);
         tri_fetch_together(q0, q1, q2);   // one memory round trip (trace.h)
         ok = tri_test_regs(q0, q1, q2, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2);
-        if (TIES && ok)   // would the reference's traversal get to this triangle (trace.h)?  w0.w = DevTri::shade
-            ok = ref_reached(sc, st.inst, w0.w, f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])),
-                             f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])), st.r.o, st.r.d, st.mint, st.maxt0);
     }
     const float tq = ok ? t : INFINITY;
     float m = fminf(tq, quad_dpp_f<GBL_QP_XOR1>(tq));
@@ -169,20 +163,21 @@ __device__ __forceinline__ bool quad_leaf(const DevScene& sc, TravState& st, con
         uint32_t wm = (ok && tq == m) ? ql.bitc : 0u;
         wm |= quad_dpp<GBL_QP_XOR1>(wm);
         wm |= quad_dpp<GBL_QP_XOR2>(wm);
-        if (odd != 0u || (m < INFINITY && ((wm & (wm - 1u)) != 0u || (m == st.hit.t && st.hit.inst == st.inst)))) {
-            *redo = true;
-            return false;
-        }
+        if (odd != 0u || (m < INFINITY && ((wm & (wm - 1u)) != 0u || (m == st.hit.t && st.hit.inst == st.inst)))) st.tied = true;
     }
     if (m < INFINITY) {   // (the same in the quad's four lanes)
-        if (ANY) {
-            *occluded = true;
-            return true;
-        }
         uint32_t wm = (ok && tq == m) ? ql.bitc : 0u;
         wm |= quad_dpp<GBL_QP_XOR1>(wm);
         wm |= quad_dpp<GBL_QP_XOR2>(wm);
         const uint32_t cw = 31u - static_cast<uint32_t>(__clz(static_cast<int>(wm)));
+        if (ANY) {
+            if (TIES) {   // the occluder, for the end-of-query check
+                st.hit.inst = st.inst;
+                st.hit.tri = first + cw;
+            }
+            *occluded = true;
+            return true;
+        }
         uint32_t u1 = ql.c == cw ? __float_as_uint(b1) : 0u, u2 = ql.c == cw ? __float_as_uint(b2) : 0u;
         u1 |= quad_dpp<GBL_QP_XOR1>(u1);
         u2 |= quad_dpp<GBL_QP_XOR1>(u2);
@@ -240,10 +235,12 @@ __device__ __forceinline__ void quad_transition(const DevScene& sc, TravState& s
 template <bool ANY, bool STATS, bool EXT, bool TIES>
 __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, F3 d, float mint, float maxt, const LdsStack& stk, gbl_lds_u32* slab,
                                            gbl_lds_u32* wave_stack, Hit& hit, LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
+    constexpr int TM = TIES ? GBL_TIE_DETECT : GBL_TIE_NONE;
     TravState st;
     if (want) {
         trav_begin(sc, st, o, d, mint, maxt, stk);
     } else {
+        st.tied = false;
         st.sp = 0;
         st.cur = GBL_STACK_EXIT;
         st.inst = -1;
@@ -287,7 +284,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 }
                 if (!at_int) {
                     const unsigned long long b0 = __builtin_amdgcn_s_memtime();
-                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, stk, cnt, &occluded, filter);
+                    done = trav_other<ANY, STATS, EXT, LdsStack, TM, false>(sc, st, stk, cnt, &occluded, filter);
                     asm volatile("" ::"v"(st.cur), "v"(st.sp));
                     cnt.pc[12] += __builtin_amdgcn_s_memtime() - b0;
                     cnt.pc[14] += 1;
@@ -303,10 +300,10 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                     trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                     if (STATS) ++steps;
                 } else {
-                    done = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, stk, cnt, &occluded, filter);
+                    done = trav_other<ANY, STATS, EXT, LdsStack, TM, false>(sc, st, stk, cnt, &occluded, filter);
                 }
             } else {
-                if (!trav_at_interior(st)) done = trav_other<ANY, STATS, EXT, LdsStack, TIES, true>(sc, st, stk, cnt, &occluded, filter);
+                if (!trav_at_interior(st)) done = trav_other<ANY, STATS, EXT, LdsStack, TM, true>(sc, st, stk, cnt, &occluded, filter);
                 if (!done && trav_at_interior(st)) {
                     trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                     if (STATS) ++steps;
@@ -343,9 +340,10 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             rec[16] = static_cast<uint32_t>(st.hit.inst); rec[17] = st.hit.tri;
             rec[18] = __float_as_uint(st.hit.b1); rec[19] = __float_as_uint(st.hit.b2);
             rec[20] = static_cast<uint32_t>(st.sp) | (lane << 8);
-            if (TIES) rec[21] = __float_as_uint(st.maxt0);
         }
         quad_fence();
+        const bool tied_before = st.tied;   // (of the lane's own ray; the lane's state now becomes its quad's ray's)
+        st.tied = false;
         const bool qlive = q < nl;
         st.world.o = st.world.d = st.world.idir = st.world.ood = f3(0.0f, 0.0f, 0.0f);   // (not kept in registers from here on)
         QuadLane ql;
@@ -365,7 +363,6 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             st.inst = static_cast<int>(qrec[15]);
             st.mint = __uint_as_float(qrec[12]);
             st.maxt = __uint_as_float(qrec[13]);
-            if (TIES) st.maxt0 = __uint_as_float(qrec[21]);
             st.cur = static_cast<int>(qrec[14]);
             st.hit.inst = static_cast<int>(qrec[16]);
             st.hit.tri = qrec[17];
@@ -419,19 +416,14 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
                 const uint4* tp = reinterpret_cast<const uint4*>(sc.tris + (lref >> 2) + min(ql.c, lref & 3u));
                 const uint4 w0 = tp[0], w1 = tp[1], w2 = tp[2];
                 const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];
-                bool redo = false;
-                qdone = quad_leaf<ANY, STATS, TIES>(sc, st, ql, cnt, &qocc, w0, w1, w2, popped, qrec + 6, &redo);
-                if (TIES && !ANY && redo) {   // an exact tie in this leaf: the reference's rule, in trav_other's own loop
-                    if (STATS && ql.c == 0u) cnt.tris -= (lref & 3u) + 1u;
-                    qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, qstk, cnt, &qocc, filter, qrec + 6);
-                }
+                qdone = quad_leaf<ANY, STATS, TIES>(st, ql, cnt, &qocc, w0, w1, w2, popped);
             } else if (st.cur == GBL_STACK_SENTINEL || (st.cur < 0 && st.inst < 0)) {
                 quad_transition<STATS, EXT>(sc, st, qstk, qrec, cnt, filter);
             } else if (!EXT && QUAD_LEAVES) {   // lean builds: all that is left is the exit marker
                 qdone = true;
                 (void)qstk;
             } else {   // the exit marker; analytic shapes; any-hit leaves of the instrumented builds
-                qdone = trav_other<ANY, STATS, EXT, LdsStack, TIES, false>(sc, st, qstk, cnt, &qocc, filter, qrec + 6);
+                qdone = trav_other<ANY, STATS, EXT, LdsStack, TM, false>(sc, st, qstk, cnt, &qocc, filter);
             }
 #ifdef GBL_PHASE_CLOCK
             {   // wave-level: the iteration's time goes to the kind of the wave's first live quad
@@ -458,7 +450,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             qrec[2] = __float_as_uint(st.hit.b1);
             qrec[3] = __float_as_uint(st.hit.b2);
             qrec[4] = __float_as_uint(st.hit.t);
-            qrec[5] = qocc ? 1u : 0u;
+            qrec[5] = (qocc ? 1u : 0u) | (st.tied ? 2u : 0u);
             if (STATS) qrec[12] = qsteps;
         }
         quad_fence();
@@ -469,10 +461,25 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             res.b1 = __uint_as_float(rec[2]);
             res.b2 = __uint_as_float(rec[3]);
             res.t = __uint_as_float(rec[4]);
-            occluded = rec[5] != 0u;
+            occluded = (rec[5] & 1u) != 0u;
+            st.tied = tied_before || (rec[5] & 2u) != 0u;
             if (STATS) steps += rec[12];
+        } else {
+            st.tied = tied_before;
         }
         quad_fence();   // the slab is free for the next query
+    }
+    if constexpr (TIES) {
+        // every ray's final hit against the reference's box tests, all lanes together; the rare ray that fails, or tied, again
+        // in the exact loop (trace.h trace_needs_redo)
+        // (of the 6.9 ms this mode costs configs[1]: the flag in the loops 2.2, this check 2.6, the exact loop's presence 2.2)
+        const bool redo = want && trace_needs_redo(sc, EXT, ANY ? occluded : res.inst >= 0, res, st.tied, o, d, mint, maxt);
+        if (__ballot(redo) != 0ull && redo) {
+            Hit h;
+            const bool g = trace_loop<ANY, STATS, EXT, GBL_TIE_EXACT>(sc, o, d, mint, maxt, stk, h, cnt, filter, nullptr);
+            if (ANY) occluded = g;
+            else res = h;
+        }
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef GBL_PHASE_CLOCK

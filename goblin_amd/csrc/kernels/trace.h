@@ -118,7 +118,8 @@ __device__ __forceinline__ bool tri_test(const DevTri* tp, F3 o, F3 d, float min
 struct TravState {
     RaySpace world, r;   // world-space ray and the ray in the current space (world or instance)
     float mint, maxt;
-    float maxt0;         // the query's own maxt (maxt shrinks with every accepted hit); read by the TIES builds only
+    float maxt0;         // the query's own maxt (maxt shrinks with every accepted hit); read by the exact loop only (GBL_TIE_EXACT)
+    bool tied;           // GBL_TIE_DETECT: a triangle was accepted at exactly the distance of the hit the ray held
     int sp, cur, inst;
     Hit hit;
 };
@@ -161,6 +162,7 @@ __device__ __forceinline__ void trav_begin(const DevScene& sc, TravState& st, F3
     st.mint = mint;
     st.maxt = maxt;
     st.maxt0 = maxt;
+    st.tied = false;
     st.sp = 0;
     stk.store(st.sp++, GBL_STACK_EXIT);
     st.cur = sc.num_instances > 0 ? sc.tlas_root : GBL_STACK_EXIT;
@@ -322,7 +324,7 @@ __device__ __forceinline__ bool ref_box_reached(F3 lo, F3 hi, F3 o, F3 d, float 
     return tmin < maxt && tmax > mint;
 }
 __device__ __forceinline__ bool ref_leaf_reached(const DevScene& sc, uint32_t tri, F3 o, F3 d, float mint, float maxt) {
-    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + sc.tris[tri].shade);
+    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + tri);
     const float4 b0 = bp[0], b1 = bp[1];
     return ref_box_reached(f3(b0.x, b0.y, b0.z), f3(b0.w, b1.x, b1.y), o, d, mint, maxt);
 }
@@ -346,7 +348,7 @@ static __device__ __attribute__((noinline)) bool tie_goes_to_impl(const DevTri* 
     const bool cand_in_second = ((b.path >> l) & 1u) != 0u;
     const bool cand_is_later = cand_in_second != near_is_second;   // the far child is visited later
     // the later one wins if its leaf is reached with maxt == t; its single-triangle leaf's box is the triangle's bound
-    const float4* bp = reinterpret_cast<const float4*>(tri_bounds + (cand_is_later ? sb : sa));
+    const float4* bp = reinterpret_cast<const float4*>(tri_bounds + (cand_is_later ? cand : cur));
     const float4 b0 = bp[0], b1 = bp[1];
     const bool reached = ref_box_reached(f3(b0.x, b0.y, b0.z), f3(b0.w, b1.x, b1.y), f3(ox, oy, oz), f3(dx, dy, dz), mint, t);
     return cand_is_later ? reached : !reached;
@@ -362,10 +364,10 @@ __device__ __forceinline__ bool tie_goes_to(const DevScene& sc, uint32_t cur, ui
 // leaf box (the triangle's own bound, one triangle per leaf) or TLAS leaf box (the instance's world bound) the same ray
 // misses by a rounding.  Every ancestor's box contains those two, so they decide.  The TIES builds (replay, stream,
 // exact_ties, instrumented) therefore accept a triangle only if both pass the reference's test, with the query's own maxt.
-__device__ __forceinline__ bool ref_reached(const DevScene& sc, int inst, uint32_t shade, F3 wo, F3 wd, F3 oo, F3 od, float mint, float maxt0) {
+__device__ __forceinline__ bool ref_reached(const DevScene& sc, int inst, uint32_t tri, F3 wo, F3 wd, F3 oo, F3 od, float mint, float maxt0) {
     const DevInstanceBound wb = sc.instance_bounds[inst];
     if (!ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), wo, wd, mint, maxt0)) return false;
-    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + shade);
+    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + tri);
     const float4 b0 = bp[0], b1 = bp[1];
     const F3 lo = f3(b0.x, b0.y, b0.z), hi = f3(b0.w, b1.x, b1.y);
     return ref_box_reached(lo, hi, oo, od, mint, maxt0);
@@ -374,19 +376,25 @@ __device__ __forceinline__ bool ref_reached(const DevScene& sc, int inst, uint32
 // EXT: the scene may hold analytic shapes (DevScene::extended); plain scenes compile the branch out.
 // `filter` (EXT builds): GBL_FILTER_* -- instances whose material is / is not a mask are skipped whole, which is
 // what Model::intersect does with the isOpaque / notOpaque IntersectFilter (GoblinModel.cpp:30-32, 44-46).
-// TIES: resolve exact ties as the reference's BVH does (tie_goes_to).  The compare sits on the accept path of the loop
-// every ray runs and costs the headline kernel 1.4 % (measured both inlined and as a flag + second pass); the native
-// sampler's lean megakernel therefore compiles it out -- its ties, ~5 per 10^7 paths, fall to the device tree's own
-// order -- and so does the wavefront's lean extension kernel, while every replay / stream / instrumented build keeps it.
-// `any`: the query kind as a value -- a compile-time constant through trav_other<ANY, ...> below, a per-lane flag in the
-// wave-pool kernel (kernels/wavepool.h), whose lanes trace shadow and extension rays side by side.
+// TM: what the loop does about the reference's exact-t tie rule (tie_goes_to) and its reachability test (ref_reached).
+//   GBL_TIE_NONE    nothing: the last triangle tested at a distance keeps it, every accepted triangle counts
+//   GBL_TIE_EXACT   both, inline, at every triangle the test accepts (needs st.world and st.maxt0)
+//   GBL_TIE_DETECT  the loop of GBL_TIE_NONE plus one compare: st.tied is set when a triangle is accepted at exactly the distance
+//                   of the hit the ray holds; an any-hit query also leaves its occluder in st.hit.  The callers (trace(),
+//                   trace_quad(), wf_trace) then check the FINAL hit with ref_reached once per query, all lanes together,
+//                   and run the rare ray that tied or whose hit the reference would not have reached again under
+//                   GBL_TIE_EXACT (trace_needs_redo below says why that is the same answer).  Inline, the two rules cost the
+//                   headline kernel 32 %: a triangle is accepted 1.5 - 3 times per query, by a few lanes at a time.
+// `any`: the query kind as a value -- a compile-time constant through trav_other<ANY, ...> below.
 // FUSE: a leaf whose pop uncovers the instance's sentinel (and then, possibly, the exit marker) takes those steps at once instead
 // of spending an iteration of the caller's loop on each (needs st.world: the one-ray-per-lane loops only).
-// `wrec`: where the WORLD ray's origin and direction wait (6 words) when the caller does not keep st.world (the quads' records,
-// kernels/quadtrace.h); null: st.world.
-template <bool STATS, bool EXT, class STK, bool TIES, bool FUSE = false>
+#define GBL_TIE_NONE 0
+#define GBL_TIE_EXACT 1
+#define GBL_TIE_DETECT 2
+template <bool STATS, bool EXT, class STK, int TM, bool FUSE = false>
 __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, const bool ANY,
-                                                bool* occluded, int filter, const gbl_lds_u32* wrec = nullptr) {
+                                                bool* occluded, int filter) {
+    constexpr bool TIES = TM == GBL_TIE_EXACT;
     const int cur = st.cur;
     if (STATS) probe(cnt.oth_lane, cnt.oth_wave);
     if (cur == GBL_STACK_EXIT) return true;
@@ -417,13 +425,15 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         bool got = first == GBL_SHAPE_FIRST_SPHERE ? sphere_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t)
                                                    : disk_test(radius, st.r.o, st.r.d, st.mint, st.maxt, &t);
         if (TIES && got) {   // the TLAS leaf box in front of the shape (ref_reached)
-            const F3 wo = wrec ? f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])) : st.world.o;
-            const F3 wd = wrec ? f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])) : st.world.d;
             const DevInstanceBound wb = sc.instance_bounds[st.inst];
-            got = ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), wo, wd, st.mint, st.maxt0);
+            got = ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), st.world.o, st.world.d, st.mint, st.maxt0);
         }
         if (got) {
             if (ANY) {
+                if (TM == GBL_TIE_DETECT) {
+                    st.hit.inst = st.inst;
+                    st.hit.tri = 0;
+                }
                 *occluded = true;
                 return true;
             }
@@ -440,15 +450,16 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
         float t, b1, b2;
         if (STATS) cnt.tris += 1;
         if (tri_test(sc.tris + first + i, st.r.o, st.r.d, st.mint, st.maxt, &t, &b1, &b2)) {
-            if (TIES) {
-                const F3 wo = wrec ? f3(__uint_as_float(wrec[0]), __uint_as_float(wrec[1]), __uint_as_float(wrec[2])) : st.world.o;
-                const F3 wd = wrec ? f3(__uint_as_float(wrec[3]), __uint_as_float(wrec[4]), __uint_as_float(wrec[5])) : st.world.d;
-                if (!ref_reached(sc, st.inst, sc.tris[first + i].shade, wo, wd, st.r.o, st.r.d, st.mint, st.maxt0)) continue;
-            }
+            if (TIES && !ref_reached(sc, st.inst, first + i, st.world.o, st.world.d, st.r.o, st.r.d, st.mint, st.maxt0)) continue;
             if (ANY) {
+                if (TM == GBL_TIE_DETECT) {
+                    st.hit.inst = st.inst;
+                    st.hit.tri = first + i;
+                }
                 *occluded = true;
                 return true;
             }
+            if (TM == GBL_TIE_DETECT && t == st.hit.t && st.hit.inst == st.inst) st.tied = true;
 #ifndef GBL_NO_TIE_RULE
             if (TIES && t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr &&
                 !tie_goes_to(sc, st.hit.tri, first + i, st.r.o, st.r.d, st.mint, t))
@@ -473,10 +484,10 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
     }
     return false;
 }
-template <bool ANY, bool STATS, bool EXT, class STK, bool TIES = true, bool FUSE = false>
+template <bool ANY, bool STATS, bool EXT, class STK, int TM, bool FUSE = false>
 __device__ __forceinline__ bool trav_other(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt, bool* occluded,
-                                           int filter = GBL_FILTER_NONE, const gbl_lds_u32* wrec = nullptr) {
-    return trav_other_kind<STATS, EXT, STK, TIES, FUSE>(sc, st, stk, cnt, ANY, occluded, filter, wrec);
+                                           int filter = GBL_FILTER_NONE) {
+    return trav_other_kind<STATS, EXT, STK, TM, FUSE>(sc, st, stk, cnt, ANY, occluded, filter);
 }
 
 __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
@@ -491,11 +502,31 @@ __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
 #define GBL_TRAV_TH 24
 #endif
 
+// After a GBL_TIE_DETECT query: does this ray have to be traced again under GBL_TIE_EXACT?  `got`: it hit (or, any-hit, was
+// occluded by) triangle h.tri of instance h.inst.
+// Why checking the end of the query is enough.  Let C be the triangles whose test the ray passes within [mint, maxt]; the loop of
+// GBL_TIE_NONE returns the nearest of C (it accepts whatever is nearer than what it holds, and never culls a node in front of
+// that).  The reference returns the nearest REACHED member of C.  If the nearest of C is reached, and no second member sits at
+// exactly its distance (the loop would have tested it against the hit it held: st.tied), the two are the same triangle.  An
+// any-hit query is occluded exactly when some member of C is reached: if the one the loop stopped at is, it is.  Everything else
+// -- a tie, a hit the reference's box tests would have passed by -- goes through the exact loop, a handful of rays per 10^6.
+__device__ __forceinline__ bool trace_needs_redo(const DevScene& sc, bool EXT, bool got, const Hit& h, bool tied, F3 o, F3 d, float mint, float maxt) {
+    if (tied) return true;
+    if (!got) return false;
+    const DevInstanceBound wb = sc.instance_bounds[h.inst];
+    if (!ref_box_reached(f3(wb.lo[0], wb.lo[1], wb.lo[2]), f3(wb.hi[0], wb.hi[1], wb.hi[2]), o, d, mint, maxt)) return true;
+    const DevInstance* ip = sc.instances + h.inst;
+    if (EXT && ip->shape != 0u) return false;   // an analytic shape: the TLAS leaf box is all that stands in front of it
+    const float4* bp = reinterpret_cast<const float4*>(sc.tri_bounds + h.tri);
+    const float4 b0 = bp[0], b1 = bp[1];
+    return !ref_box_reached(f3(b0.x, b0.y, b0.z), f3(b0.w, b1.x, b1.y), xf_point(ip->inv, o), xf_vector(ip->inv, d), mint, maxt);
+}
+
 // ANY = true : Scene::occluded (first accepted triangle ends the query)
 // ANY = false: Scene::intersect (closest hit; hit.t shrinks like ray.maxt)
-template <bool ANY, bool STATS, bool EXT, bool TIES = true, class STK>
-__device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
-                                      LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
+template <bool ANY, bool STATS, bool EXT, int TM, class STK>
+__device__ __forceinline__ bool trace_loop(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
+                                           LaneCounters& cnt, int filter, bool* tied) {
     TravState st;
     trav_begin(sc, st, o, d, mint, maxt, stk);
     bool occluded = false;
@@ -513,11 +544,11 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
             if (trav_at_interior(st)) {
                 trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                 if (STATS) ++steps;
-            } else if (trav_other<ANY, STATS, EXT, STK, TIES>(sc, st, stk, cnt, &occluded, filter)) {
+            } else if (trav_other<ANY, STATS, EXT, STK, TM>(sc, st, stk, cnt, &occluded, filter)) {
                 break;
             }
         } else {
-            if (!trav_at_interior(st) && trav_other<ANY, STATS, EXT, STK, TIES, true>(sc, st, stk, cnt, &occluded, filter)) break;
+            if (!trav_at_interior(st) && trav_other<ANY, STATS, EXT, STK, TM, true>(sc, st, stk, cnt, &occluded, filter)) break;
             if (trav_at_interior(st)) {
                 trav_interior<STATS, !ANY>(sc, st, stk, cnt);
                 if (STATS) ++steps;
@@ -531,7 +562,28 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
         cnt.hist_steps[b] += steps;
     }
 #endif
-    if (ANY) return occluded;
+    if (TM == GBL_TIE_DETECT) *tied = st.tied;
+    if (ANY) {
+        if (TM == GBL_TIE_DETECT) hit = st.hit;   // (the occluder)
+        return occluded;
+    }
     hit = st.hit;
     return st.hit.inst >= 0;
+}
+// TIES: follow the reference's exact-t tie rule and reachability test (GBL_TIE_DETECT loop, end-of-query check, exact loop for
+// the rare ray that needs it); false: the bare loop.
+template <bool ANY, bool STATS, bool EXT, bool TIES = true, class STK>
+__device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint, float maxt, const STK& stk, Hit& hit,
+                                      LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
+    if constexpr (!TIES) {
+        return trace_loop<ANY, STATS, EXT, GBL_TIE_NONE>(sc, o, d, mint, maxt, stk, hit, cnt, filter, nullptr);
+    } else {
+        bool tied = false;
+        Hit h;
+        bool got = trace_loop<ANY, STATS, EXT, GBL_TIE_DETECT>(sc, o, d, mint, maxt, stk, h, cnt, filter, &tied);
+        if (trace_needs_redo(sc, EXT, got, h, tied, o, d, mint, maxt))
+            got = trace_loop<ANY, STATS, EXT, GBL_TIE_EXACT>(sc, o, d, mint, maxt, stk, h, cnt, filter, nullptr);
+        if (!ANY) hit = h;
+        return got;
+    }
 }

@@ -190,7 +190,9 @@ __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_
                 if (at_int) trav_interior<STATS, !ANY>(sc, st, stk, cnt);
             } else if (at_oth) {
                 bool occluded = false;
-                if (trav_other<ANY, STATS, EXT, SplitStack, TIES, GBL_WF_FUSE != 0>(sc, st, stk, cnt, &occluded, filter)) {
+                // (TIES: both rules inline at every accepted triangle.  The loop-plus-end-of-query-check form of trace() was measured here
+                //  too: with the exact loop inlined behind it the 96-register kernels spill 70 - 140 registers, Cornell 126 against 79 ms.)
+                if (trav_other<ANY, STATS, EXT, SplitStack, TIES ? GBL_TIE_EXACT : GBL_TIE_NONE, GBL_WF_FUSE != 0>(sc, st, stk, cnt, &occluded, filter)) {
                     if (ANY) {
                         if constexpr (masks) if (!occluded) {
                             // evalAttenuation along the unoccluded shadow segment, then f * tr * L * |n.wi| (* lWeight) / lightPdf

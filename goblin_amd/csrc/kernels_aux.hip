@@ -22,6 +22,14 @@ __global__ void vol_combine_kernel(float4* li, const float4* vol, uint64_t n) {
     const float4 L = li[i], tr = vol[2 * i], lv = vol[2 * i + 1];
     li[i] = make_float4(1.0f * (tr.x * L.x + lv.x), 1.0f * (tr.y * L.y + lv.y), 1.0f * (tr.z * L.z + lv.z), L.w);
 }
+// device-built trees: the triangle bounds (uploaded per original triangle) in the order the build left the triangles in
+__global__ void tri_bounds_gather_kernel(const DevTri* tris, const DevTriBound* by_id, DevTriBound* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = by_id[tris[i].shade];
+}
+void gbl_launch_tri_bounds_gather(const DevTri* tris, const DevTriBound* by_id, DevTriBound* out, uint32_t n) {
+    if (n) hipLaunchKernelGGL(tri_bounds_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, tris, by_id, out, n);
+}
 void gbl_launch_vol_combine(float4* li, const float4* vol, uint64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(vol_combine_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, li, vol, n);
 }

@@ -1363,5 +1363,8 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     float dxs = flt.wx / 16, dys = flt.wy / 16;
     for (int y = 0; y < 16; ++y)
         for (int x = 0; x < 16; ++x) out->filter_table[16 * y + x] = flt.eval(x * dxs, y * dys) / norm;
+    // the triangle bounds in the order of `tris` (what the kernels index with a hit's triangle); a device build gathers them itself
+    out->tri_bounds_leaf.resize(out->tris.size());
+    for (size_t i = 0; i < out->tris.size(); ++i) out->tri_bounds_leaf[i] = out->tri_bounds[out->tris[i].shade];
     return GBL_OK;
 }

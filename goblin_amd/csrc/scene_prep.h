@@ -10,7 +10,8 @@ struct PackedScene {
     std::vector<DevNode> nodes;
     std::vector<DevTri> tris;
     std::vector<DevTriShade> tri_shade;
-    std::vector<DevTriBound> tri_bounds;
+    std::vector<DevTriBound> tri_bounds;        // per original triangle (DevTri::shade)
+    std::vector<DevTriBound> tri_bounds_leaf;   // ... and in the order of `tris` (host-built trees)
     std::vector<DevInstanceBound> instance_bounds;
     std::vector<DevTriOrder> tri_order;
     std::vector<float> positions;         // 3 per vertex
