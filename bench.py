@@ -609,7 +609,7 @@ def main():
                 torch.cuda.synchronize()
                 tie_ms = (time.perf_counter() - t1) * 1e3 / n_tie
                 line["value_tie_exact"] = {"value": round(my_paths / tie_ms * 1e-3, 3), "unit": "Mpaths/s", "ms_per_step": round(tie_ms, 3), "steps": n_tie,
-                                           "note": "gbl_render_params.exact_ties = 1: the lean quad kernel with the reference's exact-t tie rule and reachability test kept (trace.h TIES)"}
+                                           "note": "gbl_render_params.exact_ties = 1: the lean quad kernel following the reference's exact-t tie rule and reachability test (trace.h GBL_TIE_DETECT: a flag in the loops, one check per query, an exact retrace of the rare ray)"}
             except Exception as e:
                 print("value_tie_exact leg failed: %s" % e, file=sys.stderr)
         if world == 1 and wl_name == "bunny":
