@@ -533,6 +533,8 @@ __device__ __forceinline__ bool trace_loop(const DevScene& sc, F3 o, F3 d, float
     TravState st;
     trav_begin(sc, st, o, d, mint, maxt, stk);
     bool occluded = false;
+    // (Every query starts at the TLAS root: taking that node from the kernel arguments -- through the scalar cache -- for a first
+    //  step ahead of the loop saved nothing, configs[1] 42.4 against 42.1 ms, and cost the EXT kernels 30 %.)
     // The megakernel's waves are mostly coherent (lanes are samples of one pixel), so every lane
     // simply takes the step it needs; phasing by majority state (GBL_TRAV_TH) only pays in the
     // wavefront trace kernel, whose waves mix rays of many pixels and depths (measured: 64.6 ms vs
