@@ -550,6 +550,11 @@ def test_device_built_bvh_traces_the_same_radiance(torch, schedule, name, ov):
     assert flips <= LI_FLIP_TOL
     assert helpers.li_mismatch_fraction(li_dev, li_host) <= LI_FLIP_TOL
     assert helpers.rel_l2(li_dev[:, :3], li_host[:, :3]) <= 1e-4
+    # ... and under exact_ties, whose end-of-query check reads the triangle bounds in the order the DEVICE build left the
+    # triangles in (gathered on the device, kernels_aux.hip): a wrong bound would send rays past triangles they hit
+    li_exact = dev.render(seed=seed, want_li=True, exact_ties=True)["li"].cpu().numpy()
+    assert helpers.li_mismatch_fraction(li_exact, li_ref) <= LI_FLIP_TOL
+    assert helpers.rel_l2(li_exact[:, :3], li_ref[:, :3]) <= LI_RELL2_TOL
 
 
 @pytest.mark.parametrize("bvh", ["host", "device"])
