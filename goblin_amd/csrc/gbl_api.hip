@@ -275,7 +275,7 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     const bool ext = sc.extended != 0;
     const bool masks = sc.has_masks != 0;
     // native sampler, lean build: no tie rule (trace.h)
-    const bool lean_native = !masks && !want_stats && !replay && p->exact_ties == 0;
+    const bool lean_native = !ext && !masks && !want_stats && !replay && p->exact_ties == 0;
     gbl_wf_kernel k_ext = gbl_kernel_wf_trace(false, want_stats, ext || masks || want_stats, masks, !lean_native);
     gbl_wf_kernel k_shd = gbl_kernel_wf_trace(true, want_stats, ext || masks || want_stats, masks, !lean_native);
     // persistent trace grids: exactly the resident workgroups (regions are assigned statically, so a

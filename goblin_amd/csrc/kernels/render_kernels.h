@@ -424,8 +424,9 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, St
 #define GBL_SRC_NATIVE 0
 #define GBL_SRC_REPLAY 1
 #define GBL_SRC_STREAM 2
-// EXACT: the native sampler's lean kernels compile the reference's exact-t tie rule out (trace.h TIES: +2 ... 3 % on the BASELINE
-// scenes for the ~5 ties per 10^7 paths it decides); gbl_render_params.exact_ties selects the instantiations that keep it.
+// EXACT: the native sampler's lean kernels leave the reference's exact-t tie rule and reachability test out (trace.h: +16 % on
+// configs[1] for the few rays per 10^6 they decide); gbl_render_params.exact_ties selects the instantiations that follow them.
+// Every other build does anyway: replay, stream, instrumented, and the EXT builds of the feature scenes.
 #ifdef GBL_STREAM_TM   // measurement builds: the stream sampler's phase clock in every instantiation (tools/stream_probe.py)
 #define GBL_STREAM_TM_ON true
 #else
@@ -435,7 +436,7 @@ template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = fal
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
-    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM, TIES = REPLAY || STATS || EXACT;
+    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM, TIES = REPLAY || STATS || EXACT || EXT;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 // (kernels/quadtrace.h); per-sample radiance only (ra.li_defer), LDS = quads' records | ctrl | stacks.
 template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = false>
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void ao_kernel(DevScene sc, RenderArgs ra) {
-    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM, TIES = REPLAY || STATS || EXACT;
+    constexpr bool REPLAY = SAMPLER != GBL_SRC_NATIVE, STREAM = SAMPLER == GBL_SRC_STREAM, TIES = REPLAY || STATS || EXACT || EXT;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tp = GBL_TILE + 2 * sc.film.halo;
     float* tile = reinterpret_cast<float*>(smem);

@@ -451,9 +451,11 @@ typedef struct gbl_render_params {
                                   GoblinPathtracer.cpp:76)                    */
     uint32_t collect_stats;    /* fill node/triangle counters (slower)        */
     uint32_t schedule;         /* gbl_schedule                                */
-    uint32_t exact_ties;       /* native sampler, lean scenes: resolve two triangles accepted at exactly the same t as the
-                                  reference's own BVH order does (replay / stream / instrumented renders always do); costs
-                                  2-3 % for the ~5 ties per 10^7 paths it decides, so it is off by default               */
+    uint32_t exact_ties;       /* native sampler, scenes of the headline feature set (the lean kernels): follow the reference's
+                                  BVH where two triangles are accepted at exactly the same t, and its non-watertight box tests
+                                  where a ray grazes one.  Every other render does anyway (replay, stream,
+                                  instrumented, scenes that need the EXT kernels); here it costs ~16 % for the few rays per
+                                  10^6 it decides, so it is off by default                                              */
     void* stream;              /* hipStream_t, NULL = default stream          */
 } gbl_render_params;
 
