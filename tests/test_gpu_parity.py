@@ -637,6 +637,11 @@ def test_full_size_properties_on_the_headline_config(torch):
     print("lean vs tie-exact megakernel: differing samples", differing, "of", li_mk.shape[0])
     assert differing <= 2e-6 * li_mk.shape[0]
     del again
+    # ... and the exact_ties kernel (`value_tie_exact` in the bench line: quad queries, ties flagged in the loops, one check of the
+    # final hit per query, the rare ray retraced exactly) gives the instrumented exact build's samples, all of them
+    exact = r.render(seed=seed, want_li=True, schedule="megakernel", exact_ties=True)["li"]
+    assert torch.equal(exact, li_mk)
+    del exact
     # films: same up to float summation order
     np.testing.assert_allclose(wf["film"].numpy(), film_lean, rtol=1e-4, atol=1e-5)
     # shards sum to the whole
