@@ -104,9 +104,34 @@ if __name__ == "__main__":
     build_all(force="--force" in sys.argv)
 
 
+def _code_only(text):
+    """C / C++ source without its comments and with runs of white space collapsed (string literals kept as they are)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def source_stamp():
-    """sha256 (first 16 hex digits) over every source file the HIP library is built from: profiles/ records it with the
-    counters it collects, bench.py only quotes counters whose stamp is the running tree's."""
+    """sha256 (first 16 hex digits) over the CODE of every source file the HIP library is built from -- comments and white
+    space do not count, so a note added beside a kernel does not orphan the counters collected from it: profiles/ records
+    the stamp with the counters it collects, bench.py only quotes counters whose stamp is the running tree's."""
     import hashlib
     h = hashlib.sha256()
     files = []
@@ -115,6 +140,6 @@ def source_stamp():
     files.append(os.path.join(REPO, "include", "goblin_hip.h"))
     for f in sorted(files):
         h.update(os.path.relpath(f, REPO).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+        with open(f, "r", encoding="utf-8", errors="replace") as fh:
+            h.update(_code_only(fh.read()).encode())
     return h.hexdigest()[:16]

@@ -130,3 +130,22 @@ def test_integration_binding_compiles_against_the_reference_headers(tmp_path):
                         "-Duniform_real=uniform_real_distribution", "-Duniform_int=uniform_int_distribution", "-D__HIP_PLATFORM_AMD__",
                         "-I/opt/rocm/include", "-I" + ref, "-I" + os.path.join(REPO, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[:4000]
+
+
+def test_source_stamp_counts_code_not_comments():
+    """goblin_amd/build.py source_stamp ties the committed rocprof counters to the tree they were collected from (bench.py only
+    quotes counters whose stamp is the running tree's).  It hashes code: a note beside a kernel must not orphan the counters,
+    a changed token must."""
+    from goblin_amd import build
+    a = 'int f(int x) {   // adds one\n    return x + 1; /* really */\n}\nconst char* s = "// not a comment /* nor this */";\n'
+    b = 'int f(int x) {\n  return x + 1;\n}\n\n// a later note\nconst char* s = "// not a comment /* nor this */";'
+    assert build._code_only(a) == build._code_only(b)
+    assert build._code_only(a) != build._code_only(a.replace("x + 1", "x + 2"))
+    assert build._code_only(a) != build._code_only(a.replace("// not a comment", "// no comment"))   # (inside a literal: code)
+    stamp = build.source_stamp()
+    assert len(stamp) == 16 and int(stamp, 16) >= 0
+    # the committed counter summaries carry the stamp of the tree they came from
+    import json
+    for name in ("pmc_bunny_megakernel", "pmc_cornell_wavefront", "pmc_grid_megakernel", "pmc_ao_megakernel"):
+        with open(os.path.join(REPO, "profiles", name + ".json")) as f:
+            assert len(json.load(f)["source_stamp"]) == 16
