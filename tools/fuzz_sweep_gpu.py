@@ -27,8 +27,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         if True:
             ref = o.render(threads=1)["film"]
             film = r.render(sampler="stream")["film"].numpy()
-            rel = helpers.rel_l2(ob.normalize_film(film), ob.normalize_film(ref))
-            if not (rel <= 6e-5) or not np.allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6):
+            # the accumulators themselves (a filter with negative lobes leaves weight sums near zero, where rgb / weight turns
+            # the last bit of a float sum into 1e-4: seeds 537, 766, 775)
+            rel = helpers.rel_l2(film, ref)
+            if not (rel <= 2e-6) or not np.allclose(film[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6):
                 bad.append((seed, whitted, "stream", rel))
                 print("STREAM MISMATCH seed", seed, "whitted" if whitted else "pt", "relL2 %.3g" % rel, flush=True)
     if seed % 10 == 9:
