@@ -202,6 +202,27 @@ __device__ __forceinline__ void stream_emit(StreamCtx& c, uint32_t* dst, uint32_
     if (dst) __syncthreads();   // what was stored is visible to the workgroup from here on
 }
 
+// the next `count` outputs reduced modulo S (<= 256) and left in LDS as bytes, output i at ld[(i % S) * B + i / S]: the column
+// shuffles' draws, which only ever matter modulo S, where the lanes that apply them find them (stream_generate_pixel).
+// Called by the whole workgroup.
+__device__ __forceinline__ void stream_emit_mod8(StreamCtx& c, unsigned char* ld, uint32_t count, uint32_t S, uint32_t B) {
+    const uint32_t pow2 = (S & (S - 1u)) == 0u ? S - 1u : 0u, shift = 31u - static_cast<uint32_t>(__clz(static_cast<int>(S)));
+    uint32_t done = 0;
+    while (done < count) {
+        if (c.pos == GBL_MT_N) mt_twist(c);
+        const uint32_t* cur = c.mt + c.which * GBL_MT_N;
+        const uint32_t n = min(GBL_MT_N - c.pos, count - done);
+        for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const uint32_t i = done + t, x = mt_temper(cur[c.pos + t]);
+            const uint32_t col = pow2 ? i >> shift : i / S, k = pow2 ? (i & pow2) : i - col * S;
+            ld[k * B + col] = static_cast<unsigned char>(pow2 ? (x & pow2) : x % S);
+        }
+        c.pos += n;
+        done += n;
+    }
+    __syncthreads();
+}
+
 // RNGImp::randomFloat: uniform_real_distribution<float>(0, 1) over one 32-bit draw -- generate_canonical<float, 24>
 // divides the draw (rounded to float) by 2^32 and steps a result of 1.0 down to the float below it
 __device__ __forceinline__ float stream_u01(uint32_t x) {
@@ -301,15 +322,25 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
     // pattern swaps its slot with itself.  Without such patterns (the path tracer's quota without a BSSRDF block) they are passed over.
     const uint32_t n_shuffled = L.NF + L.ncols * S;
     const bool in_pattern = L.F1 + L.F2 != L.patterns;
-    stream_emit(c, c.raw, in_pattern ? L.NF + L.NU : n_shuffled);
+    unsigned short* lp = reinterpret_cast<unsigned short*>(c.lperm);
+    // When every column's positions (16 bits) AND its shuffle draws modulo S (a byte: S <= 256) fit the LDS region together, the
+    // draws never go through global memory: they are left where the shuffling lanes read them (configs[1]: 31.5 KB of the 40).
+    const bool ld_draws = S <= 256u && L.ncols <= static_cast<uint32_t>(GBL_BLOCK) && 3u * S * L.ncols <= 4u * c.lperm_words;
+    const uint32_t B = ld_draws ? L.ncols : min(static_cast<uint32_t>(GBL_BLOCK), (2u * c.lperm_words) / S);   // columns per round
+    unsigned char* ld = reinterpret_cast<unsigned char*>(lp + S * B);
+    if (ld_draws) {
+        stream_emit(c, c.raw, L.NF);
+        stream_emit_mod8(c, ld, L.ncols * S, S, B);
+        if (in_pattern) stream_emit(c, c.raw + n_shuffled, L.NF + L.NU - n_shuffled);
+    } else {
+        stream_emit(c, c.raw, in_pattern ? L.NF + L.NU : n_shuffled);
+    }
     if (!in_pattern) stream_emit(c, nullptr, L.NF + L.NU - n_shuffled);
     if (tm) {
         const unsigned long long t1 = wall_clock64();
         tm[0] += t1 - t0;
         t0 = t1;
     }
-    unsigned short* lp = reinterpret_cast<unsigned short*>(c.lperm);
-    const uint32_t B = min(static_cast<uint32_t>(GBL_BLOCK), (2u * c.lperm_words) / S);   // columns per round
     // image samples: not shuffled (sample k sits in sub-cell k, GoblinSampler.cpp:130-131)
     for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
         float* rec = c.recs + static_cast<size_t>(k) * L.dims;
@@ -323,7 +354,15 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
         // (GoblinSampler.h:149-157), tracked as the position permutation of each column
         const uint32_t b = threadIdx.x, col = c0 + b;
         const uint32_t nb = min(B, L.ncols - c0);
-        if (b < nb) {
+        if (b < nb && ld_draws) {
+            for (uint32_t k = 0; k < S; ++k) lp[k * B + b] = static_cast<unsigned short>(k);
+            for (uint32_t n = 0; n < S; ++n) {
+                const uint32_t ia = n * B + b, ib = static_cast<uint32_t>(ld[n * B + b]) * B + b;
+                const unsigned short va = lp[ia], vb = lp[ib];
+                lp[ia] = vb;
+                lp[ib] = va;
+            }
+        } else if (b < nb) {
             for (uint32_t k = 0; k < S; ++k) lp[k * B + b] = static_cast<unsigned short>(k);
             const uint32_t* u = c.raw + L.NF + col * S;
             const uint32_t pow2 = (S & (S - 1u)) == 0u ? S - 1u : 0u;   // x % S without the division where S is a power of two
