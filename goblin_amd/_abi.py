@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(HERE, "lib")
 
-GBL_ABI_VERSION = 13
+GBL_ABI_VERSION = 14
 GBL_AUTO_WAVEFRONT_RAYS_PER_PATH, GBL_AUTO_WAVEFRONT_PATHS = 6.0, 1 << 22   # gbl_schedule AUTO thresholds (goblin_hip.h)
 GBL_OK, GBL_ERR_INVALID, GBL_ERR_UNSUPPORTED, GBL_ERR_IO, GBL_ERR_DEVICE, GBL_ERR_OOM, GBL_ERR_INTERNAL = range(7)
 STATUS_NAMES = {0: "GBL_OK", 1: "GBL_ERR_INVALID", 2: "GBL_ERR_UNSUPPORTED", 3: "GBL_ERR_IO",
@@ -157,7 +157,7 @@ HOST_SYMBOLS = ["gbl_host_load_file", "gbl_host_load_string", "gbl_host_desc", "
                 "gbl_host_read_image", "gbl_host_free_image"]
 GBL_CREATE_DEVICE_BVH = 1
 HIP_SYMBOLS = ["gbl_create", "gbl_create_ex", "gbl_update_instances", "gbl_render", "gbl_film_allreduce", "gbl_film_resolve", "gbl_get_info", "gbl_destroy",
-               "gbl_last_error", "gbl_abi_version", "gbl_get_timings", "gbl_selftest_sincos", "gbl_selftest_trace", "gbl_selftest_arith", "gbl_selftest_libm", "gbl_selftest_valu_issue", "gbl_selftest_placement"]
+               "gbl_last_error", "gbl_abi_version", "gbl_get_timings", "gbl_selftest_sincos", "gbl_selftest_trace", "gbl_selftest_arith", "gbl_selftest_libm", "gbl_selftest_valu_issue"]
 
 _host = None
 _hip = None
@@ -245,7 +245,6 @@ def hip_lib():
         lib.gbl_selftest_arith.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         lib.gbl_selftest_libm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         lib.gbl_selftest_valu_issue.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
-        lib.gbl_selftest_placement.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.gbl_destroy.argtypes = [C.c_void_p]
         lib.gbl_destroy.restype = None
         lib.gbl_last_error.argtypes = [C.c_void_p]

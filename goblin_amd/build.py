@@ -96,8 +96,40 @@ def build_cli(force=False):
     return out
 
 
+TIE_INLINE_UNITS = ("kernels_path", "kernels_quad", "kernels_wavefront")
+
+
+def build_tie_inline(force=False):
+    """lib/variants/libgoblin_hip_tieinl.so: the library with the tie rule FORCED inline into the traversal loops of the path
+    tracer's kernels (-DGBL_TIE_INLINE, kernels/trace.h) -- the form a StructurizeCFG bug of this compiler once miscompiled
+    (tools/compiler_bugs/).  Test infrastructure: tests/test_gpu_ties.py renders a scene where every hit is a tie with it and
+    with the shipped library; both must equal the oracle.  The other units are the regular build's objects."""
+    from concurrent.futures import ThreadPoolExecutor
+    vdir = os.path.join(LIB, "variants")
+    odir = os.path.join(LIB, "obj_tieinl")
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(odir, exist_ok=True)
+    out = os.path.join(vdir, "libgoblin_hip_tieinl.so")
+
+    def one(unit):
+        src = os.path.join(CSRC, unit + ".hip")
+        obj = os.path.join(odir, unit + ".o")
+        dep = obj + ".d"
+        deps = _depfile_deps(dep)
+        if force or deps is None or _stale(obj, [src] + deps):
+            _run([HIPCC] + HIP_FLAGS + ["-DGBL_TIE_INLINE", "-c", src, "-o", obj, "-MD", "-MF", dep])
+        return obj
+    with ThreadPoolExecutor(max_workers=len(TIE_INLINE_UNITS)) as pool:
+        vobjs = list(pool.map(one, TIE_INLINE_UNITS))
+    rest = [os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o") for s in HIP_SOURCES
+            if os.path.splitext(os.path.basename(s))[0] not in TIE_INLINE_UNITS]
+    if force or _stale(out, vobjs + rest):
+        _run([HIPCC, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC", "-o", out] + vobjs + rest + ["-ldl", "-lpthread"])
+    return out
+
+
 def build_all(force=False):
-    return build_host(force), build_hip(force), build_cli(force)
+    return build_host(force), build_hip(force), build_cli(force), build_tie_inline(force)
 
 
 if __name__ == "__main__":

@@ -707,39 +707,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         ctx->error = "unknown schedule " + std::to_string(p->schedule);
         return GBL_ERR_INVALID;
     }
-    // GBL_SCHEDULE_AUTO for the path tracer goes by how long the scene's paths are (see the schedule paragraph below): measured
-    // once per context and max_ray_depth by a pilot -- one instrumented sample per pixel over every 4th tile, native sampler,
-    // into a scratch film -- before anything of this call is queued.
-    float pilot_rays_per_path = 0.0f;
-    if (p->schedule == GBL_SCHEDULE_AUTO && p->integrator == GBL_INTEGRATOR_PATH && p->sample_mode != GBL_SAMPLES_STREAM && sc.has_masks == 0) {
-        auto it = ctx->auto_rays_per_path.find(p->max_ray_depth);
-        if (it == ctx->auto_rays_per_path.end()) {
-            float* scratch = nullptr;
-            HIP_TRY(ctx, hipSetDevice(ctx->device));
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&scratch), static_cast<size_t>(ctx->info.xres) * ctx->info.yres * 4 * sizeof(float)));
-            gbl_render_params pilot;
-            memset(&pilot, 0, sizeof(pilot));
-            pilot.integrator = GBL_INTEGRATOR_PATH;
-            pilot.sample_per_pixel = 1;
-            pilot.max_ray_depth = p->max_ray_depth;
-            pilot.ao_sample_num = p->ao_sample_num;
-            pilot.bssrdf_sample_num = p->bssrdf_sample_num;
-            pilot.tile_shard_index = 0;
-            pilot.tile_shard_count = 4;
-            pilot.sample_mode = GBL_SAMPLES_NATIVE;
-            pilot.seed = 0x9011057ull;
-            pilot.collect_stats = 1;
-            pilot.schedule = GBL_SCHEDULE_MEGAKERNEL;
-            pilot.stream = p->stream;
-            gbl_stats ps;
-            const gbl_status pst = gbl_render_impl(ctx, &pilot, scratch, &ps);
-            (void)hipFree(scratch);
-            if (pst != GBL_OK) return pst;
-            const float rpp = ps.paths ? static_cast<float>(static_cast<double>(ps.extension_rays + ps.shadow_rays) / static_cast<double>(ps.paths)) : 0.0f;
-            it = ctx->auto_rays_per_path.emplace(p->max_ray_depth, rpp).first;
-        }
-        pilot_rays_per_path = it->second;
-    }
     ra.integrator = static_cast<int32_t>(p->integrator);
     ra.spp = round_to_square(p->sample_per_pixel, &ra.root);
     ra.max_depth = p->max_ray_depth;
@@ -828,6 +795,49 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
         return GBL_OK;
     }
 
+    // GBL_SCHEDULE_AUTO for the path tracer goes by how long the scene's paths are (see the schedule paragraph below): measured
+    // once per context, max_ray_depth and Russian-roulette setting by a pilot -- one instrumented sample per pixel over every 4th
+    // tile, native sampler, into a scratch film -- before anything of this call is queued.  A call too small to fill the
+    // wavefront pool takes the megakernel whatever the pilot would say, so it does not pay for one.
+    const uint64_t call_paths = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * static_cast<uint64_t>(ra.window[3] - ra.window[2]) * ra.spp /
+                                static_cast<uint64_t>(ra.shard_count);
+    float pilot_rays_per_path = 0.0f;
+    if (p->schedule == GBL_SCHEDULE_AUTO && p->integrator == GBL_INTEGRATOR_PATH && p->sample_mode != GBL_SAMPLES_STREAM && sc.has_masks == 0 &&
+        call_paths >= GBL_AUTO_WAVEFRONT_PATHS) {
+        const int key = p->max_ray_depth * 2 + (p->russian_roulette != 0 ? 1 : 0);
+        auto it = ctx->auto_rays_per_path.find(key);
+        if (it == ctx->auto_rays_per_path.end()) {
+            float* scratch = nullptr;
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            const hipError_t me = hipMalloc(reinterpret_cast<void**>(&scratch), static_cast<size_t>(ctx->info.xres) * ctx->info.yres * 4 * sizeof(float));
+            if (me != hipSuccess) {
+                ctx->error = std::string("hipMalloc(AUTO pilot film): ") + hipGetErrorString(me);
+                return GBL_ERR_OOM;
+            }
+            gbl_render_params pilot;
+            memset(&pilot, 0, sizeof(pilot));
+            pilot.integrator = GBL_INTEGRATOR_PATH;
+            pilot.sample_per_pixel = 1;
+            pilot.max_ray_depth = p->max_ray_depth;
+            pilot.ao_sample_num = p->ao_sample_num;
+            pilot.bssrdf_sample_num = p->bssrdf_sample_num;
+            pilot.tile_shard_index = 0;
+            pilot.tile_shard_count = 4;
+            pilot.sample_mode = GBL_SAMPLES_NATIVE;
+            pilot.seed = 0x9011057ull;
+            pilot.russian_roulette = p->russian_roulette;   // roulette shortens the paths AUTO goes by
+            pilot.collect_stats = 1;
+            pilot.schedule = GBL_SCHEDULE_MEGAKERNEL;
+            pilot.stream = p->stream;
+            gbl_stats ps;
+            const gbl_status pst = gbl_render_impl(ctx, &pilot, scratch, &ps);
+            (void)hipFree(scratch);
+            if (pst != GBL_OK) return pst;
+            const float rpp = ps.paths ? static_cast<float>(static_cast<double>(ps.extension_rays + ps.shadow_rays) / static_cast<double>(ps.paths)) : 0.0f;
+            it = ctx->auto_rays_per_path.emplace(key, rpp).first;
+        }
+        pilot_rays_per_path = it->second;
+    }
     hipStream_t stream = static_cast<hipStream_t>(p->stream);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->work_counter, 0, sizeof(uint32_t), stream));
@@ -901,8 +911,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
     // and by whether the megakernel's LDS stacks would leave three workgroups per CU; the megakernel has since gained 6 ... 9 %
     // and wins the grid at every size.)
     const bool wf_capable = p->integrator == GBL_INTEGRATOR_PATH;
-    const uint64_t call_paths = static_cast<uint64_t>(ra.window[1] - ra.window[0]) * static_cast<uint64_t>(ra.window[3] - ra.window[2]) * ra.spp /
-                                static_cast<uint64_t>(ra.shard_count);
     const bool auto_wavefront = pilot_rays_per_path >= GBL_AUTO_WAVEFRONT_RAYS_PER_PATH && call_paths >= GBL_AUTO_WAVEFRONT_PATHS;
     bool wavefront = wf_capable && !stream_mode && (p->schedule == GBL_SCHEDULE_WAVEFRONT ||
                                     (p->schedule == GBL_SCHEDULE_AUTO && !sc.has_masks && auto_wavefront));
@@ -1246,7 +1254,10 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                     fprintf(stderr, " %s %.1f%%/%.1f%%", names[i], 100.0 * h[11 + i] / rays, 100.0 * h[18 + i] / std::max(1ull, steps));
                 fprintf(stderr, "\n");
             }
-            stats->paths = h[0];
+            // (the AO kernel of the stream sampler has no instrumented build, gbl_kernel_ao_stream: its launch leaves the device
+            //  counters at zero -- report the path count computed above and no ray counters rather than zeros for both)
+            const bool main_instrumented = !(stream_mode && p->integrator == GBL_INTEGRATOR_AO);
+            if (main_instrumented) stats->paths = h[0];
             stats->extension_rays = h[1];
             stats->shadow_rays = h[2];
             stats->nodes = h[3];

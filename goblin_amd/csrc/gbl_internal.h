@@ -45,7 +45,7 @@ struct gbl_ctx {
     uint64_t vol_entries = 0;
     float4* sss_buf = nullptr;   // per-sample Lsubsurface of the render in flight (scenes with subsurface materials)
     uint64_t sss_entries = 0;
-    std::map<int, float> auto_rays_per_path;   // GBL_SCHEDULE_AUTO's pilot: rays per camera path by max_ray_depth (gbl_render)
+    std::map<int, float> auto_rays_per_path;   // GBL_SCHEDULE_AUTO's pilot: rays per camera path by 2 * max_ray_depth + russian_roulette (gbl_render)
     double build_ms = 0.0;    // pack_scene + BVH construction + node / triangle upload
     // what gbl_update_instances needs to rebuild the TLAS
     std::vector<gbl_instance> h_instances;

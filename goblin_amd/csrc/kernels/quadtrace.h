@@ -476,7 +476,8 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
         const bool redo = want && trace_needs_redo(sc, EXT, ANY ? occluded : res.inst >= 0, res, st.tied, o, d, mint, maxt);
         if (__ballot(redo) != 0ull && redo) {
             Hit h;
-            const bool g = trace_loop<ANY, STATS, EXT, GBL_TIE_EXACT>(sc, o, d, mint, maxt, stk, h, cnt, filter, nullptr);
+            LaneCounters again = {};   // (the first pass counted this ray's visits)
+            const bool g = trace_loop<ANY, STATS, EXT, GBL_TIE_EXACT>(sc, o, d, mint, maxt, stk, h, again, filter, nullptr);
             if (ANY) occluded = g;
             else res = h;
         }

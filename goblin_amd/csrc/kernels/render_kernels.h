@@ -198,7 +198,7 @@ __device__ __forceinline__ void flush_tile(const DevFilm& film, float* tile, int
 //  barrier between items: Cornell 512^2 x 64 spp 69.1 -> 63.4 ms, the grid unchanged, configs[1] 42.1 -> 44.6 ms.  Items that
 //  start together keep the four waves of a workgroup on neighbouring pixels of one tile, which the short paths of configs[1]
 //  are worth more than their drains; the long-path scenes that gain run the wavefront schedule anyway.  Not kept.
-//  Nor were per-CU item lists: blocks b, b + 256, b + 512 of the persistent grid share a CU (tools/placement.py reads HW_REG_HW_ID),
+//  Nor were per-CU item lists: blocks b, b + 256, b + 512 of the persistent grid share a CU (read from HW_REG_HW_ID by a self test since removed),
 //  so a list per blockIdx % 256 puts a CU's twelve waves on the same tiles -- no gain on the Cornell box, the grid or AO, and
 //  configs[1] 42.8 -> 60.5 ms from the static split's imbalance (bunny tiles against background tiles).)
 __device__ __forceinline__ int wave_fetch(bool want, uint32_t* next_path) {

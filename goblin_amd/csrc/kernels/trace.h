@@ -329,11 +329,19 @@ __device__ __forceinline__ bool ref_leaf_reached(const DevScene& sc, uint32_t tr
     return ref_box_reached(f3(b0.x, b0.y, b0.z), f3(b0.w, b1.x, b1.y), o, d, mint, maxt);
 }
 // true: `cand` replaces the current hit `cur` (both accepted at t).
-// A function of its own, not inlined (plain pointers and floats: no DevScene to materialise for the call).  Inlined into the quad
-// queries' leaf loop (quadtrace.h) the same code decided 114 of 6.8e7 Cornell samples the other way at -O3 -- not with a printf
-// beside it, not in trace()'s loop, not out of line -- which cost a round of keeping the tie rule out of the quads; a cold call
-// site is also the better place for it: a handful of ties per 10^7 paths.
-static __device__ __attribute__((noinline)) bool tie_goes_to_impl(const DevTri* tris, const DevTriOrder* tri_order, const DevTriBound* tri_bounds, uint32_t cur,
+// A function of its own (plain pointers and floats: no DevScene to materialise for the call): a handful of ties per 10^7 paths,
+// and out of line its two dozen registers stay out of the loops that call it.  That is the only reason left -- for a round this
+// attribute was also what hid a miscompile (inlined into the quad queries' leaf loop the rule "decided" 114 of 6.8e7 Cornell
+// samples the other way at -O3, not with a printf beside it, not out of line).  The cause is a StructurizeCFG bug of this compiler,
+// found from the ISA and reduced to sixty lines of IR in round 4 (tools/compiler_bugs/); the code that triggered it was the caller's
+// accept block, not this function, and trav_other_kind no longer has such a block.  -DGBL_TIE_INLINE builds the inlined form
+// (tests/test_gpu_ties.py runs both against the oracle on a scene where every hit is a tie).
+#ifdef GBL_TIE_INLINE
+#define GBL_TIE_ATTR __forceinline__
+#else
+#define GBL_TIE_ATTR __attribute__((noinline))
+#endif
+static __device__ GBL_TIE_ATTR bool tie_goes_to_impl(const DevTri* tris, const DevTriOrder* tri_order, const DevTriBound* tri_bounds, uint32_t cur,
                                                            uint32_t cand, float ox, float oy, float oz, float dx, float dy, float dz, float mint, float t) {
     const uint32_t sa = tris[cur].shade, sb = tris[cand].shade;
     const DevTriOrder a = tri_order[sa], b = tri_order[sb];
@@ -463,17 +471,37 @@ __device__ __forceinline__ bool trav_other_kind(const DevScene& sc, TravState& s
                 return true;
             }
             if (TM == GBL_TIE_DETECT && t == st.hit.t && st.hit.inst == st.inst) st.tied = true;
+            if constexpr (TIES) {
+                // The accepted hit is written with SELECTS on a value the optimiser cannot see through, never from a block of its
+                // own.  Written the plain way -- `if (tie && !tie_goes_to(..)) continue; st.hit.tri = first + i; ...` -- the accept
+                // block is entered both straight from the tie check and from the end of the tie rule, and this compiler
+                // (AMD clang 22.0.0git roc-7.2.0) miscompiles exactly that shape once the rule is inlined: StructurizeCFG hoists
+                // the block's zero-cost `insertelement (inst, first + i)` above the tie check and then replaces the join's phi by
+                // the Flow phi [rejected pair, hoisted pair], so a lane that WINS a tie keeps the old triangle id with the new
+                // barycentrics (114 of 6.8e7 Cornell samples, round 3).  Reduced case and the ISA evidence:
+                // tools/compiler_bugs/structurizecfg_hoisted_phi.ll, DESIGN.md 6.  (A bool would do as well until JumpThreading
+                // unfolds a select on a phi of constants back into that block; the empty asm keeps it from knowing `take`.)
+                uint32_t take = 1u;
 #ifndef GBL_NO_TIE_RULE
-            if (TIES && t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr &&
-                !tie_goes_to(sc, st.hit.tri, first + i, st.r.o, st.r.d, st.mint, t))
-                continue;
+                if (t == st.hit.t && st.hit.inst == st.inst && sc.tri_order != nullptr)
+                    take = tie_goes_to(sc, st.hit.tri, first + i, st.r.o, st.r.d, st.mint, t) ? 1u : 0u;
 #endif
-            st.maxt = t;
-            st.hit.t = t;
-            st.hit.inst = st.inst;
-            st.hit.tri = first + i;
-            st.hit.b1 = b1;
-            st.hit.b2 = b2;
+                asm volatile("" : "+v"(take));
+                const bool acc = take != 0u;
+                st.maxt = acc ? t : st.maxt;
+                st.hit.t = acc ? t : st.hit.t;
+                st.hit.inst = acc ? st.inst : st.hit.inst;
+                st.hit.tri = acc ? first + i : st.hit.tri;
+                st.hit.b1 = acc ? b1 : st.hit.b1;
+                st.hit.b2 = acc ? b2 : st.hit.b2;
+            } else {
+                st.maxt = t;
+                st.hit.t = t;
+                st.hit.inst = st.inst;
+                st.hit.tri = first + i;
+                st.hit.b1 = b1;
+                st.hit.b2 = b2;
+            }
         }
     }
     st.cur = static_cast<int>(stk.load(--st.sp));
@@ -513,6 +541,12 @@ __device__ __forceinline__ bool trav_at_interior(const TravState& st) {
 // exactly its distance (the loop would have tested it against the hit it held: st.tied), the two are the same triangle.  An
 // any-hit query is occluded exactly when some member of C is reached: if the one the loop stopped at is, it is.  Everything else
 // -- a tie, a hit the reference's box tests would have passed by -- goes through the exact loop, a handful of rays per 10^6.
+// One case this (and ref_reached) does NOT restate: the reference tests a box against the ray's SHRINKING maxt (GoblinBVH.cpp:156-187
+// reads ray.maxt, which Triangle::intersect lowers), these against the query's own.  A triangle C that is nearer than the hit H the
+// reference holds when it gets to C's leaf, but whose flat leaf box has a tMin that rounds up to >= t(H) -- C and H within an ulp or
+// two of each other along the ray, not exactly tied -- is skipped by the reference and accepted here.  st.tied only catches exact
+// equality.  No fixture, none of the 2 300 fuzz scenes and none of the full-size blocks has produced one; it is stated as a limit
+//  rather than paid for with a "within k ulp" retrace whose k nobody could justify.
 __device__ __forceinline__ bool trace_needs_redo(const DevScene& sc, bool EXT, bool got, const Hit& h, bool tied, F3 o, F3 d, float mint, float maxt) {
     if (tied) return true;
     if (!got) return false;
@@ -586,8 +620,10 @@ __device__ __forceinline__ bool trace(const DevScene& sc, F3 o, F3 d, float mint
         bool tied = false;
         Hit h;
         bool got = trace_loop<ANY, STATS, EXT, GBL_TIE_DETECT>(sc, o, d, mint, maxt, stk, h, cnt, filter, &tied);
-        if (trace_needs_redo(sc, EXT, got, h, tied, o, d, mint, maxt))
-            got = trace_loop<ANY, STATS, EXT, GBL_TIE_EXACT>(sc, o, d, mint, maxt, stk, h, cnt, filter, nullptr);
+        if (trace_needs_redo(sc, EXT, got, h, tied, o, d, mint, maxt)) {
+            LaneCounters again = {};   // (instrumented builds: the first pass counted this ray's visits already)
+            got = trace_loop<ANY, STATS, EXT, GBL_TIE_EXACT>(sc, o, d, mint, maxt, stk, h, again, filter, nullptr);
+        }
         if (!ANY) hit = h;
         return got;
     }

@@ -331,39 +331,6 @@ gbl_status gbl_selftest_libm(gbl_ctx* ctx, int fn, const float* a, const float* 
     return gbl_guard([&] { return gbl_selftest_libm_impl(ctx, fn, a, b, out, n); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
 }
 
-// Where the hardware puts the workgroups of a persistent grid: out[2 b] = HW_REG_XCC_ID, out[2 b + 1] = HW_REG_HW_ID of block b's
-// first wave (a measurement aid for the work-distribution experiments of DESIGN_HISTORY / render_kernels.h; HIP promises nothing).
-__global__ void placement_kernel(uint32_t* out, uint32_t spin) {
-    extern __shared__ __align__(16) unsigned char pl_smem[];
-    if (threadIdx.x == 0) {
-        uint32_t xcc = 0, hw = 0;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        out[2 * blockIdx.x] = xcc;
-        out[2 * blockIdx.x + 1] = hw;
-        pl_smem[0] = 1;
-    }
-    // stay resident until every block of the grid has started (bounded: the grid is sized to be resident at once)
-    for (uint32_t i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);
-}
-static gbl_status gbl_selftest_placement_impl(gbl_ctx* ctx, uint32_t blocks, uint32_t lds_bytes, uint32_t* out_host) {
-    if (!ctx || !out_host || blocks == 0 || blocks > 65536 || lds_bytes > 160 * 1024) return GBL_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), blocks * 2 * sizeof(uint32_t)));
-    if (lds_bytes > 64 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(placement_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL(placement_kernel, dim3(blocks), dim3(GBL_BLOCK), lds_bytes, nullptr, d, 2000u);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(out_host, d, blocks * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    (void)hipFree(d);
-    return GBL_OK;
-}
-gbl_status gbl_selftest_placement(gbl_ctx* ctx, uint32_t blocks, uint32_t lds_bytes, uint32_t* out_host) {
-    return gbl_guard([&] { return gbl_selftest_placement_impl(ctx, blocks, lds_bytes, out_host); }, [&](const std::string& what) { if (ctx) ctx->error = what; });
-}
-
 static gbl_status gbl_selftest_valu_issue_impl(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out) {
     if (!ctx || !out || op < 0 || op >= GBL_VALU_OP_COUNT || waves_per_simd < 1 || waves_per_simd > 4 || iters == 0) return GBL_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

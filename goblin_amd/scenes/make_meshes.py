@@ -154,8 +154,46 @@ f 2 3 7 6
 """
 
 
+def ties_mesh(n=16, h=0.25):
+    """A floor on which (almost) every hit is an EXACT t tie (tests/test_gpu_ties.py, trace.h tie_goes_to).
+
+    Per cell of an n x n grid in the plane y = 0, from the cell's corner p0: triangle A = (p0, p0 + e1, p0 + e2), its twin A' (the
+    same three positions again -- same centre, so the reference's builder leaves the two in ONE leaf: GoblinBVH.cpp:106-118) and
+    B = (p0, p0 + 2 e1, p0 + 2 e2).  Moller-Trumbore on B is the arithmetic on A with every edge doubled: powers of two go through
+    every rounding, so wherever a ray passes A it gets bit-identical distances from all three -- and B, centred elsewhere, sits in
+    another leaf, so its tie with A / A' goes through the visiting order and the strict box test (GoblinBVH.cpp:156-187).  Each
+    triangle has its own tilted vertex normals, so the radiance tells which one the traversal kept.  All coordinates are
+    multiples of 1/8: exact in float32."""
+    verts, normals, faces = [], [], []
+    tilt = ((0.3, 1.0, 0.0), (-0.3, 1.0, 0.2), (0.0, 1.0, -0.35))
+    for k, t in enumerate(tilt):
+        l = math.sqrt(sum(c * c for c in t))
+        normals.append(tuple(c / l for c in t))
+    for j in range(n):
+        for i in range(n):
+            x0, z0 = -0.5 * n * h + i * h, -0.5 * n * h + j * h
+            for kind, s in ((0, 1.0), (1, 1.0), (2, 2.0)):
+                base = len(verts)
+                verts += [(x0, 0.0, z0), (x0, 0.0, z0 + s * h), (x0 + s * h, 0.0, z0)]   # e1 = +z, e2 = +x: the face looks up
+                faces.append((base, base + 1, base + 2, kind))
+    return verts, normals, faces
+
+
+def write_ties(path, n=16, h=0.25):
+    verts, normals, faces = ties_mesh(n, h)
+    with open(path, "w") as f:
+        f.write("# %d coplanar triangles, three per cell with bit-identical hit distances (make_meshes.py ties_mesh)\n" % len(faces))
+        for v in verts:
+            f.write("v %.6f %.6f %.6f\n" % v)
+        for nn in normals:
+            f.write("vn %.6f %.6f %.6f\n" % nn)
+        for (a, b, c, k) in faces:
+            f.write("f %d//%d %d//%d %d//%d\n" % (a + 1, k + 1, b + 1, k + 1, c + 1, k + 1))
+
+
 def main(outdir):
     os.makedirs(outdir, exist_ok=True)
+    write_ties(os.path.join(outdir, "ties.obj"))
     verts, faces = build()
     write_obj(os.path.join(outdir, "bunny.obj"), verts, faces)
     # low-res variant WITH vertex normals: exercises the interpolated-normal

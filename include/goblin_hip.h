@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GBL_ABI_VERSION 13
+#define GBL_ABI_VERSION 14
 
 typedef enum gbl_status {
     GBL_OK = 0,
@@ -556,10 +556,6 @@ typedef enum gbl_valu_op {
     GBL_VALU_MED3_F32 = 10, GBL_VALU_CMP_F32 = 11, GBL_VALU_OP_COUNT = 12
 } gbl_valu_op;
 gbl_status gbl_selftest_valu_issue(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out);
-
-/* Self-test hook: where the hardware places the workgroups of a grid of `blocks` x 256 threads with `lds_bytes` of LDS each:
- * out_host[2 b] = HW_REG_XCC_ID, out_host[2 b + 1] = HW_REG_HW_ID of block b (host memory, 2 * blocks words). */
-gbl_status gbl_selftest_placement(gbl_ctx* ctx, uint32_t blocks, uint32_t lds_bytes, uint32_t* out_host);
 
 void gbl_destroy(gbl_ctx* ctx);
 /* Message for the last failing call on ctx (or on creation when ctx == NULL). */

@@ -137,6 +137,10 @@ CASES = {
     "imagetex_pt": ("imagetex", ov((64, 64), 9, 5), 2048, False),
     "ibl_pt": ("ibl", ov((64, 64), 9, 5), 2048, False),
     "ibl_whitted": ("ibl", ov((48, 48), 4, 3, method="whitted"), 1024, False),
+    # a floor of coplanar triangles with bit-identical hit distances (goblin_amd/scenes/make_meshes.py ties_mesh): nearly every
+    # hit is an exact-t tie, within one two-triangle leaf of the reference's tree or across leaves (GoblinTriangle.cpp:74-80,
+    # GoblinBVH.cpp:106-118, 156-187) -- what the oracle's and the device's tie rule restate
+    "ties_pt": ("ties", ov((64, 64), 9, 4), 4096, False),
     "subsurface_n9": ("subsurface", dict(ov((40, 40), 4, 4), render_setting=dict(ov((40, 40), 4, 4)["render_setting"], bssrdf_sample_num=7)), 1024, False),
 }
 

@@ -78,7 +78,7 @@ def fake_window(full, n_pixels):
 @pytest.mark.parametrize("case", ["bunny_pt", "bunny_pt_d8", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "bunny_vn_box",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "shapes_ao", "textured_pt", "textured_ortho", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
-                                  "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao"])
+                                  "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao", "ties_pt"])
 def test_li_matches_reference_records(golden, torch, schedule, case):
     """(Sample -> Li) pairs captured from the real reference, replayed on the GPU."""
     meta, data = golden(case)
@@ -108,7 +108,7 @@ def test_li_matches_reference_records(golden, torch, schedule, case):
 @pytest.mark.parametrize("case", ["bunny_pt", "cornell_pt", "cornell_pt_d16", "grid_pt", "bunny_ao", "cornell_triangle_crop", "cornell_mitchell",
                                   "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "textured_ortho", "masked_pt",
                                   "subsurface_pt", "whitted", "subsurface_whitted", "whitted_sss", "masked_whitted", "imagetex_pt", "ibl_pt", "ibl_whitted",
-                                  "bumpy_pt", "bumpy_whitted"])
+                                  "bumpy_pt", "bumpy_whitted", "ties_pt"])
 def test_film_matches_reference_film(golden, torch, schedule, case):
     """Whole-film parity against the reference's Film: the oracle regenerates the
     reference's exact Sample stream (it is bit-exact with it), the GPU replays it."""
@@ -137,7 +137,7 @@ def test_film_matches_reference_film(golden, torch, schedule, case):
                                   "cornell_mitchell", "shapes_pt", "shapes_thinlens", "shapes_ortho", "textured_pt", "masked_pt",
                                   "subsurface_pt", "subsurface_n9", "whitted", "whitted_d2", "subsurface_whitted", "whitted_sss", "masked_whitted",
                                   "imagetex_pt", "ibl_pt", "ibl_whitted", "bumpy_pt", "bumpy_whitted", "bumpy_ao",
-                                  "hetero_pt", "hetero_spot", "hetero_tint_whitted", "hetero_tint_ao"])
+                                  "hetero_pt", "hetero_spot", "hetero_tint_whitted", "hetero_tint_ao", "ties_pt"])
 def test_stream_mode_reproduces_the_reference_film(golden, torch, case):
     """GBL_SAMPLES_STREAM: the device generates the reference's own Sample stream (per-tile mt19937 seeded from rand(),
     Sampler::requestSamples, the discarded BSDFSample(rng) draws) -- nothing is uploaded, and the Film accumulators
