@@ -110,21 +110,29 @@ def pmc_for(workload, schedule, integrator, frame_spp=None):
             agg["kernel_avg_ms"] = agg.get("kernel_avg_ms", 0.0) + c.get("kernel_avg_ms", 0.0) * per_render
         if agg.get("SQ_INSTS_VALU"):
             agg = {k: v * factor for k, v in agg.items()}
-            return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp,
+            # resident waves per SIMD of the kernels the step spends its time in: the two trace kernels (register allocation
+            # as the profiler saw it at launch)
+            regs = kernel_registers()
+            tr = [regs[k] for k in d.get("counters_per_launch", {}) if k.startswith("void wf_trace<") and _template_arg(k, 1) == "false" and k in regs]
+            waves = min(waves_per_simd_of(v, a) for v, a in tr) if tr else None
+            return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp, waves_per_simd=waves,
                         scaled_from_spp=d.get("spp_profiled") if factor != 1.0 else None), None
         return None, "no wavefront kernels in %s" % os.path.basename(path)
     name = LEAN_KERNELS.get((integrator, schedule))
     c = d.get("counters_per_launch", {}).get(name)
     if c:
         c = {k: (v * factor if isinstance(v, (int, float)) and k in keys + ("kernel_avg_ms",) else v) for k, v in c.items()}
+        li = kernel_registers().get(name)
         return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp,
+                    waves_per_simd=waves_per_simd_of(li[0], li[1]) if li else None,
                     scaled_from_spp=d.get("spp_profiled") if factor != 1.0 else None), None
     return None, "no kernel %r in %s" % (name, os.path.basename(path))
 
 
 def valu_issue_peak(waves_per_simd):
     """The measured VALU issue peak (tools/valu_peak.py -> profiles/valu_issue_peak.json): v_fma_f32 and v_add_f32, independent
-    chains, `waves_per_simd` resident waves on every SIMD of every CU."""
+    chains, `waves_per_simd` resident waves on every SIMD of every CU; one >= 10 ms launch after 2 s of the same launch back to
+    back, cycles from s_memtime, the clock from s_memtime / s_memrealtime."""
     path = os.path.join(REPO, "profiles", "valu_issue_peak.json")
     if not os.path.exists(path):
         return None
@@ -136,9 +144,72 @@ def valu_issue_peak(waves_per_simd):
         if not rows:
             return None
         out[tag + "_cycles_per_instruction_per_simd"] = rows[0]["ticks_per_instruction_per_simd"]
-        out[tag + "_g_wave_instructions_per_s"] = rows[0]["g_wave_instructions_per_s"]
-        out[tag + "_clock_ghz_under_that_load"] = rows[0]["tick_rate_ghz"]
+        out[tag + "_clock_ghz_under_that_load"] = rows[0].get("clock_ghz", rows[0].get("tick_rate_ghz"))
     return out
+
+
+_KERNEL_REGS = None
+
+
+def kernel_registers():
+    """{demangled kernel name: (vgpr, agpr)} of the library this process runs, read from its code objects' metadata
+    (tools/kernel_resources.py).  (rocprofv3's VGPR_Count column is in allocation units of two registers: not used.)"""
+    global _KERNEL_REGS
+    if _KERNEL_REGS is None:
+        _KERNEL_REGS = {}
+        try:
+            lib = os.environ.get("GOBLIN_HIP_LIB") or os.path.join(REPO, "goblin_amd", "lib", "libgoblin_hip.so")
+            out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "kernel_resources.py"), "--json", lib], capture_output=True, text=True, timeout=120).stdout
+            for r in json.loads(out):
+                _KERNEL_REGS[r["name"]] = (int(r.get("vgpr_count", 0)), int(r.get("agpr_count", 0)))
+        except Exception as e:
+            print("kernel_registers: %s" % e, file=sys.stderr)
+    return _KERNEL_REGS
+
+
+def waves_per_simd_of(vgpr, agpr=0):
+    """Resident waves per SIMD a kernel's register allocation allows (MI355X_MICROARCH.md: 512 registers per lane per SIMD,
+    allocated in steps of 8, at most 8 waves)."""
+    alloc = max(8, (int(vgpr) + int(agpr) + 7) // 8 * 8)
+    return max(1, min(8, 512 // alloc))
+
+
+def issue_reading(r, issue):
+    """What the counters of this line say bounds the kernel -- composed from them, so that no sentence can contradict the
+    field beside it."""
+    parts = []
+    toa = r.get("traffic_over_algorithmic")
+    if toa is not None:
+        if toa < 0.1:
+            parts.append("cache resident: %.1f %% of the algorithmic bytes reach HBM (%.0f GB/s, %.1f %% of the 8 TB/s peak), so HBM does not bound this kernel"
+                         % (100 * toa, r.get("traffic_gbps", 0.0), 100 * r.get("traffic_gbps", 0.0) / HBM_PEAK_GBPS))
+        else:
+            parts.append("HBM traffic is %.2f x the algorithmic bytes (%.0f GB/s, %.0f %% of the 8 TB/s peak): the path state streams through HBM every iteration"
+                         % (toa, r.get("traffic_gbps", 0.0), 100 * r.get("traffic_gbps", 0.0) / HBM_PEAK_GBPS))
+    if "l2_hit_rate" in issue:
+        parts.append("L2 hit rate %.2f" % issue["l2_hit_rate"])
+    if "wait_frac_pmc" in issue:
+        parts.append("of the waves' cycles %.0f %% are parked on memory (s_waitcnt), %.0f %% issue-stalled, %.0f %% issuing"
+                     % (100 * issue["wait_frac_pmc"], 100 * issue.get("issue_stall_frac_pmc", 0.0), 100 * issue.get("active_frac_pmc", 0.0)))
+    cpi = issue.get("cycles_per_instruction_per_simd")
+    peak = issue.get("measured_peak")
+    if cpi and peak:
+        parts.append("a SIMD issues one wave64 VALU instruction per %.2f cycles at %d waves per SIMD where the microbenchmark sustains one per %.2f"
+                     % (cpi, issue["waves_per_simd"], peak["fma_cycles_per_instruction_per_simd"]))
+    elif cpi:
+        parts.append("a SIMD issues one wave64 VALU instruction per %.2f cycles at %d waves per SIMD" % (cpi, issue["waves_per_simd"]))
+    if "lane_util_pmc" in issue:
+        parts.append("%.0f %% of the lanes of an issued VALU instruction are switched on" % (100 * issue["lane_util_pmc"]))
+    verdict = None
+    if toa is not None and toa >= 0.5 and issue.get("wait_frac_pmc", 0) >= 0.45:
+        verdict = "bound by memory: state traffic and the latency of the traversal's dependent fetches"
+    elif issue.get("wait_frac_pmc", 0) >= 0.35:
+        verdict = "latency bound (dependent node / triangle fetches) under low lane utilisation, not bandwidth bound"
+    elif cpi and cpi <= 2.6:
+        verdict = "VALU issue bound"
+    if verdict:
+        parts.append(verdict)
+    return "; ".join(parts)
 
 
 def roofline_object(counted, kernel_ms, pmc, pmc_note, kernel_label, waves_per_simd=3):
@@ -174,26 +245,22 @@ def roofline_object(counted, kernel_ms, pmc, pmc_note, kernel_label, waves_per_s
                     issue[out] = round(pmc[key] / pmc["SQ_WAVE_CYCLES"], 4)
         if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
             issue["lane_util_pmc"] = round(pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"]), 4)
+        waves_per_simd = pmc.get("waves_per_simd") or waves_per_simd
+        issue["waves_per_simd"] = int(waves_per_simd)
         peak = valu_issue_peak(min(4, waves_per_simd))   # (the microbenchmark covers 1-4 resident waves per SIMD)
         if peak:
             # in cycles: what a SIMD with this many waves can issue (measured, independent v_fma_f32) against what the kernel's
-            # instruction stream took per instruction -- at the kernel's own clock, which it keeps (the all-FMA microbenchmark
-            # is power-throttled to a lower one)
+            # instruction stream took per instruction, each at the clock its own launch held
             issue["measured_peak"] = peak
             issue["frac_of_fma_issue_peak_in_cycles"] = round(peak["fma_cycles_per_instruction_per_simd"] / issue["cycles_per_instruction_per_simd"], 4)
-            issue["frac_of_fma_issue_peak_in_wall_time"] = round(ach_i / peak["fma_g_wave_instructions_per_s"], 4)
-        issue["reading"] = ("the scene is cache resident (traffic is a few per cent of the algorithmic bytes), so HBM does not bound this "
-                            "kernel; its waves sit parked on memory for wait_frac_pmc of their cycles and a SIMD issues one wave64 "
-                            "instruction per cycles_per_instruction_per_simd cycles where the microbenchmark sustains one per "
-                            "fma_cycles_per_instruction_per_simd: latency bound (dependent node / triangle fetches at three waves per "
-                            "SIMD), with lane_util_pmc of the lanes switched on")
+        issue["reading"] = issue_reading(r, issue)
         r["issue"] = issue
     else:
         r["pmc_note"] = pmc_note
     return r
 
 
-def cpu_baseline(workload_overrides, spp_sample, cores):
+def cpu_baseline(workload_overrides, spp_sample, cores, scene_name="bunny", what="bunny.json 512x512", full_spp=256, port=True):
     """Time the CPU path on a bounded sample of the same workload (same scene, film,
     filter and depth; fewer samples per pixel).  Prefers the REAL reference built into
     oracle/_ref (kind "reference"); falls back to the oracle port."""
@@ -202,13 +269,13 @@ def cpu_baseline(workload_overrides, spp_sample, cores):
     ov = json.loads(json.dumps(workload_overrides))
     ov.setdefault("render_setting", {})["sample_per_pixel"] = spp_sample
     harness = os.path.join(REPO, "oracle", "_ref", "ref_harness")
-    sample = "bunny.json 512x512, %d spp (of 256), max_ray_depth 8, %d threads" % (spp_sample, cores)
-    if spp_sample >= 256:
-        sample = "bunny.json 512x512, 256 spp (the whole workload), max_ray_depth 8, %d threads" % cores
+    sample = "%s, %d spp (of %d), %d threads" % (what, spp_sample, full_spp, cores)
+    if spp_sample >= full_spp:
+        sample = "%s, %d spp (the whole workload), %d threads" % (what, full_spp, cores)
     out = None
     if os.path.exists(harness):
         try:
-            src = gs.scene_path("bunny")
+            src = gs.scene_path(scene_name)
             with open(src) as f:
                 doc = json.load(f)
             gs._merge(doc, ov)
@@ -232,11 +299,13 @@ def cpu_baseline(workload_overrides, spp_sample, cores):
                    % (res["paths"], res["seconds"]), "_film": ref_film}
         except Exception as e:  # the prebuilt binary may be absent or unusable on this box
             print("cpu_baseline: reference harness failed (%s); using the oracle port" % e, file=sys.stderr)
+    if not port and out is not None:
+        return out
     try:
         import oracle_binding as ob
         ov_port = json.loads(json.dumps(ov))
         ov_port["render_setting"]["sample_per_pixel"] = min(spp_sample, 16)   # the port is a side note: keep it short
-        scene = gs.load_scene("bunny", ov_port)
+        scene = gs.load_scene(scene_name, ov_port)
         oracle = ob.Oracle(scene)
         res = oracle.render(threads=cores, ref_faithful=1)
         port = scene.num_paths() / res["seconds"] * 1e-6
@@ -407,9 +476,10 @@ def counters_of(wl, seed, shard, schedule, scale_from_spp=None):
     return wl.render_frame(seed=seed, shard=shard, stats=True, schedule=schedule)["stats"]
 
 
-def one_config(name, device_index, seed, torch):
-    """One full-size step of another BASELINE configuration (N = 1, after the headline's timed region): device time, rates,
-    the schedule AUTO resolved to, counters and SURVEY 8(d)'s fraction."""
+def one_config(name, device_index, seed, torch, steps=1, cpu_cores=0):
+    """`steps` full-size steps of another BASELINE configuration (N = 1, after the headline's timed region): the median step's
+    device time and rates, the schedule AUTO resolved to, counters, SURVEY 8(d)'s fraction, and -- with cpu_cores -- the compiled
+    reference on a bounded sample of the same frame."""
     from goblin_amd import _abi
     wl = Workload(name, device_index)
     # warm-up (allocates the radiance buffer / the wavefront pool): a full step where that is a few seconds, 16 spp for the
@@ -421,26 +491,82 @@ def one_config(name, device_index, seed, torch):
     else:
         wl.render_frame(seed=seed)
     torch.cuda.synchronize()
-    wl.film.zero_()
-    t0 = time.perf_counter()
-    full = wl.render_frame(seed=seed, timed=True)   # (timed: the library also reports the schedule AUTO resolved this call to)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3
+    runs = []
+    for _ in range(steps):
+        wl.film.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = wl.render_frame(seed=seed, timed=True)   # (timed: the library also reports the schedule AUTO resolved this call to)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        timings = wl.tracer.timings(len(wl.bands))
+        runs.append((ms, sum(x[0] for x in timings) if timings else ms))
+    runs.sort()
+    ms, kernel_ms = runs[len(runs) // 2]
     resolved = {1: "megakernel", 2: "wavefront"}.get(full["stats"]["schedule"], "megakernel")
-    timings = wl.tracer.timings(len(wl.bands))
-    kernel_ms = sum(x[0] for x in timings) if timings else ms
     counted = counters_of(wl, seed, None, resolved, scale_from_spp=64 if wl.scene.spp() > 256 else None)
     paths = counted["paths"]
     rays = counted["extension_rays"] + counted["shadow_rays"]
     pmc, note = pmc_for(name, resolved, wl.integrator, wl.scene.spp())
     roof = roofline_object({k: v for k, v in counted.items() if not k.startswith("_")}, kernel_ms, pmc, note, wl.kernel_label(resolved),
                            waves_per_simd=5 if resolved == "wavefront" else 3)
-    out = {"workload": wl.describe(), "schedule": resolved, "steps": 1, "ms_per_step": round(ms, 2), "kernel_ms": round(kernel_ms, 2),
+    out = {"workload": wl.describe(), "schedule": resolved, "steps": steps, "ms_per_step": round(ms, 2), "ms_all_steps": [round(r[0], 2) for r in runs],
+           "kernel_ms": round(kernel_ms, 2),
            "paths_per_step": int(paths), "value": round(paths / ms * 1e-3, 2), "unit": "Mpaths/s",
            "rays_per_path": round(rays / max(1, paths), 3), "grays_per_s": round(rays / ms * 1e-6, 3), "roofline": roof}
+    if steps > 1:
+        out["note"] = "median of %d steps" % steps
     if "_scaled_from_spp" in counted:
         out["counters_note"] = "counted by an instrumented launch at %d spp and scaled to the frame's %d" % (counted["_scaled_from_spp"], wl.scene.spp())
+    if cpu_cores:
+        # the compiled reference on the same frame at a few samples per pixel (its rate does not depend on the count: the
+        # sampler is stratified per pixel); ~5-15 s each on a many-core host
+        cpu_spp = {"cornell": 16, "grid": 16, "ao": 4}[name]
+        try:
+            cb = cpu_baseline(wl.overrides, cpu_spp, cpu_cores, scene_name=wl.scene_name,
+                              what="%s.json %dx%d%s" % (wl.scene_name, wl.res[0], wl.res[1], ", AO" if wl.integrator == "ao" else ""),
+                              full_spp=wl.scene.spp(), port=False)
+            if cb:
+                cb.pop("_film", None)
+                out["cpu_baseline"] = cb
+                out["gpu_over_cpu"] = round(out["value"] / cb["value"], 1) if cb.get("value") else None
+        except Exception as e:
+            print("other_configs[%s] cpu_baseline failed: %s" % (name, e), file=sys.stderr)
     del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+FEATURE_SCENES = ("whitted", "hetero", "masked")
+
+
+def feature_scenes(device_index, seed, torch):
+    """One step each of three scenes outside the headline feature set: the Whitted integrator, a
+    heterogeneous participating medium, mask materials -- 512x512 film, 64 spp (17 M camera paths), AUTO schedule.  The best of
+    three steps; no roofline (their EXT kernels are shading bound)."""
+    from goblin_amd import scene as gs
+    from goblin_amd.renderer import HipPathTracer
+    out = {}
+    for name in FEATURE_SCENES:
+        try:
+            scene = gs.load_scene(name, gs.config_overrides(resolution=(512, 512), spp=64))
+            tr = HipPathTracer(scene, device_index)
+            film = tr.new_film()
+            best, paths = 1e30, 0
+            for _ in range(3):
+                film.zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = tr.render(film=film, seed=seed)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+                paths = r["paths"]
+            integ = {0: "path_tracing", 1: "ao", 2: "whitted"}.get(int(scene.desc.setting.integrator), "?")
+            out[name] = {"workload": "%s.json 512x512, 64 spp, %s" % (name, integ), "paths_per_step": int(paths), "ms_per_step": round(best, 2),
+                         "value": round(paths / best * 1e-3, 1), "unit": "Mpaths/s", "steps": 3, "film_mean": round(float(film.normalized().mean()), 6)}
+            del tr, film
+        except Exception as e:
+            out[name] = {"error": str(e)}
     torch.cuda.empty_cache()
     return out
 
@@ -458,6 +584,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / l2 legs")
     ap.add_argument("--no-others", action="store_true", help="skip the full-size steps of the other BASELINE configurations")
     ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel"], default="auto")
+    ap.add_argument("--dump-film", default=None, help="rank 0 saves the film accumulators of the last step (reduced, N > 1) as .npy (tests)")
     args = ap.parse_args()
 
     import torch
@@ -511,6 +638,9 @@ def main():
         zero_film=film.zero_, allreduce=lambda: gd.allreduce_film(film.accum), barrier=gd.barrier, sync=torch.cuda.synchronize,
         steps=args.steps, warmup=args.warmup, world=world, make_event=lambda: torch.cuda.Event(enable_timing=True))
     my_elapsed = elapsed
+    if args.dump_film and rank == 0:
+        import numpy as np
+        np.save(args.dump_film, film.accum.detach().cpu().numpy())
     call_ms = [a for a, _ in per_step]          # device events around gbl_render (the launch stream)
     reduce_ms = [b for _, b in per_step]
     my_trace_ms = sum(call_ms) / len(call_ms)
@@ -530,6 +660,16 @@ def main():
         per_rank = [g.cpu().tolist() for g in gathered]
     elapsed = float(t.item())
     job_paths = float(paths.item())   # paths all ranks traced in one step
+    if per_rank is not None:
+        # every rank resolves GBL_SCHEDULE_AUTO by itself (its own pilot over its own tiles): they must all have come to the same
+        # schedule, or the ranks' times would not be comparable and the film would mix two summation orders
+        resolved_all = [int(p[3]) for p in per_rank]
+        if len(set(resolved_all)) != 1:
+            if rank == 0:
+                print("bench.py: the ranks resolved GBL_SCHEDULE_AUTO differently: %s (1 = megakernel, 2 = wavefront); pass --schedule"
+                      % resolved_all, file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
 
     # what AUTO resolved to: the library reports the schedule a call ran under (gbl_stats.schedule)
     resolved = args.schedule if args.schedule != "auto" else {1: "megakernel", 2: "wavefront"}.get(counted.get("schedule"), "megakernel")
@@ -633,12 +773,16 @@ def main():
         if world == 1 and wl_name == "bunny" and wl.standard and not args.no_others:
             # every other BASELINE configuration, one full-size step each, outside the headline's timed region
             line["other_configs"] = {}
+            host_cores = max(1, len(os.sched_getaffinity(0)))
             for other in ("cornell", "grid", "ao"):
                 try:
-                    line["other_configs"][other] = one_config(other, device_index, base_seed, torch)
+                    line["other_configs"][other] = one_config(other, device_index, base_seed, torch, steps=1 if other == "ao" else 3,
+                                                              cpu_cores=host_cores if (host_cores >= 12 and not args.no_cpu) else 0)
                 except Exception as e:
                     line["other_configs"][other] = {"error": str(e)}
                     print("other_configs[%s] failed: %s" % (other, e), file=sys.stderr)
+        if world == 1 and wl_name == "bunny" and wl.standard and not args.no_others:
+            line["feature_scenes"] = feature_scenes(device_index, base_seed, torch)
         if world == 1 and wl_name == "bunny" and not args.no_cpu:
             # every host core this process may run on (the reference defaults to hardware_concurrency, GoblinThreadPool.cpp:5-10)
             cores = max(1, len(os.sched_getaffinity(0)))

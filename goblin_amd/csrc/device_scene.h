@@ -42,6 +42,8 @@ struct DevNode {
     int32_t child[4];     // unused slots: GBL_REF_NONE with qlo = 255, qhi = 0 (an empty interval for every ray)
 };
 #define GBL_REF_NONE 0x7ffffffd
+#define GBL_WF_HOT_NODES 0      // nodes the wavefront trace kernels keep in LDS (measured: see DESIGN.md 9)
+#define GBL_HOT_NODES_MAX 512   // most nodes of the breadth-first prefix (scene_prep.cpp hot prefix; 32 KB)
 // BLAS "roots" of analytic shapes: leaf references whose first-triangle field is out of range
 #define GBL_SHAPE_FIRST_SPHERE 0x1fffffffu
 #define GBL_SHAPE_FIRST_DISK 0x1ffffffeu
@@ -241,7 +243,7 @@ struct DevScene {
     int32_t has_bssrdf;           // some material is a subsurface material: sss_kernel runs ahead of the path kernels
     int32_t wh_slots;             // Whitted quota: sum of the lights' wh_n
     int32_t has_ibl;              // some light is image based: rays that leave the scene collect Le (evalEnvironmentLight)
-    int32_t pad_scene;
+    uint32_t hot_nodes;           // nodes[0 .. hot_nodes) are the top of the two-level tree, breadth first (scene_prep.cpp)
     DevCamera camera;
     DevFilm film;
     DevVolume volume;
@@ -277,6 +279,7 @@ struct RenderArgs {
     uint32_t stream_lperm_words;   // LDS words behind the traversal stacks' base the shuffles may use (>= the stacks' own)
     float* image_xy;            // per camera sample (indexed like li_out): the image position its record held, for the splat
     const float* replay;        // Sample records for the sub-window, pixel-major
+    uint32_t hot_count, hot_word;   // quad kernels: nodes[0 .. hot_count) also live in LDS, at word hot_word of the workgroup's block
     float* li_out;
     float* li_defer;            // when set, the render kernel stores per-sample radiance here (pixel-major)
                                 // and a separate splat kernel filters it into the film afterwards

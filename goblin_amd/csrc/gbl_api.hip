@@ -108,19 +108,19 @@ gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     if (ctx->wf_pool) return GBL_OK;
     uint32_t pool_log2 = GBL_WF_POOL_LOG2;
     if (const char* e = getenv("GBL_WF_POOL_LOG2")) pool_log2 = static_cast<uint32_t>(std::min(26, std::max(16, atoi(e))));
-    const uint32_t pool = 1u << pool_log2;   // path slots (~230 B each)
+    const uint32_t pool = 1u << pool_log2;   // path slots (~160 B each)
     WfArgs& w = ctx->wf;
     memset(&w, 0, sizeof(w));
     gbl_status st;
 #define WF_A(field, n) if ((st = wf_alloc(ctx, &w.field, (n))) != GBL_OK) return st
     WF_A(ray_o, pool); WF_A(ray_d, pool); WF_A(hit, pool); WF_A(hit_inst, pool);
-    WF_A(s_thr, pool); WF_A(s_li, pool); WF_A(s_ld, pool); WF_A(s_f, pool); WF_A(s_id, pool); WF_A(s_pixel, pool);
+    WF_A(s_thr, pool); WF_A(s_li, pool); WF_A(s_ld, pool); WF_A(s_f, pool); WF_A(s_id, pool); WF_A(s_vis, pool);
     WF_A(ext_q, pool); WF_A(ext_count, pool / 64);
-    WF_A(sh_o, pool); WF_A(sh_d, pool); WF_A(sh_c, pool); WF_A(sh_count, pool / 64);
+    WF_A(sh_d, pool); WF_A(sh_slot, pool); WF_A(sh_count, pool / 64);
     WF_A(live_flags, 8);
     WF_A(wave_next, pool / 64);
     if (ctx->scene.has_masks) {   // see WfArgs
-        WF_A(hit2, pool); WF_A(hit2_inst, pool); WF_A(mis_tr, pool); WF_A(sh_f, pool); WF_A(sh_L, pool);
+        WF_A(hit2, pool); WF_A(hit2_inst, pool); WF_A(mis_tr, pool); WF_A(sh_f, pool); WF_A(sh_L, pool); WF_A(sh_c, pool);
     }
 #undef WF_A
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_flags), 8 * sizeof(uint32_t)) != hipSuccess) {
@@ -267,7 +267,17 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
         const uint32_t waves = pool / 64, blocks = (total + 63) / 64;
         wa.paths_per_wave = ((blocks + waves - 1) / waves) * 64;
     }
-    const size_t lds_stack = static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t);
+    size_t lds_stack = static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t);
+    // the trace kernels keep the top of the tree in LDS behind their stacks (trace.h HotSplitStack): GBL_WF_HOT nodes
+    RenderArgs ra_trace = ra;
+    ra_trace.hot_word = static_cast<uint32_t>(lds_stack / sizeof(uint32_t));
+    ra_trace.hot_count = 0;
+    {
+        uint32_t want = GBL_WF_HOT_NODES;
+        if (const char* e = getenv("GBL_WF_HOT")) want = static_cast<uint32_t>(std::max(0, atoi(e)));
+        ra_trace.hot_count = std::min<uint32_t>(want, sc.hot_nodes);
+        lds_stack += ra_trace.hot_count * sizeof(DevNode);
+    }
     const int tp = GBL_TILE + 2 * sc.film.halo;
     const size_t lds_tile = sizeof(float) * (4 * tp * tp + 256);
     // EXT kernels carry the analytic shapes / directional light / non-pinhole cameras; plain scenes run the lean
@@ -340,18 +350,18 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
             for (int b = 0; b < batch; ++b) {
                 wa.flag_index = b & 7;
                 wa.stack_spill = spill_ext;
-                hipLaunchKernelGGL(k_ext, grid_ext, block, lds_stack, stream, sc, ra, wa);
+                hipLaunchKernelGGL(k_ext, grid_ext, block, lds_stack, stream, sc, ra_trace, wa);
                 if (overlap && shadow_pending) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->wf_ev_shadow, 0));   // wf_shade reads s_ld, rewrites the shadow queue
                 hipLaunchKernelGGL(k_shade, grid_shade, block, 0, stream, sc, ra, wa);
                 wa.stack_spill = spill_shd;
                 if (overlap) {
                     HIP_TRY(ctx, hipEventRecord(ctx->wf_ev_shade, stream));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->wf_aux, ctx->wf_ev_shade, 0));
-                    hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, ctx->wf_aux, sc, ra, wa);
+                    hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, ctx->wf_aux, sc, ra_trace, wa);
                     HIP_TRY(ctx, hipEventRecord(ctx->wf_ev_shadow, ctx->wf_aux));
                     shadow_pending = true;
                 } else {
-                    hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, stream, sc, ra, wa);
+                    hipLaunchKernelGGL(k_shd, grid_shd, block, lds_stack, stream, sc, ra_trace, wa);
                 }
                 ++iter;
             }
@@ -507,6 +517,7 @@ static gbl_status gbl_create_ex_impl(const gbl_scene_desc* desc, int device, uin
     if ((st = upload(ctx, packed.ibl_dist, &sc.ibl_dist)) != GBL_OK) return bail(st);
     if ((st = upload(ctx, packed.vol_density, &sc.vol_density)) != GBL_OK) return bail(st);
     sc.has_ibl = packed.has_ibl;
+    sc.hot_nodes = packed.hot_nodes;
     ctx->has_images = desc->num_images > 0;
     sc.tlas_root = packed.tlas_root;
     sc.num_instances = static_cast<int32_t>(packed.instances.size());
@@ -1138,7 +1149,20 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             // (stream mode: the shuffles' LDS region, at least the stacks', and the generator's state come on top)
             const size_t stack_bytes = stream_mode ? static_cast<size_t>(ra.stream_lperm_words) * sizeof(uint32_t)
                                                    : static_cast<size_t>(sc.stack_entries) * GBL_BLOCK * sizeof(uint32_t);
-            const size_t lds_quad = (gbl_quad_lds_words() + 4 + (stream_mode ? GBL_STREAM_LDS_WORDS : 0)) * sizeof(uint32_t) + stack_bytes;
+            size_t lds_quad = (gbl_quad_lds_words() + 4 + (stream_mode ? GBL_STREAM_LDS_WORDS : 0)) * sizeof(uint32_t) + stack_bytes;
+            // the top of the tree in LDS (trace.h HotLdsStack): as many nodes of the breadth-first prefix as fit into what the
+            // stacks leave of the LDS share of the workgroups per CU they allow anyway (granules of 1280 bytes, 128 per CU)
+            ra.hot_count = 0;
+            ra.hot_word = static_cast<uint32_t>(lds_quad / sizeof(uint32_t));
+            if (!stream_mode && sc.hot_nodes > 0 && lds_quad <= 160 * 1024) {
+                const size_t gran = 1280, granules = (lds_quad + gran - 1) / gran;
+                const size_t wgs = std::max<size_t>(1, std::min<size_t>(GBL_PT_WAVES * 4 * 64 / GBL_BLOCK, 128 / granules));
+                size_t room = (128 / wgs) * gran - lds_quad;
+                if (const char* e = getenv("GBL_HOT_LDS")) room = static_cast<size_t>(std::max(0, atoi(e))) * sizeof(DevNode);   // measurement aid: any size
+                ra.hot_count = static_cast<uint32_t>(std::min<size_t>(sc.hot_nodes, room / sizeof(DevNode)));
+                if (lds_quad + ra.hot_count * sizeof(DevNode) > 160 * 1024) ra.hot_count = 0;
+                lds_quad += ra.hot_count * sizeof(DevNode);
+            }
             gbl_render_kernel k_quad = stream_mode ? (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_stream_quad() : nullptr)
                                        : p->integrator == GBL_INTEGRATOR_AO ? gbl_kernel_ao_quad(p->exact_ties != 0)
                                        : (p->integrator == GBL_INTEGRATOR_PATH ? gbl_kernel_path_quad(p->exact_ties != 0) : nullptr);

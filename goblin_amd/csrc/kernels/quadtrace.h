@@ -232,8 +232,8 @@ __device__ __forceinline__ void quad_transition(const DevScene& sc, TravState& s
 #ifndef GBL_QUAD_PRIO_DENSE
 #define GBL_QUAD_PRIO_DENSE 2    // ... and in the one-ray-per-lane phase of a query (shading runs at 0)
 #endif
-template <bool ANY, bool STATS, bool EXT, bool TIES>
-__device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, F3 d, float mint, float maxt, const LdsStack& stk, gbl_lds_u32* slab,
+template <bool ANY, bool STATS, bool EXT, bool TIES, class STK>
+__device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, F3 d, float mint, float maxt, const STK& stk, gbl_lds_u32* slab,
                                            gbl_lds_u32* wave_stack, Hit& hit, LaneCounters& cnt, int filter = GBL_FILTER_NONE) {
     constexpr int TM = TIES ? GBL_TIE_DETECT : GBL_TIE_NONE;
     TravState st;
@@ -401,7 +401,7 @@ __device__ __forceinline__ bool trace_quad(const DevScene& sc, bool want, F3 o, 
             //  leaving an instance costs no iteration of its own: 44.5 against 42.2 ms, Cornell 74.2 against 69.1, 51 spilled
             //  registers against 26.)
             if (trav_at_interior(st)) {
-                const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
+                const uint4* np = node_ptr(sc, stk, st.cur);
                 const uint4 w0 = np[0], w1 = np[1], w2 = np[2];
                 const uint32_t w3 = reinterpret_cast<const uint32_t*>(np)[12 + ql.c];
                 const uint32_t popped = ql.col[(st.sp - 1) * GBL_BLOCK];   // the stack's top, should every child be missed

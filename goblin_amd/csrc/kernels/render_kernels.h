@@ -15,6 +15,7 @@
 // any-hit query and one closest-hit query: the MIS lookup and the path
 // extension are the same ray, so its hit is used for both.
 #pragma once
+#include <type_traits>
 #include "../device_scene.h"
 #include "sampler.h"
 #include "shade.h"
@@ -447,8 +448,14 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     // QUAD: LDS = 16 records per wave | ctrl | stacks
     gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
     gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
-    LdsStack stk;
+    typename std::conditional<QUAD, HotLdsStack, LdsStack>::type stk;
     stk.p = gbl_as_lds(stack + threadIdx.x);
+    if constexpr (QUAD) {   // the top of the tree, once per workgroup (trace.h HotLdsStack); the item loop's first barrier publishes it
+        uint4* hot = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(smem) + ra.hot_word);
+        for (uint32_t i = threadIdx.x; i < 4u * ra.hot_count; i += GBL_BLOCK) hot[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
+        stk.hot = (const gbl_lds_u4*)hot;
+        stk.hot_count = ra.hot_count;
+    }
     if (!QUAD)
         for (int i = threadIdx.x; i < 256; i += GBL_BLOCK) ftab[i] = sc.filter_table[i];
     StreamCtx scx = {};
@@ -899,7 +906,14 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     uint32_t* ctrl = QUAD ? reinterpret_cast<uint32_t*>(smem) + GBL_QUAD_LDS_WORDS : reinterpret_cast<uint32_t*>(ftab + 256);
     uint32_t* stack = ctrl + 4 + (STREAM ? GBL_STREAM_LDS_WORDS : 0);
     static_assert(!(QUAD && (STREAM || EXT || STATS)), "quad-per-ray steps are built for the lean AO kernel");
-    const LdsStack stk = {gbl_as_lds(stack + threadIdx.x)};
+    typename std::conditional<QUAD, HotLdsStack, LdsStack>::type stk;
+    stk.p = gbl_as_lds(stack + threadIdx.x);
+    if constexpr (QUAD) {   // see path_trace_kernel
+        uint4* hot = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(smem) + ra.hot_word);
+        for (uint32_t i = threadIdx.x; i < 4u * ra.hot_count; i += GBL_BLOCK) hot[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
+        stk.hot = (const gbl_lds_u4*)hot;
+        stk.hot_count = ra.hot_count;
+    }
     gbl_lds_u32* const quad_slab = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + (threadIdx.x >> 6) * 16 * GBL_QUAD_REC_WORDS);
     gbl_lds_u32* const quad_stack = gbl_as_lds(stack + (threadIdx.x & ~63u));
     if (!QUAD)

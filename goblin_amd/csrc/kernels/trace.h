@@ -139,6 +139,29 @@ struct LdsStack {
     __device__ __forceinline__ void store(int i, uint32_t v) const { p[i * GBL_BLOCK] = v; }
     __device__ __forceinline__ uint32_t load(int i) const { return p[i * GBL_BLOCK]; }
 };
+// LdsStack + the top of the two-level tree in LDS.  The first DevScene::hot_nodes nodes of the node array are the breadth-first
+// prefix of the tree (scene_prep.cpp); the lean quad kernels copy as many of them as fit beside their stacks into LDS once per
+// workgroup (RenderArgs::hot_count) and fetch a node whose reference lies below that count from there.  One instruction stream
+// for both: the pointer is chosen per lane and the four 16-byte loads go through it (flat_load: LDS aperture or memory).
+typedef __attribute__((address_space(3))) uint4 gbl_lds_u4;
+struct HotLdsStack : LdsStack {
+    const gbl_lds_u4* hot;
+    uint32_t hot_count;
+};
+template <class STK> struct stk_is_hot { static constexpr bool value = false; };
+template <> struct stk_is_hot<HotLdsStack> { static constexpr bool value = true; };
+struct HotSplitStack;
+template <> struct stk_is_hot<HotSplitStack> { static constexpr bool value = true; };
+template <class STK>
+__device__ __forceinline__ const uint4* node_ptr(const DevScene& sc, const STK& stk, int cur) {
+    const uint4* g = reinterpret_cast<const uint4*>(sc.nodes + cur);
+    if constexpr (stk_is_hot<STK>::value) {
+        const uint4* l = (const uint4*)(stk.hot + 4 * cur);
+        return static_cast<uint32_t>(cur) < stk.hot_count ? l : g;
+    } else {
+        return g;
+    }
+}
 #ifndef GBL_WF_STACK_LDS
 #define GBL_WF_STACK_LDS 16
 #endif
@@ -153,6 +176,11 @@ struct SplitStack {
     __device__ __forceinline__ uint32_t load(int i) const {
         return i < GBL_WF_STACK_LDS ? p[i * GBL_BLOCK] : g[static_cast<size_t>(i - GBL_WF_STACK_LDS) * gstride];
     }
+};
+
+struct HotSplitStack : SplitStack {   // the wavefront trace kernels' stack + the top of the tree in LDS (see HotLdsStack)
+    const gbl_lds_u4* hot;
+    uint32_t hot_count;
 };
 
 template <class STK>
@@ -203,7 +231,7 @@ __device__ __forceinline__ float child_entry(uint32_t nx, uint32_t ny, uint32_t 
 // triangle wherever it lies, so it skips the 5-comparator sorting network and takes the hit children in slot order.
 template <bool STATS, bool SORTED, class STK>
 __device__ __forceinline__ void trav_interior(const DevScene& sc, TravState& st, const STK& stk, LaneCounters& cnt) {
-    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + st.cur);
+    const uint4* np = node_ptr(sc, stk, st.cur);
     const uint4 w0 = np[0];   // o.x o.y o.z scale.x
     const uint4 w1 = np[1];   // scale.y scale.z qlo.x qlo.y
     const uint4 w2 = np[2];   // qlo.z qhi.x qhi.y qhi.z

@@ -106,8 +106,17 @@ __device__ __forceinline__ PathId decode_path(const RenderArgs& ra, const WfArgs
 template <bool ANY, bool STATS, bool EXT, bool MASKS = false, bool TIES = true>
 __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_trace(DevScene sc, RenderArgs ra, WfArgs wa) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const SplitStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x),
-                            gbl_as_global(wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x), gridDim.x * GBL_BLOCK};
+    HotSplitStack stk;
+    stk.p = gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x);
+    stk.g = gbl_as_global(wa.stack_spill + blockIdx.x * GBL_BLOCK + threadIdx.x);
+    stk.gstride = gridDim.x * GBL_BLOCK;
+    {   // the top of the tree, once per (persistent) workgroup: trace.h HotLdsStack
+        uint4* hot = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(smem) + ra.hot_word);
+        for (uint32_t i = threadIdx.x; i < 4u * ra.hot_count; i += GBL_BLOCK) hot[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
+        stk.hot = (const gbl_lds_u4*)hot;
+        stk.hot_count = ra.hot_count;
+        if (ra.hot_count) __syncthreads();
+    }
     LaneCounters cnt = {};
     const int lane = threadIdx.x & 63;
     const uint32_t n_regions = wa.pool_size / 64u;
@@ -154,11 +163,13 @@ __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_
                 float4 a, b;
                 float maxt;
                 if (ANY) {
-                    a = wf_ld_nt(&wa.sh_o[my_entry]);
+                    slot = wa.sh_slot[my_entry];
+                    a = wf_ld_nt(&wa.ray_o[slot]);   // the vertex the slot stands at: origin and mint of its shadow ray too
                     b = wf_ld_nt(&wa.sh_d[my_entry]);
-                    float4 c = wf_ld_nt(&wa.sh_c[my_entry]);
-                    contrib = f3(c.x, c.y, c.z);   // mask scenes: (lightPdf, isArea, -) -- the product is formed after the walk
-                    slot = __float_as_uint(c.w);
+                    if constexpr (masks) {
+                        const float4 c = wf_ld_nt(&wa.sh_c[my_entry]);
+                        contrib = f3(c.x, c.y, c.z);   // (lightPdf, isArea, -): the product is formed after the attenuation walk
+                    }
                     maxt = b.w;
                     entry = my_entry;
                 } else {
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_
                 bool occluded = false;
                 // (TIES: both rules inline at every accepted triangle.  The loop-plus-end-of-query-check form of trace() was measured here
                 //  too: with the exact loop inlined behind it the 96-register kernels spill 70 - 140 registers, Cornell 126 against 79 ms.)
-                if (trav_other<ANY, STATS, EXT, SplitStack, TIES ? GBL_TIE_EXACT : GBL_TIE_NONE, GBL_WF_FUSE != 0>(sc, st, stk, cnt, &occluded, filter)) {
+                if (trav_other<ANY, STATS, EXT, HotSplitStack, TIES ? GBL_TIE_EXACT : GBL_TIE_NONE, GBL_WF_FUSE != 0>(sc, st, stk, cnt, &occluded, filter)) {
                     if (ANY) {
                         if constexpr (masks) if (!occluded) {
                             // evalAttenuation along the unoccluded shadow segment, then f * tr * L * |n.wi| (* lWeight) / lightPdf
@@ -202,11 +213,16 @@ __global__ __launch_bounds__(GBL_BLOCK, MASKS ? 3 : GBL_WF_TRACE_WAVES) void wf_
                             contrib = contrib.y != 0.0f ? div(lf * tr * lL * ff.w * LL.w, contrib.x) : div(lf * tr * lL * ff.w, contrib.x);
                         }
                         if (!occluded) {
-                            float4 ld = wa.s_ld[slot];   // one shadow ray per slot per iteration: plain read-modify-write
-                            ld.x += contrib.x;
-                            ld.y += contrib.y;
-                            ld.z += contrib.z;
-                            wa.s_ld[slot] = ld;
+                            // the light-sampled term waits in the slot (wf_shade put it there); it counts from now on.  (Until round 4
+                            // this kernel added it into the slot's Ld: a 32-byte read-modify-write per unoccluded ray, and 28 more
+                            // bytes of queue entry to carry the term and the origin here.)
+                            if constexpr (masks) {
+                                float* ld = reinterpret_cast<float*>(&wa.s_ld[slot]);
+                                ld[0] = contrib.x;
+                                ld[1] = contrib.y;
+                                ld[2] = contrib.z;
+                            }
+                            wa.s_vis[slot] = 1;
                         }
                     } else {
                         wf_st_nt(&wa.hit[slot], make_float4(st.hit.t, st.hit.b1, st.hit.b2, __uint_as_float(st.hit.tri)));
@@ -252,14 +268,22 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     ps.light = 0;
     ps.path = 0;
     uint32_t out_index = 0, k = 0, pixel_key = 0;
+    const int sub_w_id = ra.window[1] - ra.window[0];
+    // the native sampler's key of the pixel a sample index belongs to (what the regeneration below derives from the path id)
+    auto pixel_key_of = [&](uint32_t index) {
+        const uint32_t pix = index / static_cast<uint32_t>(wa.pass_spp);
+        const int px = ra.window[0] + static_cast<int>(pix % static_cast<uint32_t>(sub_w_id)), py = ra.window[2] + static_cast<int>(pix / static_cast<uint32_t>(sub_w_id));
+        const int full_w = sc.film.window[1] - sc.film.window[0];
+        return nat_mix(ra.seed_key, static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0])));
+    };
     if (!wa.init) {
-        uint4 id = wa.s_id[slot];
+        const uint2 id = wa.s_id[slot];
         ps.light = static_cast<int>(id.x & 0xffffu);
-        ps.bounce = static_cast<int>(id.x >> 16) - 4;
+        ps.bounce = static_cast<int>((id.x >> 16) & 0x3fffu) - 4;
         out_index = id.y;
-        k = id.z;
-        ps.punch = (id.w & 1u) != 0u;
-        ps.first = (id.w & 2u) != 0u;
+        k = static_cast<uint32_t>(wa.pass_k0) + out_index % static_cast<uint32_t>(wa.pass_spp);
+        ps.punch = (id.x & (1u << 30)) != 0u;
+        ps.first = (id.x & (1u << 31)) != 0u;
     } else {
         ps.punch = false;
         ps.first = true;
@@ -280,9 +304,13 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         ps.d = f3(d.x, d.y, d.z);
         ps.throughput = f3(a.x, a.y, a.z); ps.cosw = a.w;
         ps.Li = f3(b.x, b.y, b.z); ps.fw = b.w;
-        ps.Ld = f3(c.x, c.y, c.z); ps.bsdf_pdf = c.w;
+        // Ld of the vertex the slot stands at: 0 + its light-sampled term if the shadow ray got through (the sum the shadow kernel
+        // used to form in place)
+        const bool lit = wa.s_vis[slot] != 0;
+        ps.Ld = lit ? f3(0.0f + c.x, 0.0f + c.y, 0.0f + c.z) : f3(0.0f, 0.0f, 0.0f);
+        ps.bsdf_pdf = c.w;
         ps.f = f3(e.x, e.y, e.z); ps.pick_pdf = e.w;
-        pixel_key = wa.s_pixel[slot];
+        if (!REPLAY) pixel_key = pixel_key_of(out_index);
         hit.t = h.x; hit.b1 = h.y; hit.b2 = h.z; hit.tri = __float_as_uint(h.w);
         hit.inst = wa.hit_inst[slot];
         got = hit.inst >= 0;
@@ -512,13 +540,14 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
         unsigned long long m = __ballot(need_shadow);
         if (need_shadow) {
             uint32_t pos = wave_gid * 64u + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-            wa.sh_o[pos] = make_float4(fr.p.x, fr.p.y, fr.p.z, fr.eps);
             wa.sh_d[pos] = make_float4(shadow_d.x, shadow_d.y, shadow_d.z, shadow_maxt);
-            wa.sh_c[pos] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(slot));
+            wa.sh_slot[pos] = slot;
             if (masks) {
+                wa.sh_c[pos] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
                 wa.sh_f[pos] = sh_f4;
                 wa.sh_L[pos] = sh_L4;
             }
+            wa.s_vis[slot] = 0;   // until the shadow ray says otherwise
         }
         if (lane == 0) wa.sh_count[wave_gid] = static_cast<uint32_t>(__popcll(m));
     }
@@ -602,16 +631,21 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
             wf_st_nt(&wa.ray_o[slot], make_float4(ps.o.x, ps.o.y, ps.o.z, ps.mint));
             // .w: this ray also serves the MIS estimate (not a camera ray, not a punch-through continuation)
             wf_st_nt(&wa.ray_d[slot], make_float4(ps.d.x, ps.d.y, ps.d.z, (ps.bounce >= 0 && !ps.punch) ? 1.0f : 0.0f));
+        } else if (zombie) {
+            // no extension ray, but the shadow ray still leaves from this vertex (the shadow kernel reads the origin here)
+            wf_st_nt(&wa.ray_o[slot], make_float4(fr.p.x, fr.p.y, fr.p.z, fr.eps));
         }
         if (zombie) wa.hit_inst[slot] = -1;
+        // the light-sampled term of the vertex just shaded waits for its shadow ray (mask scenes: the shadow kernel forms it)
+        const F3 pending = (need_shadow && !masks) ? contrib : f3(0.0f, 0.0f, 0.0f);
         wf_st_nt(&wa.s_thr[slot], make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z, ps.cosw));
         wf_st_nt(&wa.s_li[slot], make_float4(ps.Li.x, ps.Li.y, ps.Li.z, ps.fw));
-        wf_st_nt(&wa.s_ld[slot], make_float4(ps.Ld.x, ps.Ld.y, ps.Ld.z, ps.bsdf_pdf));
+        wf_st_nt(&wa.s_ld[slot], make_float4(pending.x, pending.y, pending.z, ps.bsdf_pdf));
         wf_st_nt(&wa.s_f[slot], make_float4(ps.f.x, ps.f.y, ps.f.z, ps.pick_pdf));
-        wa.s_pixel[slot] = pixel_key;
     }
     if (keep || dead || want_new || wa.init)
-        wa.s_id[slot] = make_uint4(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16), out_index, k, (ps.punch ? 1u : 0u) | (ps.first ? 2u : 0u));
+        wa.s_id[slot] = make_uint2(static_cast<uint32_t>(ps.light) | (static_cast<uint32_t>(ps.bounce + 4) << 16) | (ps.punch ? 1u << 30 : 0u) | (ps.first ? 1u << 31 : 0u),
+                                   out_index);
     // ---- extension queue: compacted into this wave's region
     {
         bool enq = keep && has_ray;

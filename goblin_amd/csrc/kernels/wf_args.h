@@ -12,16 +12,17 @@ struct WfArgs {
     int32_t* hit_inst;  // -1: miss
     float4* s_thr;      // throughput.xyz, cosw
     float4* s_li;       // Li.xyz, fw
-    float4* s_ld;       // Ld.xyz, bsdf_pdf
+    float4* s_ld;       // this vertex's light-sampled term (f * L * |n.wi| * w / pdf).xyz, bsdf_pdf -- it counts iff s_vis says so
     float4* s_f;        // f.xyz, pick_pdf
-    uint4* s_id;        // (light | (bounce + 4) << 16, out_index, k, -)
-    uint32_t* s_pixel;  // pixel key of the native sampler
+    uint2* s_id;        // (light | (bounce + 4) << 16 | punch << 30 | first << 31, out_index): the sample number and the native
+                        // sampler's pixel key follow from out_index
+    uint8_t* s_vis;     // 1: the slot's shadow ray reached the light (written by wf_trace<true>, cleared by wf_shade with the ray)
     // per-wave queue regions: region w covers entries [64 w, 64 w + count[w])
     uint32_t* ext_q;      // slot ids
     uint32_t* ext_count;
-    float4* sh_o;         // o.xyz, mint
-    float4* sh_d;         // d.xyz, maxt
-    float4* sh_c;         // contrib.xyz, as_float(slot)
+    float4* sh_d;         // shadow ray: d.xyz, maxt -- its origin and mint are the slot's ray_o (the vertex it leaves from)
+    uint32_t* sh_slot;    // ... and the slot it reports to
+    float4* sh_c;         // mask scenes only: (lightPdf, isArea, -, -) -- the product is formed after the attenuation walk
     uint32_t* sh_count;
     uint32_t* wave_next;  // per shade-wave cursor into that wave's contiguous list of path ids (no atomics:
                           // only the owning wave ever touches its word)

@@ -1,6 +1,7 @@
 // libgoblin_hip.so, kernel unit: the first-hit passes (subsurface term, participating medium), the film resolve, the
 // device BLAS build (kernels/lbvh.h) and the device self tests of the C ABI.
 #include "abi_guard.h"
+#include <chrono>
 #include "gbl_internal.h"
 #include "kernels/render_kernels.h"
 #include "kernels/subsurface.h"
@@ -165,6 +166,8 @@ __global__ __launch_bounds__(1024) void valu_issue_kernel(float* out, int op, ui
         p[i] = gbl_f2{a[i], a[i]};
         u[i] = threadIdx.x * 16u + i;
     }
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555" ::: "vcc");   // (v_cndmask_b32 reads it)
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     switch (op) {   // (wave-uniform: one scalar branch in front of the measured loop)
         case 0: valu_issue_loop<0>(a, p, u, b, c, pb, pc, ub, iters); break;
@@ -178,13 +181,27 @@ __global__ __launch_bounds__(1024) void valu_issue_kernel(float* out, int op, ui
         case 8: valu_issue_loop<8>(a, p, u, b, c, pb, pc, ub, iters); break;
         case 9: valu_issue_loop<9>(a, p, u, b, c, pb, pc, ub, iters); break;
         case 10: valu_issue_loop<10>(a, p, u, b, c, pb, pc, ub, iters); break;
-        default: valu_issue_loop<11>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 11: valu_issue_loop<11>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 12: valu_issue_loop<12>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 13: valu_issue_loop<13>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 14: valu_issue_loop<14>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 15: valu_issue_loop<15>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 16: valu_issue_loop<16>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 17: valu_issue_loop<17>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 18: valu_issue_loop<18>(a, p, u, b, c, pb, pc, ub, iters); break;
+        default: valu_issue_loop<19>(a, p, u, b, c, pb, pc, ub, iters); break;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float sum = 0.0f;
     for (int i = 0; i < 16; ++i) sum += a[i] + p[i].x + p[i].y + __uint_as_float(u[i] & 0x3fffffffu);
     if (sum == 12345.678f) out[0] = sum + vi_smem[threadIdx.x];   // keeps the chains alive; never true
-    if ((threadIdx.x & 63u) == 0u) atomicAdd(ticks, t1 - t0);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(ticks, t1 - t0);
+        atomicAdd(ticks + 1, r1 - r0);   // the constant 100 MHz counter: shader clock = (t1 - t0) / (r1 - r0) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+        atomicMax(ticks + 2, r1 - r0);   // longest / shortest span of a wave: the waves of a SIMD start together and do NOT finish together
+        atomicMin(ticks + 3, r1 - r0);   // (the older wave is served first), so only the longest span is the SIMD's time
+    }
 }
 template <int OP>
 __device__ __forceinline__ void valu_issue_loop(float (&a)[16], gbl_f2 (&p)[16], uint32_t (&u)[16], float b, float c, gbl_f2 pb, gbl_f2 pc, uint32_t ub, uint32_t iters) {
@@ -216,6 +233,22 @@ __device__ __forceinline__ void valu_issue_loop(float (&a)[16], gbl_f2 (&p)[16],
             if constexpr (OP == 9) { GBL_VI_16(GBL_VI_RCP) }
             if constexpr (OP == 10) { GBL_VI_16(GBL_VI_MED3) }
             if constexpr (OP == 11) { GBL_VI_16(GBL_VI_CMP) }
+#define GBL_VI_MUL(i) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define GBL_VI_FMAC(i) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(c));
+#define GBL_VI_MAX(i) asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define GBL_VI_MOV(i) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_ADDU(i) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_LSHL(i) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(u[i]));
+#define GBL_VI_ADD64(i) asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+#define GBL_VI_FMAK(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 12) { GBL_VI_16(GBL_VI_MUL) }
+            if constexpr (OP == 13) { GBL_VI_16(GBL_VI_FMAC) }
+            if constexpr (OP == 14) { GBL_VI_16(GBL_VI_MAX) }
+            if constexpr (OP == 15) { GBL_VI_16(GBL_VI_MOV) }
+            if constexpr (OP == 16) { GBL_VI_16(GBL_VI_ADDU) }
+            if constexpr (OP == 17) { GBL_VI_16(GBL_VI_LSHL) }
+            if constexpr (OP == 18) { GBL_VI_16(GBL_VI_ADD64) }   // v_add_f32 in its 64-bit (VOP3) encoding: is it the encoding or the operation?
+            if constexpr (OP == 19) { GBL_VI_16(GBL_VI_FMAK) }    // v_fma_f32 reading two distinct registers instead of three
         }
     }
 }
@@ -340,23 +373,33 @@ static gbl_status gbl_selftest_valu_issue_impl(gbl_ctx* ctx, int op, int waves_p
     float* d_out = nullptr;
     unsigned long long* d_ticks = nullptr;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), 64));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_ticks), 8));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_ticks), 32));
     hipEvent_t e0, e1;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     const dim3 grid(ctx->num_cus), block(256 * waves_per_simd);
     float ms = 0.0f;
-    unsigned long long ticks = 0;
-    for (int pass = 0; pass < 2; ++pass) {   // the second launch is the measured one
-        HIP_TRY(ctx, hipMemset(d_ticks, 0, 8));
-        HIP_TRY(ctx, hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k, grid, block, lds, nullptr, d_out, op, iters, d_ticks);
-        HIP_TRY(ctx, hipEventRecord(e1, nullptr));
-        HIP_TRY(ctx, hipEventSynchronize(e1));
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
-        HIP_TRY(ctx, hipMemcpy(&ticks, d_ticks, 8, hipMemcpyDeviceToHost));
+    unsigned long long ticks[4] = {0, 0, 0, 0};
+    // The chip settles its clock under a load over seconds, not milliseconds (MI355X_MICROARCH.md, DVFS item 6): the same launch
+    // back to back for warm_ms (2 s unless GBL_VALU_WARM_MS says otherwise) before the one that is read.
+    double warm_ms = 2000.0;
+    if (const char* e = getenv("GBL_VALU_WARM_MS")) warm_ms = atof(e);
+    const auto w0 = std::chrono::steady_clock::now();
+    do {
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(k, grid, block, lds, nullptr, d_out, op, iters, d_ticks);
+        HIP_TRY(ctx, hipDeviceSynchronize());
+    } while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count() < warm_ms);
+    {
+        const unsigned long long init[4] = {0ull, 0ull, 0ull, ~0ull};
+        HIP_TRY(ctx, hipMemcpy(d_ticks, init, 32, hipMemcpyHostToDevice));
     }
+    HIP_TRY(ctx, hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k, grid, block, lds, nullptr, d_out, op, iters, d_ticks);
+    HIP_TRY(ctx, hipEventRecord(e1, nullptr));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(ctx, hipMemcpy(ticks, d_ticks, 32, hipMemcpyDeviceToHost));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(d_out);
@@ -364,8 +407,12 @@ static gbl_status gbl_selftest_valu_issue_impl(gbl_ctx* ctx, int op, int waves_p
     const double waves = static_cast<double>(ctx->num_cus) * 4.0 * waves_per_simd;
     out[0] = ms;                                             // the launch, HIP events
     out[1] = waves * 64.0 * iters;                           // wave-instructions of the measured kind, whole launch
-    out[2] = static_cast<double>(ticks) / waves;             // s_memtime ticks per wave, first to last instruction
+    out[2] = static_cast<double>(ticks[0]) / waves;          // s_memtime ticks per wave, first to last instruction
     out[3] = out[2] / (64.0 * iters);                        // ... per instruction of that wave
+    out[4] = static_cast<double>(ticks[1]) / waves;          // s_memrealtime ticks (100 MHz) per wave over the same span
+    out[5] = out[4] > 0.0 ? out[2] / out[4] * 0.1 : 0.0;      // shader clock in GHz while the loop ran
+    out[6] = static_cast<double>(ticks[2]);                  // longest span of a wave, 100 MHz ticks
+    out[7] = static_cast<double>(ticks[3]);                  // shortest
     return GBL_OK;
 }
 gbl_status gbl_selftest_valu_issue(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out) {

@@ -1366,5 +1366,62 @@ gbl_status pack_scene(const gbl_scene_desc* d, PackedScene* out, std::string* er
     // the triangle bounds in the order of `tris` (what the kernels index with a hit's triangle); a device build gathers them itself
     out->tri_bounds_leaf.resize(out->tris.size());
     for (size_t i = 0; i < out->tris.size(); ++i) out->tri_bounds_leaf[i] = out->tri_bounds[out->tris[i].shade];
+    // ---- hot prefix: the nodes every ray starts with, once more, at indices [0, hot_nodes) in breadth-first order from the
+    // TLAS root through the instances' BLAS roots.  The lean kernels keep as many of them as their LDS has room for beside
+    // the traversal stacks (trace.h HotNodes): a reference below hot_nodes is served from LDS, anything else from memory.  The
+    // originals stay where they were (unreferenced from now on: at most GBL_HOT_NODES_MAX * 64 bytes); every interior reference
+    // -- child slots, instance roots, mesh roots, the TLAS root -- is rewritten to `hot index` or `old index + hot_nodes`, and
+    // tlas_base moves with the rest, so gbl_update_instances rebuilds the TLAS in the ordinary region and the BLAS part of the
+    // prefix stays valid.  (Host-built trees only: the device builder writes its nodes on the device.)
+    out->hot_nodes = 0;
+    if (!device_blas && !out->nodes.empty() && out->instances.size() > 0) {
+        uint32_t want = GBL_HOT_NODES_MAX;
+        if (const char* e = getenv("GBL_HOT_NODES")) want = static_cast<uint32_t>(std::max(0, std::min(4096, atoi(e))));
+        auto interior = [&](int32_t r) { return r >= 0 && static_cast<uint32_t>(r) < static_cast<uint32_t>(GBL_REF_NONE); };
+        std::vector<int32_t> order;          // old indices in breadth-first order
+        std::vector<int32_t> hot_of(out->nodes.size(), -1);
+        auto visit = [&](int32_t r) {
+            if (interior(r) && static_cast<size_t>(r) < out->nodes.size() && hot_of[r] < 0 && order.size() < want) {
+                hot_of[r] = static_cast<int32_t>(order.size());
+                order.push_back(r);
+            }
+        };
+        visit(out->tlas_root);
+        for (size_t head = 0; head < order.size() && order.size() < want; ++head) {
+            const DevNode& nd = out->nodes[order[head]];
+            for (int k = 0; k < 4; ++k) {
+                const int32_t c = nd.child[k];
+                if (interior(c)) {
+                    visit(c);
+                } else if (c < 0 && order[head] >= out->tlas_base) {   // a TLAS leaf: on into the instance's BLAS
+                    const uint32_t inst = (~static_cast<uint32_t>(c)) >> 2;
+                    if (inst < out->instances.size() && out->instances[inst].shape == 0u) visit(out->instances[inst].root);
+                }
+            }
+        }
+        if (interior(out->tlas_root) == false)   // a one-instance scene: the TLAS "root" is the instance's leaf reference itself
+            for (const DevInstance& di : out->instances)
+                if (di.shape == 0u) visit(di.root);
+        for (size_t head = 0; head < order.size() && order.size() < want; ++head)
+            for (int k = 0; k < 4; ++k) visit(out->nodes[order[head]].child[k]);
+        const int32_t H = static_cast<int32_t>(order.size());
+        if (H > 0) {
+            auto remap = [&](int32_t r) { return !interior(r) ? r : (hot_of[r] >= 0 ? hot_of[r] : r + H); };
+            std::vector<DevNode> moved;
+            moved.reserve(out->nodes.size() + H);
+            for (int32_t i = 0; i < H; ++i) moved.push_back(out->nodes[order[i]]);
+            moved.insert(moved.end(), out->nodes.begin(), out->nodes.end());
+            for (DevNode& nd : moved)
+                for (int k = 0; k < 4; ++k) nd.child[k] = remap(nd.child[k]);
+            out->nodes.swap(moved);
+            for (DevInstance& di : out->instances)
+                if (di.shape == 0u) di.root = remap(di.root);
+            for (uint32_t mi = 0; mi < d->num_meshes; ++mi)
+                if (d->meshes[mi].shape == GBL_SHAPE_MESH) out->mesh_root[mi] = remap(out->mesh_root[mi]);
+            out->tlas_root = remap(out->tlas_root);
+            out->tlas_base += H;
+            out->hot_nodes = static_cast<uint32_t>(H);
+        }
+    }
     return GBL_OK;
 }

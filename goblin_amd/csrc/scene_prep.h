@@ -40,6 +40,7 @@ struct PackedScene {
     std::vector<int32_t> mesh_root;        // per mesh: BLAS root reference
     int32_t tlas_base = 0;                 // device index of TLAS node 0
     uint32_t tlas_capacity = 0;            // nodes reserved at tlas_base (any TLAS over the instances fits)
+    uint32_t hot_nodes = 0;                // nodes[0 .. hot_nodes): the top of the two-level tree in breadth-first order (hot_prefix)
     DevCamera camera;
     DevFilm film;
 };

@@ -96,12 +96,15 @@ class HipPathTracer:
         return [(buf[i].main_kernel_ms, buf[i].total_ms) for i in range(got)]
 
     def valu_issue(self, op, waves_per_simd, iters=4096):
-        """gbl_selftest_valu_issue: {ms, wave_instructions, ticks_per_wave, ticks_per_instruction} of one launch."""
-        out = (C.c_double * 4)()
+        """gbl_selftest_valu_issue: {ms, wave_instructions, ticks_per_wave, ticks_per_instruction, realtime_ticks_per_wave, clock_ghz}
+        of one launch made after two seconds of the same launch back to back."""
+        out = (C.c_double * 8)()
         st = self.lib.gbl_selftest_valu_issue(self.handle, int(op), int(waves_per_simd), int(iters), out)
         if st != _abi.GBL_OK:
             raise _abi.GoblinError(st, self.lib.gbl_last_error(self.handle).decode())
-        return {"ms": out[0], "wave_instructions": out[1], "ticks_per_wave": out[2], "ticks_per_instruction": out[3]}
+        return {"ms": out[0], "wave_instructions": out[1], "ticks_per_wave": out[2], "ticks_per_instruction": out[3],
+                "realtime_ticks_per_wave": out[4], "clock_ghz": out[5],
+                "longest_span_us": out[6] * 0.01, "shortest_span_us": out[7] * 0.01}
 
     def new_film(self):
         return Film(self.info.xres, self.info.yres, self.device)

@@ -548,12 +548,17 @@ gbl_status gbl_selftest_trace(gbl_ctx* ctx, const float* rays, float* out, uint3
 
 /* Self-test hook: VALU issue-rate microbenchmark, no memory traffic.  Every CU runs one workgroup of 4 * waves_per_simd
  * waves (waves_per_simd 1..4 resident on each SIMD), every wave `iters` x 64 instructions of kind `op` over 16 independent
- * register chains.  out[4] = {launch ms (HIP events), wave-instructions of the launch, s_memtime ticks per wave, ticks per
- * instruction of a wave}.  The peak the traversal kernels' VALU roofline is priced against comes from this measurement. */
+ * register chains.  The launch that is read follows two seconds of the same launch back to back (the chip settles its clock
+ * under a load over seconds).  out[8] = {launch ms (HIP events), wave-instructions of the launch, s_memtime ticks per wave,
+ * ticks per instruction of a wave, s_memrealtime (100 MHz) ticks per wave over the same span, shader clock in GHz = the ratio
+ * of the two x 0.1, the longest and the shortest span of a wave in 100 MHz ticks}.  The waves of a SIMD start together but the
+ * older one is served first, so they finish one after the other: a SIMD's issue rate follows from the LONGEST span (or the
+ * launch time), not from the average one.  The peak the traversal kernels' issue rate is read against comes from this measurement. */
 typedef enum gbl_valu_op {
     GBL_VALU_FMA_F32 = 0, GBL_VALU_PK_FMA_F32 = 1, GBL_VALU_ADD_F32 = 2, GBL_VALU_MAX3_F32 = 3, GBL_VALU_CVT_UBYTE = 4,
     GBL_VALU_PERM_B32 = 5, GBL_VALU_MOV_DPP = 6, GBL_VALU_CNDMASK = 7, GBL_VALU_AND_B32 = 8, GBL_VALU_RCP_F32 = 9,
-    GBL_VALU_MED3_F32 = 10, GBL_VALU_CMP_F32 = 11, GBL_VALU_OP_COUNT = 12
+    GBL_VALU_MED3_F32 = 10, GBL_VALU_CMP_F32 = 11, GBL_VALU_MUL_F32 = 12, GBL_VALU_FMAC_F32 = 13, GBL_VALU_MAX_F32 = 14, GBL_VALU_MOV_B32 = 15,
+    GBL_VALU_ADD_U32 = 16, GBL_VALU_LSHL_B32 = 17, GBL_VALU_ADD_F32_E64 = 18, GBL_VALU_FMA_F32_2SRC = 19, GBL_VALU_OP_COUNT = 20
 } gbl_valu_op;
 gbl_status gbl_selftest_valu_issue(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out);
 
