@@ -42,7 +42,7 @@ struct DevNode {
     int32_t child[4];     // unused slots: GBL_REF_NONE with qlo = 255, qhi = 0 (an empty interval for every ray)
 };
 #define GBL_REF_NONE 0x7ffffffd
-#define GBL_WF_HOT_NODES 0      // nodes the wavefront trace kernels keep in LDS (measured: see DESIGN.md 9)
+#define GBL_WF_HOT_NODES 128      // nodes the wavefront trace kernels keep in LDS (measured: see DESIGN.md 9)
 #define GBL_HOT_NODES_MAX 512   // most nodes of the breadth-first prefix (scene_prep.cpp hot prefix; 32 KB)
 // BLAS "roots" of analytic shapes: leaf references whose first-triangle field is out of range
 #define GBL_SHAPE_FIRST_SPHERE 0x1fffffffu

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(1024) void valu_issue_kernel(float* out, int op, ui
         p[i] = gbl_f2{a[i], a[i]};
         u[i] = threadIdx.x * 16u + i;
     }
-    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555" ::: "vcc");   // (v_cndmask_b32 reads it)
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\ts_mov_b32 s10, 0x33333333\n\ts_mov_b32 s11, 0x33333333" ::: "vcc", "s10", "s11");   // (v_cndmask_b32 reads it)
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     switch (op) {   // (wave-uniform: one scalar branch in front of the measured loop)
@@ -189,7 +189,13 @@ __global__ __launch_bounds__(1024) void valu_issue_kernel(float* out, int op, ui
         case 16: valu_issue_loop<16>(a, p, u, b, c, pb, pc, ub, iters); break;
         case 17: valu_issue_loop<17>(a, p, u, b, c, pb, pc, ub, iters); break;
         case 18: valu_issue_loop<18>(a, p, u, b, c, pb, pc, ub, iters); break;
-        default: valu_issue_loop<19>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 19: valu_issue_loop<19>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 20: valu_issue_loop<20>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 21: valu_issue_loop<21>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 22: valu_issue_loop<22>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 23: valu_issue_loop<23>(a, p, u, b, c, pb, pc, ub, iters); break;
+        case 24: valu_issue_loop<24>(a, p, u, b, c, pb, pc, ub, iters); break;
+        default: valu_issue_loop<25>(a, p, u, b, c, pb, pc, ub, iters); break;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -249,6 +255,18 @@ __device__ __forceinline__ void valu_issue_loop(float (&a)[16], gbl_f2 (&p)[16],
             if constexpr (OP == 17) { GBL_VI_16(GBL_VI_LSHL) }
             if constexpr (OP == 18) { GBL_VI_16(GBL_VI_ADD64) }   // v_add_f32 in its 64-bit (VOP3) encoding: is it the encoding or the operation?
             if constexpr (OP == 19) { GBL_VI_16(GBL_VI_FMAK) }    // v_fma_f32 reading two distinct registers instead of three
+#define GBL_VI_MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_MUL24(i) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_MULHI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_XOR(i) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(u[i]) : "v"(ub));
+#define GBL_VI_LSHR(i) asm volatile("v_lshrrev_b32_e32 %0, 3, %0" : "+v"(u[i]));
+#define GBL_VI_CNDS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(u[i]) : "v"(ub));
+            if constexpr (OP == 20) { GBL_VI_16(GBL_VI_MULLO) }   // the native sampler's hashes are made of these
+            if constexpr (OP == 21) { GBL_VI_16(GBL_VI_MUL24) }
+            if constexpr (OP == 22) { GBL_VI_16(GBL_VI_MULHI) }
+            if constexpr (OP == 23) { GBL_VI_16(GBL_VI_XOR) }
+            if constexpr (OP == 24) { GBL_VI_16(GBL_VI_LSHR) }
+            if constexpr (OP == 25) { GBL_VI_16(GBL_VI_CNDS) }    // v_cndmask_b32 selecting by an SGPR pair other than vcc
         }
     }
 }

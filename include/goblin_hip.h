@@ -558,7 +558,8 @@ typedef enum gbl_valu_op {
     GBL_VALU_FMA_F32 = 0, GBL_VALU_PK_FMA_F32 = 1, GBL_VALU_ADD_F32 = 2, GBL_VALU_MAX3_F32 = 3, GBL_VALU_CVT_UBYTE = 4,
     GBL_VALU_PERM_B32 = 5, GBL_VALU_MOV_DPP = 6, GBL_VALU_CNDMASK = 7, GBL_VALU_AND_B32 = 8, GBL_VALU_RCP_F32 = 9,
     GBL_VALU_MED3_F32 = 10, GBL_VALU_CMP_F32 = 11, GBL_VALU_MUL_F32 = 12, GBL_VALU_FMAC_F32 = 13, GBL_VALU_MAX_F32 = 14, GBL_VALU_MOV_B32 = 15,
-    GBL_VALU_ADD_U32 = 16, GBL_VALU_LSHL_B32 = 17, GBL_VALU_ADD_F32_E64 = 18, GBL_VALU_FMA_F32_2SRC = 19, GBL_VALU_OP_COUNT = 20
+    GBL_VALU_ADD_U32 = 16, GBL_VALU_LSHL_B32 = 17, GBL_VALU_ADD_F32_E64 = 18, GBL_VALU_FMA_F32_2SRC = 19, GBL_VALU_MUL_LO_U32 = 20,
+    GBL_VALU_MUL_U32_U24 = 21, GBL_VALU_MUL_HI_U32 = 22, GBL_VALU_XOR_B32 = 23, GBL_VALU_LSHR_B32 = 24, GBL_VALU_CNDMASK_SGPR = 25, GBL_VALU_OP_COUNT = 26
 } gbl_valu_op;
 gbl_status gbl_selftest_valu_issue(gbl_ctx* ctx, int op, int waves_per_simd, uint32_t iters, double* out);
 

@@ -19,7 +19,8 @@ from goblin_amd.renderer import HipPathTracer
 
 OPS = ["v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_perm_b32", "v_mov_b32_dpp quad_perm", "v_cndmask_b32",
        "v_and_b32", "v_rcp_f32", "v_med3_f32", "v_cmp_lt_f32", "v_mul_f32", "v_fmac_f32", "v_max_f32", "v_mov_b32", "v_add_u32", "v_lshlrev_b32",
-       "v_add_f32_e64 (VOP3 encoding)", "v_fma_f32 (two source registers)"]
+       "v_add_f32_e64 (VOP3 encoding)", "v_fma_f32 (two source registers)", "v_mul_lo_u32", "v_mul_u32_u24", "v_mul_hi_u32", "v_xor_b32", "v_lshrrev_b32",
+       "v_cndmask_b32 (sgpr pair)"]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 only = None
 for a in sys.argv[1:]:
