@@ -462,6 +462,10 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
     StreamLayout slay = {};
     if constexpr (STREAM) {
         slay = stream_layout(ra.spp, ra.root, ra.max_depth, ra.bssrdf_n, ra.bssrdf_n2);
+        slay.path_quota = 1u;   // only the columns this integrator reads are shuffled and placed (stream.h stream_col_needed)
+        slay.used_bounces = static_cast<uint32_t>(max(0, ra.max_depth - 1));
+        slay.use_lens = (EXT && sc.camera.lens_radius != 0.0f) ? 1u : 0u;
+        slay.use_bssrdf = (EXT && sc.has_bssrdf != 0) ? 1u : 0u;
         scx.mt = ctrl + 4;
         scx.lperm = stack;
         scx.lperm_words = ra.stream_lperm_words;

@@ -39,9 +39,15 @@ struct StreamLayout {
     uint32_t ncols;                 // shuffled columns: lens, then every 1D slot, then every 2D slot
     uint32_t dims;
     uint32_t patterns;              // 1D + 2D patterns requested (of any slot count)
+    // Which columns anybody will READ (the generator still makes every draw).  path_quota: the layout is the path tracer's --
+    // per-bounce sets first, then the BSSRDF block -- and of its D sets the integrator reads used_bounces = D - 1 (the loop of
+    // PathTracer::Li runs D - 1 times, GoblinPathtracer.cpp:76: the last set only moves the stream), the lens sample only under
+    // a thin lens, the BSSRDF block only with subsurface materials in the scene.  0: every column (AO, Whitted).
+    uint32_t path_quota, used_bounces, use_lens, use_bssrdf;
 };
 __host__ __device__ inline void stream_layout_finish(StreamLayout& L) {
     L.F1 = L.F2 = L.patterns = 0u;
+    L.path_quota = L.used_bounces = L.use_lens = L.use_bssrdf = 0u;
     for (uint32_t i = 0; i < L.nr1; ++i) L.F1 += L.r1c[i] * L.r1n[i], L.patterns += L.r1n[i] != 0u ? L.r1c[i] : 0u;
     for (uint32_t i = 0; i < L.nr2; ++i) L.F2 += L.r2c[i] * L.r2n[i], L.patterns += L.r2n[i] != 0u ? L.r2c[i] : 0u;
     L.NF = L.S * (4u + L.F1 + 2u * L.F2);
@@ -98,7 +104,8 @@ struct DevStreamCol {
     uint32_t rec;     // the slot's float offset in a record
     float a, b;       // the stratum's corner: j * strata | ux * strata, uy * strata (stratifiedUniform1D / 2D, GoblinSampler.cpp:276-307)
     float sub;        // the sub-cell's width
-    uint32_t pad[2];
+    uint32_t col;     // the column's number (the table only lists the columns that are read)
+    uint32_t pad;
 };
 // words of global scratch one workgroup needs: raw draws, the column table, records
 // tail_per_sample: most outputs one sample can take after its record (the integrator's discarded draws + the medium's)
@@ -116,7 +123,8 @@ struct StreamCtx {
     uint32_t* lperm;    // LDS scratch for the shuffles (the traversal stacks' region, idle while samples are generated)
     uint32_t lperm_words;
     uint32_t* raw;      // global, this workgroup's: the pixel's NF + NU raw draws
-    DevStreamCol* cols; // global: ncols column descriptors (stream_columns)
+    DevStreamCol* cols; // global: descriptors of the ncols_used columns somebody reads, in column order (stream_columns)
+    uint32_t ncols_used;
     float* recs;        // global: S x dims floats
 };
 
@@ -269,12 +277,29 @@ __device__ __forceinline__ StreamCol stream_column(const StreamLayout& L, uint32
     return c;
 }
 
-// The workgroup's column table, once per launch.  Called by the whole workgroup.
-__device__ __forceinline__ void stream_columns(const StreamCtx& c, const StreamLayout& L) {
+// Does anybody read column `col` of a pixel's records?  (StreamLayout::path_quota)
+__device__ __forceinline__ bool stream_col_needed(const StreamLayout& L, uint32_t col) {
+    if (L.path_quota == 0u) return true;
+    if (col == 0u) return L.use_lens != 0u;
+    uint32_t s = col - 1u;
+    if (s < L.F1) return s < L.r1c[0] ? (s / 3u) < L.used_bounces : L.use_bssrdf != 0u;   // {light, bsdf, pick} per bounce, then the block
+    s -= L.F1;
+    return s < L.r2c[0] ? (s / 2u) < L.used_bounces : L.use_bssrdf != 0u;                  // {light, bsdf} per bounce, then the block
+}
+
+// The workgroup's column table, once per launch: the columns that are read, in column order.  Called by the whole workgroup.
+__device__ __forceinline__ void stream_columns(StreamCtx& c, const StreamLayout& L) {
     const uint32_t S = L.S;
+    uint32_t used = 0;
+    for (uint32_t col = 0; col < L.ncols; ++col) used += stream_col_needed(L, col) ? 1u : 0u;
+    c.ncols_used = used;
     for (uint32_t col = threadIdx.x; col < L.ncols; col += blockDim.x) {
+        if (!stream_col_needed(L, col)) continue;
+        uint32_t at = 0;
+        for (uint32_t q = 0; q < col; ++q) at += stream_col_needed(L, q) ? 1u : 0u;
         DevStreamCol d;
-        d.pad[0] = d.pad[1] = 0u;
+        d.col = col;
+        d.pad = 0u;
         if (col == 0u) {   // the lens sample: stream_strat2(L, 1, 0, ...)
             d.two_d = 1u;
             d.raw = 2 * S;
@@ -302,7 +327,7 @@ __device__ __forceinline__ void stream_columns(const StreamCtx& c, const StreamL
                 d.sub = strata / static_cast<int>(L.root);
             }
         }
-        c.cols[col] = d;
+        c.cols[at] = d;
     }
     __syncthreads();
 }
@@ -354,7 +379,8 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
         // (GoblinSampler.h:149-157), tracked as the position permutation of each column
         const uint32_t b = threadIdx.x, col = c0 + b;
         const uint32_t nb = min(B, L.ncols - c0);
-        if (b < nb && ld_draws) {
+        const bool col_read = b < nb && stream_col_needed(L, col);   // (a column nobody reads needs no permutation)
+        if (col_read && ld_draws) {
             for (uint32_t k = 0; k < S; ++k) lp[k * B + b] = static_cast<unsigned short>(k);
             for (uint32_t n = 0; n < S; ++n) {
                 const uint32_t ia = n * B + b, ib = static_cast<uint32_t>(ld[n * B + b]) * B + b;
@@ -362,7 +388,7 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
                 lp[ia] = vb;
                 lp[ib] = va;
             }
-        } else if (b < nb) {
+        } else if (col_read) {
             for (uint32_t k = 0; k < S; ++k) lp[k * B + b] = static_cast<unsigned short>(k);
             const uint32_t* u = c.raw + L.NF + col * S;
             const uint32_t pow2 = (S & (S - 1u)) == 0u ? S - 1u : 0u;   // x % S without the division where S is a power of two
@@ -394,17 +420,27 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
         // ---- records: sample k takes, in every column of the round, the element its position's permutation points at
         // (eight columns at a time: their draws are fetched together, then placed)
         const uint32_t root_pow2 = (L.root & (L.root - 1u)) == 0u ? L.root - 1u : 0u, root_shift = 31u - static_cast<uint32_t>(__clz(static_cast<int>(L.root)));
+        // the table's entries whose columns belong to this round: [u0, u1)
+        uint32_t u0 = 0, u1 = c.ncols_used;
+        if (nb != L.ncols) {
+            u0 = u1 = 0;
+            for (uint32_t q = 0; q < c.ncols_used; ++q) {
+                const uint32_t qc = c.cols[q].col;
+                u0 += qc < c0 ? 1u : 0u;
+                u1 += qc < c0 + nb ? 1u : 0u;
+            }
+        }
         for (uint32_t k = threadIdx.x; k < S; k += blockDim.x) {
             float* rec = c.recs + static_cast<size_t>(k) * L.dims;
-            for (uint32_t b0 = 0; b0 < nb; b0 += 8) {
+            for (uint32_t b0 = u0; b0 < u1; b0 += 8) {
                 uint32_t pp[8];
                 DevStreamCol dc[8];
                 float f0[8], f1[8];
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i) {
-                    const uint32_t bb = min(b0 + i, nb - 1u);
-                    pp[i] = lp[k * B + bb];
-                    dc[i] = c.cols[c0 + bb];
+                    const uint32_t bb = min(b0 + i, u1 - 1u);
+                    dc[i] = c.cols[bb];
+                    pp[i] = lp[k * B + (dc[i].col - c0)];
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i) {
@@ -415,7 +451,7 @@ __device__ __forceinline__ void stream_generate_pixel(StreamCtx& c, const Stream
 #pragma unroll
                 for (uint32_t i = 0; i < 8; ++i) {
                     const uint32_t p = pp[i];
-                    if (b0 + i >= nb) {
+                    if (b0 + i >= u1) {
                     } else if (dc[i].two_d == 0u) {
                         const float off = static_cast<int>(p) + f0[i];
                         rec[dc[i].rec] = dc[i].a + off * dc[i].sub;   // stratifiedUniform1D, GoblinSampler.cpp:276-286
