@@ -201,12 +201,14 @@ def issue_reading(r, issue):
     if "lane_util_pmc" in issue:
         parts.append("%.0f %% of the lanes of an issued VALU instruction are switched on" % (100 * issue["lane_util_pmc"]))
     verdict = None
-    if toa is not None and toa >= 0.5 and issue.get("wait_frac_pmc", 0) >= 0.45:
+    issue_frac = (peak["fma_cycles_per_instruction_per_simd"] / cpi) if (cpi and peak) else None
+    if issue_frac is not None and issue_frac >= 0.8:
+        verdict = ("VALU issue bound: the SIMDs issue at %.2f of what they can (what one wave waits for, the other waves' instructions fill) -- with %.0f %% of "
+                   "the lanes on, the lever is lane utilisation and instructions per ray, not memory" % (issue_frac, 100 * issue.get("lane_util_pmc", 0.0)))
+    elif toa is not None and toa >= 0.5 and issue.get("wait_frac_pmc", 0) >= 0.45:
         verdict = "bound by memory: state traffic and the latency of the traversal's dependent fetches"
     elif issue.get("wait_frac_pmc", 0) >= 0.35:
         verdict = "latency bound (dependent node / triangle fetches) under low lane utilisation, not bandwidth bound"
-    elif cpi and cpi <= 2.6:
-        verdict = "VALU issue bound"
     if verdict:
         parts.append(verdict)
     return "; ".join(parts)
