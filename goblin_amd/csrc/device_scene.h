@@ -249,6 +249,8 @@ struct DevScene {
     DevVolume volume;
 };
 
+#define GBL_PRIM_MISS (-1)   // RenderArgs::prim_inst of a camera ray that left the scene
+#define GBL_PRIM_TIED (-2)   // ... of one that met two triangles at exactly its closest distance: the path kernel traces it itself
 struct RenderArgs {
     int32_t integrator;
     int32_t spp, root;          // roundToSquare(sample_per_pixel) and its root
@@ -279,6 +281,8 @@ struct RenderArgs {
     uint32_t stream_lperm_words;   // LDS words behind the traversal stacks' base the shuffles may use (>= the stacks' own)
     float* image_xy;            // per camera sample (indexed like li_out): the image position its record held, for the splat
     const float* replay;        // Sample records for the sub-window, pixel-major
+    const float* prim_hit;      // primary pass (kernels/packet.h): per camera sample {t, b1, b2, as_float(tri)} of the camera ray's hit ...
+    const int32_t* prim_inst;   // ... and its instance, or GBL_PRIM_MISS / GBL_PRIM_TIED; null: the path kernel traces the camera rays itself
     uint32_t hot_count, hot_word;   // quad kernels: nodes[0 .. hot_count) also live in LDS, at word hot_word of the workgroup's block
     float* li_out;
     float* li_defer;            // when set, the render kernel stores per-sample radiance here (pixel-major)

@@ -433,7 +433,7 @@ __device__ void stream_medium_phase(const DevScene& sc, const RenderArgs& ra, St
 #else
 #define GBL_STREAM_TM_ON false
 #endif
-template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = false>
+template <int SAMPLER, bool STATS, bool EXT, bool QUAD = false, bool EXACT = false, bool PRIM = false>
 // (EXT builds carry the analytic shapes, texture graphs, image lookups (out-of-line calls), masks, the BSSRDF and medium hooks:
 //  held to the lean build's 168 registers they spilled 300-1200 of them; two waves per SIMD (256 registers) hold them)
 __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void path_trace_kernel(DevScene sc, RenderArgs ra) {
@@ -538,8 +538,9 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
 
         for (;;) {
             // ---- regeneration: idle lanes start a new camera path
-            int fetched = wave_fetch(!active && !exhausted, ctrl + 1);
-            if (!active && !exhausted) {
+            // (PRIM: below, after the bounce in flight is closed -- a path starts at the hit the primary pass found for it)
+            int fetched = PRIM ? -1 : wave_fetch(!active && !exhausted, ctrl + 1);
+            if (!PRIM && !active && !exhausted) {
                 if (fetched >= 0 && fetched < it.paths) {
                     int pix = fetched / ra.chunk_spp;
                     src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);
@@ -585,14 +586,15 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     exhausted = true;
                 }
             }
-            if (__ballot(active) == 0ull) break;
+            if (!PRIM && __ballot(active) == 0ull) break;
 
             bool finished = false;
             Hit hit;
             bool got = false;
             if constexpr (QUAD) {
                 const bool want = active && sc.num_lights != 0;
-                got = trace_quad<false, STATS, EXT, TIES>(sc, want, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
+                if (!PRIM || __ballot(want) != 0ull)
+                    got = trace_quad<false, STATS, EXT, TIES>(sc, want, ps.o, ps.d, ps.mint, INFINITY, stk, quad_slab, quad_stack, hit, cnt);
                 if (active && !want) finished = true;
                 if (STATS && want) cnt.ext += 1;
             } else if (active) {
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     if (STATS) cnt.ext += 1;
                 }
             }
-            const bool vis = active;
+            bool vis = active;
             Frag fr;
             TexFrag tf;
             if (vis && !finished) {
@@ -694,6 +696,69 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     if (!got) finished = true;
                 }
                 if (!finished && ps.bounce >= ra.max_depth - 1) finished = true;
+            }
+            if constexpr (PRIM) {
+                // The lanes whose path ended at this bounce hand in their Li and start the next path HERE, at the first hit the primary
+                // pass (kernels_quad.hip primary_kernel) found for its camera ray: the new path shades its first vertex in this same
+                // iteration, so a path costs one extension query less, and a camera ray that left the scene costs a Black and nothing else
+                // (PathTracer::Li, GoblinPathtracer.cpp:58-66).  Requires lights (the host only takes this kernel with num_lights > 0).
+                if (vis && finished) {
+                    reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(ps.Li.x, ps.Li.y, ps.Li.z, 1.0f);
+                    active = false;
+                    finished = false;
+                    paths_done += 1;
+                }
+                for (;;) {
+                    const bool idle = !active && !exhausted;
+                    if (__ballot(idle) == 0ull) break;
+                    fetched = wave_fetch(idle, ctrl + 1);
+                    if (!idle) continue;
+                    if (fetched < 0 || fetched >= it.paths) {
+                        exhausted = true;
+                        continue;
+                    }
+                    const int pix = fetched / ra.chunk_spp;
+                    src.k = static_cast<uint32_t>(it.k0 + fetched % ra.chunk_spp);
+                    const int px = it.px0 + pix % it.tw, py = it.py0 + pix / it.tw;
+                    out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
+                    hit.inst = ra.prim_inst[out_index];
+                    if (hit.inst == GBL_PRIM_MISS) {
+                        reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+                        paths_done += 1;
+                        continue;
+                    }
+                    const uint32_t pixel = static_cast<uint32_t>((py - sc.film.window[2]) * full_w + (px - sc.film.window[0]));
+                    src.pixel_key = nat_mix(ra.seed_key, pixel);
+                    float u, v;
+                    src.native_2d(0u, 1u, 0u, false, &u, &v);
+                    image_x = px + u;
+                    image_y = py + v;
+                    camera_ray<EXT>(sc.camera, image_x, image_y, 0.0f, 0.0f, &ps.o, &ps.d, &ps.mint);
+                    ps.throughput = f3(1.0f, 1.0f, 1.0f);
+                    ps.punch = false;
+                    ps.first = true;
+                    ps.path = fetched;
+                    active = true;
+                    if (hit.inst == GBL_PRIM_TIED) {
+                        // the packet met two triangles at exactly this ray's closest distance: which of them a ray on its own keeps
+                        // depends on its own visiting order, so it is traced here like any other ray (next iteration's query)
+                        ps.Li = f3(0.0f, 0.0f, 0.0f);
+                        ps.bounce = -1;
+                        continue;
+                    }
+                    const float4 h = reinterpret_cast<const float4*>(ra.prim_hit)[out_index];
+                    hit.t = h.x;
+                    hit.b1 = h.y;
+                    hit.b2 = h.z;
+                    hit.tri = __float_as_uint(h.w);
+                    make_fragment<EXT>(sc, hit, ps.o, ps.d, fr, &tf);
+                    const F3 le = hit_Le(sc, hit.inst, fr.n, -ps.d);
+                    ps.Li = f3(0.0f + le.x, 0.0f + le.y, 0.0f + le.z);
+                    ps.bounce = 0;
+                    finished = ra.max_depth <= 1;
+                }
+                if (__ballot(active) == 0ull) break;
+                vis = active && ps.bounce >= 0;   // (a tied camera ray has nothing to shade yet)
             }
 
             // ---- shade the vertex: light sample (shadow ray below) and BSDF sample
