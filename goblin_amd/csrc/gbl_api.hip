@@ -1173,12 +1173,14 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                 if (lds > 64 * 1024)
                     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
                 // The primary pass (kernels/packet.h): the camera rays of the call traced as packets, one wave per pixel and 64 of its
-                // samples, ahead of the path kernel, which then starts every path at its first hit.  Lean native path tracer only (the
-                // exact-tie builds resolve ties in the reference's order, which a packet's shared visiting order is not); 20 bytes per
-                // camera sample, within the per-sample radiance buffer's budget; GBL_PRIMARY=0 turns it off (A/B, bit-identity test).
+                // samples, ahead of the path kernel, which then starts every path at its first hit (a camera ray whose answer depends
+                // on the visiting order -- an exact tie; under exact_ties also a hit the reference might not reach -- is flagged and
+                // traced by the path kernel itself, so the radiance is bit for bit what it is without the pass).  Native sampler's quad
+                // path kernels; 20 bytes per camera sample, within the per-sample radiance buffer's budget; GBL_PRIMARY=0 turns it
+                // off (A/B, bit-identity test).
                 const char* pe = getenv("GBL_PRIMARY");
                 const uint64_t entries = npix * ra.spp;
-                if (!stream_mode && p->integrator == GBL_INTEGRATOR_PATH && p->exact_ties == 0 && sc.num_lights > 0 && !(pe && pe[0] == '0') &&
+                if (!stream_mode && p->integrator == GBL_INTEGRATOR_PATH && sc.num_lights > 0 && !(pe && pe[0] == '0') &&
                     sc.stack_entries <= 64 && entries * 20 <= li_budget_bytes(ctx)) {
                     if (entries > ctx->prim_entries) {
                         if (ctx->prim_buf) (void)hipFree(ctx->prim_buf);
@@ -1193,11 +1195,11 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                     }
                     float4* ph = static_cast<float4*>(ctx->prim_buf);
                     int32_t* pi = reinterpret_cast<int32_t*>(ph + entries);
-                    gbl_launch_primary(sc, ra, ph, pi, static_cast<unsigned>(ctx->num_cus) * 8u, stream);
+                    gbl_launch_primary(sc, ra, p->exact_ties != 0, ph, pi, static_cast<unsigned>(ctx->num_cus) * 8u, stream);
                     HIP_TRY(ctx, hipGetLastError());
                     ra.prim_hit = reinterpret_cast<const float*>(ph);
                     ra.prim_inst = pi;
-                    kernel = gbl_kernel_path_quad_primary();   // the same kernel, its paths starting at those hits
+                    kernel = gbl_kernel_path_quad_primary(p->exact_ties != 0);   // the same kernel, its paths starting at those hits
                     if (lds > 64 * 1024)
                         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
                 }

@@ -88,10 +88,10 @@ gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext, bool exact_
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext, bool exact_ties = false);
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
 gbl_render_kernel gbl_kernel_path_quad(bool exact_ties);
-gbl_render_kernel gbl_kernel_path_quad_primary(void);   // ... its paths starting at RenderArgs::prim_hit (primary_kernel's output)
+gbl_render_kernel gbl_kernel_path_quad_primary(bool exact_ties);   // ... its paths starting at RenderArgs::prim_hit (primary_kernel's output)
 gbl_render_kernel gbl_kernel_path_stream_quad(void);
 gbl_render_kernel gbl_kernel_ao_quad(bool exact_ties);
-void gbl_launch_primary(const DevScene& sc, const RenderArgs& ra, float4* prim_hit, int32_t* prim_inst, unsigned blocks, hipStream_t stream);   // kernels/packet.h
+void gbl_launch_primary(const DevScene& sc, const RenderArgs& ra, bool exact_ties, float4* prim_hit, int32_t* prim_inst, unsigned blocks, hipStream_t stream);   // kernels/packet.h
 uint32_t gbl_quad_lds_words(void);          // LDS words of the quads' records, in the film tile's place
 // kernels_stream.hip: the same two under GBL_SAMPLES_STREAM (kernels/stream.h)
 gbl_render_kernel gbl_kernel_path_stream(bool stats, bool ext);

@@ -9,7 +9,9 @@
 gbl_render_kernel gbl_kernel_path_quad(bool exact_ties) {
     return exact_ties ? path_trace_kernel<GBL_SRC_NATIVE, false, false, true, true> : path_trace_kernel<GBL_SRC_NATIVE, false, false, true>;
 }
-gbl_render_kernel gbl_kernel_path_quad_primary(void) { return path_trace_kernel<GBL_SRC_NATIVE, false, false, true, false, true>; }
+gbl_render_kernel gbl_kernel_path_quad_primary(bool exact_ties) {
+    return exact_ties ? path_trace_kernel<GBL_SRC_NATIVE, false, false, true, true, true> : path_trace_kernel<GBL_SRC_NATIVE, false, false, true, false, true>;
+}
 gbl_render_kernel gbl_kernel_ao_quad(bool exact_ties) {
     return exact_ties ? ao_kernel<GBL_SRC_NATIVE, false, false, true, true> : ao_kernel<GBL_SRC_NATIVE, false, false, true>;
 }
@@ -21,6 +23,10 @@ uint32_t gbl_quad_lds_words(void) { return GBL_QUAD_LDS_WORDS; }
 // RenderArgs::prim_hit / prim_inst; the lean quad path kernel then starts every path at its first hit instead of tracing the camera
 // ray among the scattered ones.  Camera samples are made exactly as the path kernel's regeneration makes them (native sampler).
 // Replaces, for the first segment of every path, Scene::intersect as PathTracer::Li calls it (GoblinPathtracer.cpp:58-60).
+// EXACT (gbl_render_params.exact_ties): a hit the reference's own traversal might not have returned -- one its box tests pass by, or
+// one of a tie (trace.h trace_needs_redo, the same end-of-query check the path kernel's queries make) -- is left to the path kernel,
+// which traces that camera ray under the reference's rule.
+template <bool EXACT>
 __global__ __launch_bounds__(GBL_BLOCK) void primary_kernel(DevScene sc, RenderArgs ra, float4* prim_hit, int32_t* prim_inst) {
     __shared__ uint32_t pk_stack[(GBL_BLOCK / 64) * GBL_PACKET_STACK_WORDS];
     gbl_lds_u32* const wstack = gbl_as_lds(pk_stack + (threadIdx.x >> 6) * GBL_PACKET_STACK_WORDS);
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void primary_kernel(DevScene sc, RenderA
         Hit h;
         bool tied;
         packet_closest(sc, live, o, d, mint, wstack, h, tied);
+        if (EXACT && live) tied = trace_needs_redo(sc, false, h.inst >= 0, h, tied, o, d, mint, INFINITY);
         if (live) {
             const size_t out_index = static_cast<size_t>(static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0]))) * ra.spp + k;
             if (h.inst >= 0 && !tied) prim_hit[out_index] = make_float4(h.t, h.b1, h.b2, __uint_as_float(h.tri));
@@ -61,6 +68,9 @@ __global__ __launch_bounds__(GBL_BLOCK) void primary_kernel(DevScene sc, RenderA
         }
     }
 }
-void gbl_launch_primary(const DevScene& sc, const RenderArgs& ra, float4* prim_hit, int32_t* prim_inst, unsigned blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(primary_kernel, dim3(blocks), dim3(GBL_BLOCK), 0, stream, sc, ra, prim_hit, prim_inst);
+void gbl_launch_primary(const DevScene& sc, const RenderArgs& ra, bool exact_ties, float4* prim_hit, int32_t* prim_inst, unsigned blocks, hipStream_t stream) {
+    if (exact_ties)
+        hipLaunchKernelGGL(primary_kernel<true>, dim3(blocks), dim3(GBL_BLOCK), 0, stream, sc, ra, prim_hit, prim_inst);
+    else
+        hipLaunchKernelGGL(primary_kernel<false>, dim3(blocks), dim3(GBL_BLOCK), 0, stream, sc, ra, prim_hit, prim_inst);
 }
