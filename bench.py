@@ -69,8 +69,11 @@ def _template_arg(kernel_name, index):
 
 
 # the un-instrumented lean kernels a standard run launches, by (integrator, schedule)
-LEAN_KERNELS = {("path", "megakernel"): "void path_trace_kernel<0, false, false, true, false>(DevScene, RenderArgs)",
-                ("ao", "megakernel"): "void ao_kernel<0, false, false, true, false>(DevScene, RenderArgs)"}
+# (a path-tracing step under the megakernel schedule is two launches: the primary pass -- the camera rays as per-pixel packets,
+#  kernels/packet.h -- and the path kernel whose paths start at those hits; the first name is the one the step spends its time in)
+LEAN_KERNELS = {("path", "megakernel"): ("void path_trace_kernel<0, false, false, true, false, true>(DevScene, RenderArgs)",
+                                         "void primary_kernel<false>(DevScene, RenderArgs, HIP_vector_type<float, 4u>*, int*)"),
+                ("ao", "megakernel"): ("void ao_kernel<0, false, false, true, false>(DevScene, RenderArgs)",)}
 
 
 def pmc_for(workload, schedule, integrator, frame_spp=None):
@@ -118,15 +121,20 @@ def pmc_for(workload, schedule, integrator, frame_spp=None):
             return dict(agg, kernel="one step: " + ", ".join(kernels), file=os.path.relpath(path, REPO), source_stamp=stamp, waves_per_simd=waves,
                         scaled_from_spp=d.get("spp_profiled") if factor != 1.0 else None), None
         return None, "no wavefront kernels in %s" % os.path.basename(path)
-    name = LEAN_KERNELS.get((integrator, schedule))
-    c = d.get("counters_per_launch", {}).get(name)
-    if c:
-        c = {k: (v * factor if isinstance(v, (int, float)) and k in keys + ("kernel_avg_ms",) else v) for k, v in c.items()}
-        li = kernel_registers().get(name)
-        return dict(c, kernel=name, file=os.path.relpath(path, REPO), source_stamp=stamp,
+    names = LEAN_KERNELS.get((integrator, schedule), ())
+    per_launch = d.get("counters_per_launch", {})
+    if names and all(n in per_launch for n in names):
+        # one launch of each per step: the step's counters and kernel time are their sums (ratios are taken of the sums)
+        c = {}
+        for n in names:
+            for k, v in per_launch[n].items():
+                if isinstance(v, (int, float)) and k in keys + ("kernel_avg_ms",):
+                    c[k] = c.get(k, 0.0) + v * factor
+        li = kernel_registers().get(names[0])
+        return dict(c, kernel=" + ".join(n.split("(")[0].replace("void ", "") for n in names), file=os.path.relpath(path, REPO), source_stamp=stamp,
                     waves_per_simd=waves_per_simd_of(li[0], li[1]) if li else None,
                     scaled_from_spp=d.get("spp_profiled") if factor != 1.0 else None), None
-    return None, "no kernel %r in %s" % (name, os.path.basename(path))
+    return None, "not every kernel of %r in %s" % (names, os.path.basename(path))
 
 
 def valu_issue_peak(waves_per_simd):
@@ -427,7 +435,9 @@ class Workload:
     def kernel_label(self, resolved):
         if resolved == "wavefront":
             return "wf_trace / wf_shade (all wavefront kernels of a step)"
-        return ("ao_kernel" if self.integrator == "ao" else "path_trace_kernel") + "<native sampler, lean, quad-per-ray queries>"
+        if self.integrator == "ao":
+            return "ao_kernel<native sampler, lean, quad-per-ray queries>"
+        return "primary_kernel (camera rays as per-pixel packets) + path_trace_kernel<native sampler, lean, quad-per-ray queries, paths start at the primary hits>"
 
 
 def run_steps(render, zero_film, allreduce, barrier, sync, steps, warmup, world, make_event=None):

@@ -21,6 +21,34 @@
 #define GBL_PACKET_STACK 64   // entries of the wave's shared stack (the per-lane stacks' need is DevScene::stack_entries <= this)
 #define GBL_PACKET_STACK_WORDS (3 * GBL_PACKET_STACK)   // {reference, lane mask lo, lane mask hi}
 
+// Wave-uniform addresses go through the scalar cache (s_load): the node, the instance record and the triangles of a packet step are
+// the same for all 64 lanes; their words then sit in SGPRs and feed the VALU as scalar operands -- no vector-memory instruction, no
+// 64 copies of the same 64 bytes in VGPRs, a shorter round trip.  (Read-only data: the scalar cache is not coherent with stores.)
+typedef uint32_t gbl_u32x4 __attribute__((ext_vector_type(4)));
+struct gbl_k_u4 {   // sixteen-byte words behind a wave-uniform address, read with s_load
+    const __attribute__((address_space(4))) gbl_u32x4* p;
+    __device__ __forceinline__ uint4 operator[](int i) const {
+        const gbl_u32x4 v = p[i];
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+};
+__device__ __forceinline__ gbl_k_u4 pk_k(const void* p) { return gbl_k_u4{(const __attribute__((address_space(4))) gbl_u32x4*)p}; }
+__device__ __forceinline__ float4 pk_f4(uint4 w) { return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)); }
+// the instance record's inverse transform (floats 12..23) and BLAS root (word 24)
+__device__ __forceinline__ int pk_enter_instance(const DevScene& sc, uint32_t index, const RaySpace& world, RaySpace& r) {
+    const gbl_k_u4 ip = pk_k(sc.instances + index);
+    const uint4 a = ip[3], b = ip[4], c = ip[5], e = ip[6];
+    const float inv[12] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                           __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w),
+                           __uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w)};
+    ray_space(r, xf_point(inv, world.o), xf_vector(inv, world.d));
+    return static_cast<int>(e.x);
+}
+__device__ __forceinline__ bool pk_tri_test(const DevScene& sc, uint32_t tri, F3 o, F3 d, float mint, float maxt, float* t, float* b1, float* b2) {
+    const gbl_k_u4 tp = pk_k(sc.tris + tri);
+    return tri_test_regs(pk_f4(tp[0]), pk_f4(tp[1]), pk_f4(tp[2]), o, d, mint, maxt, t, b1, b2);
+}
+
 __device__ __forceinline__ unsigned long long pk_uniform64(unsigned long long v) {
     return static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)))) |
            (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)))) << 32);
@@ -58,7 +86,7 @@ __device__ __forceinline__ bool packet_closest(const DevScene& sc, bool live, F3
         const bool here = __builtin_amdgcn_inverse_ballot_w64(mask);
         if (static_cast<uint32_t>(cur) < static_cast<uint32_t>(GBL_REF_NONE)) {
             // ---- interior node: every lane of the mask tests the four children against its own ray
-            const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + cur);
+            const gbl_k_u4 np = pk_k(sc.nodes + cur);
             const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
             const F3 A = f3(__builtin_fmaf(__uint_as_float(w0.x), r.idir.x, -r.ood.x), __builtin_fmaf(__uint_as_float(w0.y), r.idir.y, -r.ood.y),
                             __builtin_fmaf(__uint_as_float(w0.z), r.idir.z, -r.ood.z));
@@ -125,18 +153,16 @@ __device__ __forceinline__ bool packet_closest(const DevScene& sc, bool live, F3
         }
         const uint32_t ref = ~static_cast<uint32_t>(cur);
         if (inst < 0) {   // a TLAS leaf: every lane's ray into the instance's space (Transform::invertRay, un-normalised: t is shared)
-            const DevInstance* ip = sc.instances + (ref >> 2);
             inst = static_cast<int>(ref >> 2);
-            ray_space(r, xf_point(ip->inv, world.o), xf_vector(ip->inv, world.d));
             pk_push(wstack, sp, GBL_STACK_SENTINEL, 0ull);
-            cur = ip->root;   // (same lanes: `mask` stays)
+            cur = pk_enter_instance(sc, ref >> 2, world, r);   // (same lanes: `mask` stays)
             continue;
         }
         // ---- a triangle leaf: the lanes of the mask test every triangle of it
         const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
         for (uint32_t i = 0; i < count; ++i) {
             float t, b1, b2;
-            if (tri_test(sc.tris + first + i, r.o, r.d, mint, maxt, &t, &b1, &b2) && here) {
+            if (pk_tri_test(sc, first + i, r.o, r.d, mint, maxt, &t, &b1, &b2) && here) {
                 tied = tied || t == hit.t;
                 maxt = t;
                 hit.t = t;
@@ -150,3 +176,4 @@ __device__ __forceinline__ bool packet_closest(const DevScene& sc, bool live, F3
     }
     return hit.inst >= 0;
 }
+

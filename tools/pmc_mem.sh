@@ -17,8 +17,8 @@ for f in glob.glob('/root/repo/gpurun_out/pmc_mem/**/*counter_collection.csv', r
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'path_trace_kernel<0, false, false, true, false>' in k:
+        if 'path_trace_kernel<0, false, false, true, false' in k or 'primary_kernel' in k:
             acc[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
     for k, v in acc.items():
-        print({c: x / cnt[(k, c)] for c, x in v.items()})
+        print(k.split('(')[0], {c: x / cnt[(k, c)] for c, x in v.items()})
 PY
