@@ -118,7 +118,7 @@ gbl_status wf_ensure_pool(gbl_ctx* ctx) {
     WF_A(ext_q, pool); WF_A(ext_count, pool / 64);
     WF_A(sh_d, pool); WF_A(sh_slot, pool); WF_A(sh_count, pool / 64);
     WF_A(live_flags, 8);
-    WF_A(wave_next, pool / 64);
+    WF_A(wave_next, 2 * (pool / 64)); WF_A(steal_next, 1);
     if (ctx->scene.has_masks) {   // see WfArgs
         WF_A(hit2, pool); WF_A(hit2_inst, pool); WF_A(mis_tr, pool); WF_A(sh_f, pool); WF_A(sh_L, pool); WF_A(sh_c, pool);
     }
@@ -264,8 +264,13 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     wa.total_paths = total;
     wa.pass_spp = pass_spp;
     {   // ids are dealt in blocks of 64, round-robin over the pool/64 shade-waves
+        // ... three quarters of them up front; the rest is the reserve the waves that finish early draw on (wf_shade)
         const uint32_t waves = pool / 64, blocks = (total + 63) / 64;
-        wa.paths_per_wave = ((blocks + waves - 1) / waves) * 64;
+        uint32_t reserve_pct = 25;
+        if (const char* e = getenv("GBL_WF_RESERVE")) reserve_pct = static_cast<uint32_t>(std::min(100, std::max(0, atoi(e))));   // measurement aid
+        wa.static_blocks = static_cast<uint32_t>(static_cast<uint64_t>(blocks / waves) * (100 - reserve_pct) / 100);
+        if (reserve_pct == 0) wa.static_blocks = (blocks + waves - 1) / waves;   // (everything dealt up front: round 3's scheme)
+        wa.total_blocks = blocks;
     }
     size_t lds_stack = static_cast<size_t>(std::min<int>(sc.stack_entries, GBL_WF_STACK_LDS)) * GBL_BLOCK * sizeof(uint32_t);
     // the trace kernels keep the top of the tree in LDS behind their stacks (trace.h HotSplitStack): GBL_WF_HOT nodes
@@ -336,7 +341,8 @@ gbl_status render_wavefront(gbl_ctx* ctx, const RenderArgs& ra, const gbl_render
     }
     for (int k0 = 0; k0 < ra.spp; k0 += pass_spp) {
         wa.pass_k0 = k0;
-        HIP_TRY(ctx, hipMemsetAsync(wa.wave_next, 0, (pool / 64) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(wa.wave_next, 0, 2 * (pool / 64) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(wa.steal_next, 0, sizeof(uint32_t), stream));
         wa.init = 1;
         wa.flag_index = 7;
         hipLaunchKernelGGL(k_shade, grid_shade, block, 0, stream, sc, ra, wa);

@@ -29,6 +29,7 @@
 #include "wf_args.h"
 
 #define WF_BOUNCE_EMPTY (-2)   // slot needs a new path
+#define WF_BLOCK_NONE 0xffffffffu   // no block of path ids (the shared reserve is used up)
 #define WF_BOUNCE_DEAD (-3)    // slot has traced all its paths of this pass
 
 // Path state streams through the pool once per iteration: non-temporal accesses keep it from evicting the BVH nodes
@@ -561,18 +562,45 @@ __global__ __launch_bounds__(GBL_BLOCK) void wf_shade(DevScene sc, RenderArgs ra
     const bool want_new = (alive && finished) || ps.bounce == WF_BOUNCE_EMPTY;
     if (alive && finished) ps.bounce = WF_BOUNCE_EMPTY;
     {
-        // Each shade-wave owns a contiguous list of path ids and hands them to its lanes in order:
-        // ballot + prefix popcount over a cursor only this wave touches (plain load / store).
+        // Path ids come in blocks of 64 (= consecutive samples of one pixel).  Every shade-wave is dealt `static_blocks` of them up
+        // front, round-robin, so its list is spread over the whole image; it hands their ids to its lanes in order -- ballot + prefix
+        // popcount over a cursor only this wave touches (plain load / store).  A pixel's paths are as long as what the pixel sees,
+        // so the waves' lists do NOT take equally long (on the Cornell box the slowest of 131 072 waves needed 18 % more iterations
+        // than the mean, and every iteration costs the whole pool's launches): the last quarter of the blocks is a shared reserve, a
+        // wave whose own list is used up takes its next block from there -- one atomic per 64 paths, by the waves that finish early.
         unsigned long long wm = __ballot(want_new);
         if (wm != 0ull) {
-            const uint32_t cursor = wa.wave_next[wave_gid];
+            const uint32_t waves = wa.pool_size >> 6;
+            const uint32_t cursor = wa.wave_next[2u * wave_gid];
+            const uint32_t held = wa.wave_next[2u * wave_gid + 1u];   // reserve block in use (index cursor >> 6, once that is past the static ones)
+            const uint32_t n_new = static_cast<uint32_t>(__popcll(wm));
             const uint32_t local = cursor + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
-            if (lane == 0) wa.wave_next[wave_gid] = cursor + static_cast<uint32_t>(__popcll(wm));
+            // the ids of this round lie in block index j0, or j0 and j0 + 1; at most one of the two is begun in this round
+            const uint32_t j0 = cursor >> 6, j1 = (cursor + n_new - 1u) >> 6;
+            const bool begins = (cursor & 63u) == 0u || j1 != j0;
+            const uint32_t jb = (cursor & 63u) == 0u ? j0 : j1;   // ... the one that is begun
+            uint32_t begun = WF_BLOCK_NONE;
+            if (begins) {
+                if (jb < wa.static_blocks) {
+                    begun = jb * waves + wave_gid;
+                } else if (held != WF_BLOCK_NONE || jb == wa.static_blocks) {   // (NONE after the first reserve block: the reserve is empty)
+                    uint32_t g = 0;
+                    if (lane == 0) g = atomicAdd(wa.steal_next, 1u);
+                    g = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g)));
+                    begun = wa.static_blocks * waves + g;
+                    if (begun >= wa.total_blocks) begun = WF_BLOCK_NONE;
+                }
+            }
+            if (lane == 0) {
+                wa.wave_next[2u * wave_gid] = cursor + n_new;
+                if (begins && jb >= wa.static_blocks) wa.wave_next[2u * wave_gid + 1u] = begun;
+            }
             if (want_new) {
-                // ids are dealt to the waves in blocks of 64 (= consecutive samples of one pixel), round-robin,
-                // so every wave's list is spread over the whole image and the waves finish together
-                const uint64_t id = (static_cast<uint64_t>(local >> 6) * (wa.pool_size >> 6) + wave_gid) * 64u + (local & 63u);
-                if (local < wa.paths_per_wave && id < wa.total_paths) {
+                const uint32_t j = local >> 6;
+                uint32_t block = (begins && j == jb) ? begun : (j < wa.static_blocks ? j * waves + wave_gid : held);
+                if (j >= wa.static_blocks && j != jb && held == WF_BLOCK_NONE) block = WF_BLOCK_NONE;
+                const uint64_t id = static_cast<uint64_t>(block) * 64u + (local & 63u);
+                if (block != WF_BLOCK_NONE && id < wa.total_paths) {
                     PathId pid = decode_path(ra, wa, static_cast<uint32_t>(id));
                     if (pid.valid) {   // (a pixel clipped off an edge tile leaves the slot EMPTY: it asks again next iteration)
                         const int full_w = sc.film.window[1] - sc.film.window[0];

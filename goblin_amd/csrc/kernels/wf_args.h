@@ -24,9 +24,11 @@ struct WfArgs {
     uint32_t* sh_slot;    // ... and the slot it reports to
     float4* sh_c;         // mask scenes only: (lightPdf, isArea, -, -) -- the product is formed after the attenuation walk
     uint32_t* sh_count;
-    uint32_t* wave_next;  // per shade-wave cursor into that wave's contiguous list of path ids (no atomics:
-                          // only the owning wave ever touches its word)
-    uint32_t paths_per_wave;
+    uint32_t* wave_next;  // per shade-wave {ids handed out so far, the block taken from the shared reserve that is in use}: only the
+                          // owning wave ever touches its two words
+    uint32_t* steal_next; // the shared reserve's counter: blocks of 64 path ids beyond the statically dealt ones (wf_shade)
+    uint32_t static_blocks;   // blocks dealt to every wave up front, round-robin (block j of wave w = j * waves + w)
+    uint32_t total_blocks;    // total_paths / 64
     // mask scenes only (DevScene::has_masks): the isOpaque-filtered MIS hit + attenuation of an extension ray whose
     // closest hit is a mask (-2 in hit2_inst: same as the closest hit), and the shadow queue's un-multiplied terms
     float4* hit2;         // t, b1, b2, as_float(tri)
