@@ -1206,30 +1206,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                     ra.prim_hit = reinterpret_cast<const float*>(ph);
                     ra.prim_inst = pi;
                     kernel = gbl_kernel_path_quad_primary(p->exact_ties != 0);   // the same kernel, its paths starting at those hits
-                    // the lean kernel with persistent traversal (kernels/persist.h); GBL_PERSIST=0: the query-per-iteration kernel
-                    const char* pp = getenv("GBL_PERSIST");
-                    if (p->exact_ties == 0 && pp && pp[0] == '1') {   // (measured: slower -- off unless asked for)
-                        kernel = gbl_kernel_path_persist();
-                        // its work items are taken per wave: finer ones (>= 32 per resident wave, down to 8 samples per pixel),
-                        // or the launch ends with the few waves that drew a heavy tile last
-                        {
-                            int chunks = ra.chunks;
-                            const uint64_t want = 32ull * ctx->num_cus * 12;
-                            while (static_cast<uint64_t>(ra.local_tiles) * chunks < want && ra.spp / chunks > 8 && ra.spp % (chunks * 2) == 0) chunks *= 2;
-                            if (const char* pc = getenv("GBL_PERSIST_CHUNK_SPP")) {   // measurement aid
-                                const int c = atoi(pc);
-                                if (c >= 1 && ra.spp % c == 0) chunks = ra.spp / c;
-                            }
-                            ra.chunks = chunks;
-                            ra.chunk_spp = ra.spp / chunks;
-                        }
-                        ra.persist_wait = 32;
-                        ra.persist_switch = 16;
-                        ra.persist_th = 24;
-                        if (const char* pt = getenv("GBL_PERSIST_TH")) ra.persist_th = static_cast<uint32_t>(std::min(64, std::max(1, atoi(pt))));
-                        if (const char* ps = getenv("GBL_PERSIST_SWITCH")) ra.persist_switch = static_cast<uint32_t>(std::min(64, std::max(1, atoi(ps))));
-                        if (const char* pw = getenv("GBL_PERSIST_WAIT")) ra.persist_wait = static_cast<uint32_t>(std::min(64, std::max(1, atoi(pw))));
-                    }
                     if (lds > 64 * 1024)
                         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
                 }
@@ -1256,13 +1232,6 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
             unsigned long long h[32];
             HIP_TRY(ctx, hipStreamSynchronize(stream));
             HIP_TRY(ctx, hipMemcpy(h, ctx->stats, sizeof(h), hipMemcpyDeviceToHost));
-            if (h[30]) {   // -DGBL_PERSIST_CLOCK (kernels/persist.h): one lane per wave reports
-                const double k = static_cast<double>(h[30]);
-                fprintf(stderr, "persist clock (share of the waves' ticks): traverse %.1f%% (steps %llu, %.1f lanes stepping each, %.0f ticks each) | shadow->extension switches %.1f%% "
-                        "(%llu, %.1f lanes each) | shade %.1f%% (phases %llu, %.1f lanes closing + %.1f at a vertex each, %.0f ticks each; of it fetching %.1f%%) | wave ticks %llu\n",
-                        100 * h[0] / k, h[1], h[1] ? double(h[2]) / h[1] : 0.0, h[1] ? double(h[0]) / h[1] : 0.0, 100 * h[3] / k, h[4], h[4] ? double(h[5]) / h[4] : 0.0,
-                        100 * h[6] / k, h[7], h[7] ? double(h[9]) / h[7] : 0.0, h[7] ? double(h[10]) / h[7] : 0.0, h[7] ? double(h[6]) / h[7] : 0.0, 100 * h[11] / k, h[30]);
-            }
             if (h[25] + h[26] + h[27] + h[28] + h[29]) {   // -DGBL_STREAM_TM: the stream sampler's phases in an un-instrumented build
                 const double tot = static_cast<double>(h[25] + h[26] + h[27] + h[28] + h[29]);
                 fprintf(stderr, "stream phases (share of the workgroups' time): emit %.1f%% permute %.1f%% assemble %.1f%% paths %.1f%% skip %.1f%%\n",

@@ -88,8 +88,7 @@ gbl_render_kernel gbl_kernel_path(bool replay, bool stats, bool ext, bool exact_
 gbl_render_kernel gbl_kernel_ao(bool replay, bool stats, bool ext, bool exact_ties = false);
 // kernels_quad.hip: the megakernel whose sparse interior steps put four lanes on each ray (kernels/quadtrace.h)
 gbl_render_kernel gbl_kernel_path_quad(bool exact_ties);
-gbl_render_kernel gbl_kernel_path_quad_primary(bool exact_ties);
-gbl_render_kernel gbl_kernel_path_persist(void);   // kernels/persist.h: the lean path kernel with persistent traversal (needs the primary pass)   // ... its paths starting at RenderArgs::prim_hit (primary_kernel's output)
+gbl_render_kernel gbl_kernel_path_quad_primary(bool exact_ties);   // ... its paths starting at RenderArgs::prim_hit (primary_kernel's output)
 gbl_render_kernel gbl_kernel_path_stream_quad(void);
 gbl_render_kernel gbl_kernel_ao_quad(bool exact_ties);
 void gbl_launch_primary(const DevScene& sc, const RenderArgs& ra, bool exact_ties, float4* prim_hit, int32_t* prim_inst, unsigned blocks, hipStream_t stream);   // kernels/packet.h

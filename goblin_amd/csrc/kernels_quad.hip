@@ -3,7 +3,6 @@
 #include "gbl_internal.h"
 #include "kernels/render_kernels.h"
 #include "kernels/packet.h"
-#include "kernels/persist.h"
 
 // (the lean kernels of the native sampler only: the EXT builds are slower under the quad queries, the replay / instrumented builds
 //  run one ray per lane -- gbl_api.hip.  exact_ties: the reference's tie rule and reachability test kept, trace.h TIES)
@@ -13,7 +12,6 @@ gbl_render_kernel gbl_kernel_path_quad(bool exact_ties) {
 gbl_render_kernel gbl_kernel_path_quad_primary(bool exact_ties) {
     return exact_ties ? path_trace_kernel<GBL_SRC_NATIVE, false, false, true, true, true> : path_trace_kernel<GBL_SRC_NATIVE, false, false, true, false, true>;
 }
-gbl_render_kernel gbl_kernel_path_persist(void) { return path_persist_kernel; }
 gbl_render_kernel gbl_kernel_ao_quad(bool exact_ties) {
     return exact_ties ? ao_kernel<GBL_SRC_NATIVE, false, false, true, true> : ao_kernel<GBL_SRC_NATIVE, false, false, true>;
 }
