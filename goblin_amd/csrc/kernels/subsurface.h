@@ -6,8 +6,11 @@
 // One lane per camera sample of the launch's tiles (ids enumerate owned tile, pixel in tile, sample: consecutive lanes
 // are samples of one pixel, so the primary rays of a wave are coherent).  out[pixel * spp + k], pixel-major over the
 // render window like li_out.
+#ifndef GBL_SSS_WAVES
+#define GBL_SSS_WAVES 2   // 256 registers (left alone: 301 with 45 accumulation registers, one wave per SIMD)
+#endif
 template <bool REPLAY, bool STATS>
-__global__ __launch_bounds__(GBL_BLOCK) void sss_kernel(DevScene sc, RenderArgs ra, float4* out) {
+__global__ __launch_bounds__(GBL_BLOCK, GBL_SSS_WAVES) void sss_kernel(DevScene sc, RenderArgs ra, float4* out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x)};
     LaneCounters cnt = {};

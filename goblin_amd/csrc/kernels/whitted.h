@@ -268,10 +268,15 @@ __device__ F3 whitted_li(const DevScene& sc, const RenderArgs& ra, const SampleS
     }
 }
 
+// Two waves per SIMD (256 registers; the recursion frames live in scratch either way): left to itself the compiler takes 335 (79 of
+// them accumulation registers as spill space) and one wave per SIMD -- whitted.json 512^2 x 64 spp: 50.1 ms; held to 256: 31.5 ms.
+#ifndef GBL_WHITTED_WAVES
+#define GBL_WHITTED_WAVES 2
+#endif
 // One lane per camera sample (ids enumerate owned tile, pixel in tile, sample), per-sample radiance into `out`
 // (pixel-major like li_out); wf_splat filters it into the film.
 template <bool REPLAY, bool STATS>
-__global__ __launch_bounds__(GBL_BLOCK) void whitted_kernel(DevScene sc, RenderArgs ra, float4* out) {
+__global__ __launch_bounds__(GBL_BLOCK, GBL_WHITTED_WAVES) void whitted_kernel(DevScene sc, RenderArgs ra, float4* out) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsStack stk = {gbl_as_lds(reinterpret_cast<uint32_t*>(smem) + threadIdx.x)};
     LaneCounters cnt = {};
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(GBL_BLOCK) void whitted_kernel(DevScene sc, RenderA
 // whitted_li -- one workgroup per tile, per pixel the reference's records generated from the tile's mt19937, the S
 // samples traced, and the stream moved past the 6 floats per (light, slot) and 6 per specular level they discarded.
 template <bool STATS>
-__global__ __launch_bounds__(GBL_BLOCK) void whitted_stream_kernel(DevScene sc, RenderArgs ra, float4* out) {
+__global__ __launch_bounds__(GBL_BLOCK, GBL_WHITTED_WAVES) void whitted_stream_kernel(DevScene sc, RenderArgs ra, float4* out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(smem);
     uint32_t* stack = ctrl + 4 + GBL_STREAM_LDS_WORDS;
