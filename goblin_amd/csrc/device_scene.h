@@ -282,6 +282,7 @@ struct RenderArgs {
     float* image_xy;            // per camera sample (indexed like li_out): the image position its record held, for the splat
     const float* replay;        // Sample records for the sub-window, pixel-major
     const float* prim_hit;      // primary pass (kernels/packet.h): per camera sample {t, b1, b2, as_float(tri)} of the camera ray's hit ...
+    uint32_t* prim_items;       // ... per work item of the path kernel: nonzero when one of its camera rays did not simply miss (zeroed per call)
     const int32_t* prim_inst;   // ... and its instance, or GBL_PRIM_MISS / GBL_PRIM_TIED; null: the path kernel traces the camera rays itself
     uint32_t hot_count, hot_word;   // quad kernels: nodes[0 .. hot_count) also live in LDS, at word hot_word of the workgroup's block
     float* li_out;

@@ -651,6 +651,7 @@ void gbl_destroy(gbl_ctx* ctx) {
     for (void* p : ctx->allocations) (void)hipFree(p);
     if (ctx->wf_li) (void)hipFree(ctx->wf_li);
     if (ctx->prim_buf) (void)hipFree(ctx->prim_buf);
+    if (ctx->prim_items) (void)hipFree(ctx->prim_items);
     if (ctx->sss_buf) (void)hipFree(ctx->sss_buf);
     if (ctx->vol_buf) (void)hipFree(ctx->vol_buf);
     if (ctx->stream_seeds) (void)hipFree(ctx->stream_seeds);
@@ -1198,6 +1199,22 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                             return GBL_ERR_OOM;
                         }
                         ctx->prim_entries = entries;
+                    }
+                    {   // one word per work item of the path kernel
+                        const uint64_t items = static_cast<uint64_t>(ra.local_tiles) * ra.chunks;
+                        if (items > ctx->prim_items_cap) {
+                            if (ctx->prim_items) (void)hipFree(ctx->prim_items);
+                            ctx->prim_items = nullptr;
+                            ctx->prim_items_cap = 0;
+                            const hipError_t ie = hipMalloc(reinterpret_cast<void**>(&ctx->prim_items), items * sizeof(uint32_t));
+                            if (ie != hipSuccess) {
+                                ctx->error = std::string("hipMalloc(primary items): ") + hipGetErrorString(ie);
+                                return GBL_ERR_OOM;
+                            }
+                            ctx->prim_items_cap = items;
+                        }
+                        HIP_TRY(ctx, hipMemsetAsync(ctx->prim_items, 0, items * sizeof(uint32_t), stream));
+                        ra.prim_items = ctx->prim_items;
                     }
                     float4* ph = static_cast<float4*>(ctx->prim_buf);
                     int32_t* pi = reinterpret_cast<int32_t*>(ph + entries);

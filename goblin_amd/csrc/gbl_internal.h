@@ -23,6 +23,8 @@ struct gbl_ctx {
     uint32_t* work_counter = nullptr;
     void* prim_buf = nullptr;         // the primary pass's hits: entries x (float4 + int32)
     uint64_t prim_entries = 0;
+    uint32_t* prim_items = nullptr;   // ... and its word per work item of the path kernel (RenderArgs::prim_items)
+    uint64_t prim_items_cap = 0;
     unsigned long long* stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
         __syncthreads();
         const uint32_t item = ctrl[0];
         if (item >= n_items) break;
+        if (PRIM && ra.prim_items[item] == 0u) continue;   // (uniform) every camera ray of the item left the scene: the pass has written its Blacks
         const ItemInfo tile_item = decode_item(ra, item);
         const int tx0 = tile_item.px0 - sc.film.halo, ty0 = tile_item.py0 - sc.film.halo;
         if constexpr (STREAM) {
@@ -722,8 +723,7 @@ __global__ __launch_bounds__(GBL_BLOCK, EXT ? GBL_EXT_WAVES : GBL_PT_WAVES) void
                     const int px = it.px0 + pix % it.tw, py = it.py0 + pix / it.tw;
                     out_index = static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0])) * ra.spp + src.k;
                     hit.inst = ra.prim_inst[out_index];
-                    if (hit.inst == GBL_PRIM_MISS) {
-                        reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+                    if (hit.inst == GBL_PRIM_MISS) {   // (its Black is in li already: primary_kernel)
                         paths_done += 1;
                         continue;
                     }

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(GBL_BLOCK) void primary_kernel(DevScene sc, RenderA
             const size_t out_index = static_cast<size_t>(static_cast<uint32_t>((py - ra.window[2]) * sub_w + (px - ra.window[0]))) * ra.spp + k;
             if (h.inst >= 0 && !tied) prim_hit[out_index] = make_float4(h.t, h.b1, h.b2, __uint_as_float(h.tri));
             prim_inst[out_index] = tied ? GBL_PRIM_TIED : h.inst;   // (a miss: GBL_PRIM_MISS)
+            if (h.inst < 0 && !tied) {
+                // PathTracer::Li of a camera ray that left the scene: Black (:58-66, no image based light in the lean builds) ...
+                reinterpret_cast<float4*>(ra.li_defer)[out_index] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            } else {
+                // ... and the path kernel's work item (owned tile x chunk of samples) of every other sample has something to do
+                ra.prim_items[lt * ra.chunks + k / static_cast<uint32_t>(ra.chunk_spp)] = 1u;
+            }
         }
     }
 }
