@@ -797,6 +797,10 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
     const uint64_t want_items = 16ull * ctx->num_cus * 4;
     while (static_cast<uint64_t>(ra.local_tiles) * chunks < want_items && ra.spp / chunks > 4 && ra.spp % (chunks * 2) == 0)
         chunks *= 2;
+    if (const char* e = getenv("GBL_CHUNK_SPP")) {   // measurement aid: samples of a pixel per work item
+        const int c = atoi(e);
+        if (c >= 1 && ra.spp % c == 0) chunks = ra.spp / c;
+    }
     const bool stream_mode = p->sample_mode == GBL_SAMPLES_STREAM;
     if (stream_mode) chunks = 1;   // a work item is a whole tile, walked pixel by pixel (kernels/stream.h)
     ra.chunks = chunks;
@@ -1218,7 +1222,9 @@ static gbl_status gbl_render_impl(gbl_ctx* ctx, const gbl_render_params* p, floa
                     }
                     float4* ph = static_cast<float4*>(ctx->prim_buf);
                     int32_t* pi = reinterpret_cast<int32_t*>(ph + entries);
-                    gbl_launch_primary(sc, ra, p->exact_ties != 0, ph, pi, static_cast<unsigned>(ctx->num_cus) * 8u, stream);
+                    unsigned prim_wgs = 64u;   // workgroups per CU of the pass's grid-stride launch: 5 / 8 / 16 / 32 / 64 / 128 / 2048 -> 2.92 / 2.76 / 2.54 / 2.45 / 2.43 / 2.42 / 2.53 ms on configs[1]
+                    if (const char* e = getenv("GBL_PRIMARY_WGS")) prim_wgs = static_cast<unsigned>(std::min(4096, std::max(1, atoi(e))));   // measurement aid
+                    gbl_launch_primary(sc, ra, p->exact_ties != 0, ph, pi, static_cast<unsigned>(ctx->num_cus) * prim_wgs, stream);
                     HIP_TRY(ctx, hipGetLastError());
                     ra.prim_hit = reinterpret_cast<const float*>(ph);
                     ra.prim_inst = pi;
