@@ -79,3 +79,22 @@ def test_the_pass_leaves_the_tied_camera_rays_to_the_path_kernel(torch):
     li = r.render(seed=5150, want_li=True, schedule="megakernel", exact_ties=True)["li"].cpu().numpy()
     assert helpers.li_mismatch_fraction(li, li_ref) == 0.0
     np.testing.assert_array_equal(li[:, :3], li_ref[:, :3])
+
+
+def test_a_pass_that_does_not_fit_the_budget_is_left_out(torch):
+    """The pass keeps 20 bytes per camera sample beside the 16 of the per-sample radiance, both under GBL_LI_BUDGET_MB (a quarter of
+    the device by default): a call whose radiance fits and whose pass does not runs without the pass -- same radiance."""
+    from goblin_amd.renderer import HipPathTracer
+    scene = gs.load_scene("bunny", gs.config_overrides(resolution=(64, 64), spp=64, depth=4))
+    samples = scene.num_paths()
+    budget_mb = (samples * 18) >> 20                     # between 16 and 20 bytes per sample
+    assert samples * 16 <= budget_mb << 20 < samples * 20
+    ref = HipPathTracer(scene, 0).render(seed=77, want_li=True, schedule="megakernel")["li"]
+    os.environ["GBL_LI_BUDGET_MB"] = str(budget_mb)
+    try:
+        small = HipPathTracer(scene, 0).render(seed=77, want_li=False, schedule="megakernel")   # (its own radiance buffer: the budget applies)
+        again = HipPathTracer(scene, 0).render(seed=77, want_li=True, schedule="megakernel")["li"]
+    finally:
+        os.environ.pop("GBL_LI_BUDGET_MB", None)
+    assert torch.equal(again, ref)
+    assert np.isfinite(small["film"].numpy()).all()
