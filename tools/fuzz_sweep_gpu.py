@@ -19,7 +19,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         r = HipPathTracer(scene, 0)
         for schedule in (("megakernel",) if whitted else ("megakernel", "wavefront")):
             li = r.render(seed=99 + seed, want_li=True, schedule=schedule)["li"].cpu().numpy()
-            n = int(np.any(li != li_ref, axis=1).sum())
+            # (a NaN radiance -- the reference produces one now and then with a medium -- must be NaN on the device too)
+            n = int(np.any((li != li_ref) & ~(np.isnan(li) & np.isnan(li_ref)), axis=1).sum())
             if n:
                 bad.append((seed, whitted, schedule, n))
                 print("MISMATCH seed", seed, "whitted" if whitted else "pt", schedule, n, "of", li.shape[0], "volume", doc.get("volume", {}).get("type"),
